@@ -1,0 +1,123 @@
+/* ldn_hip.h -- C ABI of libldn_hip.so, the MI355X (gfx950) implementation of LAUDNet's
+ * dynamic-inference hot path (masker-driven masked bottleneck).
+ *
+ * The reference (LeapLabTHU/LAUDNet) has no FFI: its "operator API" is the Python nn.Module
+ * surface.  Each entry point below therefore cites the reference Python it
+ * replaces (paths relative to imagenet_classification/); the laudnet_amd python modules bind them with
+ * ctypes (INTEGRATION.md shows the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative LDN_E* code otherwise;
+ *     ldn_last_error() returns a thread-local message for the last failure on this thread;
+ *   - all data pointers are DEVICE pointers owned by the caller; nothing is allocated or freed;
+ *   - `stream` is a hipStream_t (pass NULL for the default stream); no entry point synchronises;
+ *   - activations are NHWC fp32 ("channels-last": one pixel = one contiguous row of C floats);
+ *   - index/count tensors are int32; masks are fp32 {0,1} like the reference's;
+ *   - data-dependent sizes (active-row counts, per-image channel counts) stay on the device:
+ *     grids are sized for the worst case and surplus workgroups exit on the device-side count.
+ */
+#ifndef LDN_HIP_H
+#define LDN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDN_OK 0
+#define LDN_EINVAL (-1)   /* bad argument (shape/alignment/unsupported combination) */
+#define LDN_EHIP (-2)     /* HIP runtime error at launch */
+
+const char* ldn_last_error(void);
+int ldn_version(void);
+/* number of compute units of the current device (used by callers to size persistent grids) */
+int ldn_device_cus(int* cus);
+
+/* ---- a1: Masker_spatial.forward, eval branch (models/utils.py:47-65) ------------------------
+ * x [B,Hi,Wi,C] NHWC -> adaptive average pool to SxS (only if S < Hi, utils.py:48; bins
+ * floor(i*H/S)..ceil((i+1)*H/S)) -> 1x1 conv C->2g (+bias) -> mask[b,j,y,x] = (l[j] >= l[g+j]).
+ * logits [B,2g,S,S] may be NULL.  mask [B,g,S,S] fp32 {0,1}. */
+int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w /*[2g,C]*/,
+                       const float* bias /*[2g]*/, int g, int S, float* mask, float* logits, void* stream);
+
+/* ---- a4/a11: F.interpolate(nearest) + ExpandMask x2 -> packed index lists -------------------
+ * (laud_resnet.py:106-110, models/utils.py:74-89).  patch_mask [B,S,S] fp32 {0,1} (one mask
+ * group) is up-sampled (nearest: src = min(floor(i*float(S)/float(Ho)), S-1)) to the output
+ * resolution Ho x Wo (= mask3 = mask2) and dilated to the block's input resolution
+ * Hi x Wi = Ho*stride x Wo*stride with a 3x3 box after zero-insertion (= mask1).
+ * Outputs (all row-major over b,y,x; "row" = flat pixel number b*H*W + y*W + x):
+ *   idx3 [B*Ho*Wo]   rows of set mask3 pixels (first cnt[0] entries valid)  == torch.nonzero
+ *   pos3 [B*Ho*Wo]   rank of the pixel in idx3, -1 if unset
+ *   idx1 [B*Hi*Wi]   rows of set mask1 pixels (first cnt[1] entries valid)
+ *   pos1 [B*Hi*Wi]   rank in idx1 or -1
+ *   nbr  [B*Ho*Wo*9] for packed output row r, tap t=ky*3+kx: rank in idx1 of input pixel
+ *                    (oy*stride-1+ky, ox*stride-1+kx), -1 if out of bounds
+ *   cnt  [2]         {#mask3 rows, #mask1 rows}
+ *   img_prefix3/1 [B+1]  exclusive per-image prefix of the two lists
+ *   stats [3]        {mean(patch_mask), mean(mask2 pixels), mean(mask1 pixels)}  (the three
+ *                    spatial sparsities of laud_resnet.py:98,108,110)
+ * work: int32 scratch of 3*B entries. */
+int ldn_mask_to_index(const float* patch_mask, int B, int S, int Ho, int Wo, int stride, int32_t* idx3,
+                      int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
+                      int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work, void* stream);
+
+/* ---- K2/K5: stand-alone row gather / masked scatter-add (DyNetSimulator simulate_gather,
+ * simulate_scatter_add; laud_resnet.py:133,143-144) ----------------------------------------- */
+/* packed[r,:] = src[rows[r],:] for r < *count (count==NULL -> cap) ; C % 4 == 0 */
+int ldn_gather_rows(const float* src, int ld_src, const int32_t* rows, const int32_t* count, int cap, int C,
+                    float* packed, int ld_packed, void* stream);
+/* out[rows[r],:] = relu(identity[rows[r],:] + packed[r,:]) ; out may alias identity */
+int ldn_scatter_add_relu(const float* packed, int ld_packed, const int32_t* rows, const int32_t* count, int cap,
+                         int C, const float* identity, int ld_id, float* out, int ld_out, void* stream);
+
+/* ---- a7 (spatial / layer mode): convolution over PACKED ROWS with shared weights ------------
+ * (laud_resnet.py:115-144 restricted to the active pixels; conv+BN(+ReLU) fused, fp32 MFMA)
+ *   acc[m,o] = sum_{t<taps} sum_{c<cin} A[a_rows[m*taps+t], c] * w[o, t, c]     (a_rows<0 -> 0)
+ *   v        = scale[o]*acc + shift[o]
+ *   dst row  = out_rows ? out_rows[m] : m
+ *   if residual: v += residual[dst row, o]
+ *   relu     : relu==1 always; relu==2 only where relu_if_neg[m] < 0; relu==0 never
+ *   out[dst row, o] = v                                   for m < *m_count (NULL -> m_cap)
+ * a_rows==NULL means A row m is row m (taps must be 1).  cin % 4 == 0, lda/ldo/ldr % 4 == 0. */
+int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
+                  const float* w, int cin, int cout, const float* scale, const float* shift, int relu,
+                  const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
+                  float* out, int ldo, void* stream);
+
+/* ---- a2: Masker_channel_MLP.forward, eval branch (models/utils.py:113-131) + index build ----
+ * x [B,HW,C] NHWC -> global average pool -> Linear(C,hidden)+ReLU+Linear(hidden,2G) (hidden>0)
+ * or Linear(C,2G) (hidden==0: w1=[2G,C], b1=[2G], w2/b2 unused) -> mask[b,j] = l[j] >= l[G+j].
+ * Also emits the per-image ACTIVE CHANNEL LIST over `width` = G*gran channels (group j owns
+ * channels [j*gran,(j+1)*gran), models/utils.py:18-25): ch_idx [B,width] left-packed ascending,
+ * ch_cnt [B].  logits [B,2G] may be NULL.  If mask_in != NULL the masker arithmetic is skipped
+ * and the lists are built from mask_in ("identical masks" parity runs).
+ * work: float scratch of B*splits*C + B*C entries, splits = ldn_channel_masker_splits(HW). */
+int ldn_channel_masker_splits(int HW);
+int ldn_channel_masker(const float* x, int B, int HW, int C, const float* w1, const float* b1, const float* w2,
+                       const float* b2, int hidden, int G, int gran, const float* mask_in, float* mask,
+                       float* logits, int32_t* ch_idx, int32_t* ch_cnt, float* work, void* stream);
+
+/* ---- a7 (channel mode): per-image channel-subset convolution --------------------------------
+ * (laud_resnet.py:115-144 with apply_channel_mask, models/utils.py:18-25; also the plain dense
+ * NHWC 1x1/3x3 conv when k_idx==n_idx==NULL, used for the downsample branch :138-141)
+ * For image b, output pixel p=(oy,ox), packed output column j (channel o = n_idx? n_idx[b,j] : j):
+ *   acc = sum_{tap} sum_{i<Kb} A[b, pix(p,tap), i] * w[o, tap, (k_idx? k_idx[b,i] : i)]
+ *         (Kb = k_cnt[b] or cin; 3x3 taps use pad 1, out-of-bounds taps contribute 0)
+ *   v   = scale[o]*acc + shift[cls(p)*cout + o]      cls = 0 if shift_classes==1, else the 4x4
+ *         border class (top|bottom<<1)*4 + (left|right<<1) of the taps that fall outside
+ *   if residual: v += residual[b,p,j] ; if relu: v = max(v,0) ; if post_sub: v -= post_sub[o]
+ *   out[b,p,j] = v for j < Nb (= n_cnt[b] or cout); columns Nb..roundup4(Nb)-1 are written 0.
+ * A columns are "left-packed": column i of image b is channel k_idx[b,i].
+ * kgran: every run of `kgran` consecutive k_idx entries is a run of consecutive channels
+ * (the channel_dyn_granularity); must divide every k_cnt. */
+int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, int stride, int Ho, int Wo,
+                   const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt, int kgran,
+                   const int32_t* n_idx, const int32_t* n_cnt, const float* scale, const float* shift,
+                   int shift_classes, const float* post_sub, int relu, const float* residual, int ldr,
+                   float* out, int ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDN_HIP_H */

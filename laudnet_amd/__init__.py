@@ -1,0 +1,11 @@
+"""laudnet_amd -- MI355X-native implementation of LAUDNet's dynamic-inference hot path.
+
+The package holds only what that path needs: `csrc/` (HIP kernels + the C ABI of include/ldn_hip.h),
+`_lib.py`/`ops.py` (ctypes binding) and `laud_resnet.py` (host-side mirror of the reference's
+nn.Module surface).  There is no CPU or PyTorch fallback for the hot path.
+"""
+from ._lib import LdnError, load as load_library  # noqa: F401
+from .laud_resnet import (Bottleneck, ExpandMask, Masker_channel_conv_linear, Masker_channel_MLP,  # noqa: F401
+                          Masker_spatial, ResNet, uni_resnet50, uni_resnet101)
+
+__version__ = "0.1.0"

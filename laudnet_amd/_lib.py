@@ -1,0 +1,76 @@
+"""ctypes binding of libldn_hip.so (include/ldn_hip.h).  There is NO fallback: if the library is
+missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libldn_hip.so")
+
+_P = C.c_void_p
+_I = C.c_int
+
+# name -> argtypes, in the order of include/ldn_hip.h
+SIGNATURES = {
+    "ldn_last_error": ([], C.c_char_p),
+    "ldn_version": ([], _I),
+    "ldn_device_cus": ([C.POINTER(_I)], _I),
+    "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P], _I),
+    "ldn_mask_to_index": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "ldn_gather_rows": ([_P, _I, _P, _P, _I, _I, _P, _I, _P], _I),
+    "ldn_scatter_add_relu": ([_P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P], _I),
+    "ldn_conv_rows": ([_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P], _I),
+    "ldn_channel_masker_splits": ([_I], _I),
+    "ldn_channel_masker": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "ldn_conv_image": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I,
+                        _P, _I, _P, _I, _P], _I),
+}
+
+_lib = None
+
+
+class LdnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises LdnError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LdnError(f"{LIB_PATH} not found: build it with `python -m laudnet_amd.build` "
+                       "(laudnet_amd has no CPU or PyTorch fallback for the hot path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().ldn_last_error()
+        raise LdnError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise LdnError("laudnet_amd ops need tensors on a HIP device (cuda:N); there is no CPU path")

@@ -1,0 +1,501 @@
+// Mask / index kernels of the LAUDNet hot path (gfx950): maskers, mask -> packed index lists
+// (wave64 ballot + popcount prefix sums), stand-alone row gather and masked scatter-add.
+#include <stdarg.h>
+
+#include "ldn_common.h"
+
+namespace ldn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// rank of this lane among the set lanes of `flag` in its wave, and the wave total
+__device__ __forceinline__ int wave_rank(bool flag, int& total) {
+    const unsigned long long m = __ballot(flag);
+    total = __popcll(m);
+    const int lane = threadIdx.x & 63;
+    return __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// Ordered compaction step for one chunk of 256 candidates (one per thread) inside a 256-thread block.
+// Returns the rank of this thread's element among the chunk's set flags (valid if flag), and adds the
+// chunk total to `running` (uniform across the block).  s_w: 4 ints of LDS.
+__device__ __forceinline__ int block_rank(bool flag, int* s_w, int& chunk_total) {
+    int wtot;
+    const int r = wave_rank(flag, wtot);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();  // protect s_w from the previous call
+    if ((threadIdx.x & 63) == 0) s_w[wave] = wtot;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) before += i < wave ? s_w[i] : 0;
+    chunk_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return before + r;
+}
+
+// ---------------------------------------------------------------------------------------- a1
+// one wave per (image, patch); lanes stride over channels.
+__global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict__ x, int B, int Hi, int Wi, int C,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         int g, int S, float* __restrict__ mask,
+                                                         float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool pooled = S < Hi;  // models/utils.py:48
+    const int Sy = pooled ? S : Hi, Sx = pooled ? S : Wi;
+    if (job >= B * Sy * Sx) return;
+    const int b = job / (Sy * Sx), pp = job - b * Sy * Sx;
+    const int py = pp / Sx, px = pp - py * Sx;
+    int y0 = py, y1 = py + 1, x0 = px, x1 = px + 1;
+    if (pooled) {  // adaptive pool bins: floor(i*H/S) .. ceil((i+1)*H/S)
+        y0 = (py * Hi) / S; y1 = ((py + 1) * Hi + S - 1) / S;
+        x0 = (px * Wi) / S; x1 = ((px + 1) * Wi + S - 1) / S;
+    }
+    const float inv = 1.f / float((y1 - y0) * (x1 - x0));
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    const int G2 = 2 * g;
+    for (int c = lane; c < C; c += 64) {
+        float s = 0.f;
+        for (int y = y0; y < y1; ++y)
+            for (int xx = x0; xx < x1; ++xx) s += x[((size_t)(b * Hi + y) * Wi + xx) * C + c];
+        s *= inv;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < G2) acc[o] += w[o * C + c] * s;
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = wave_sum(acc[o]);
+    if (lane < g) {
+        float lk = 0.f, ld = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            if (o == lane) lk = acc[o] + bias[o];
+            if (o == lane + g) ld = acc[o] + bias[o];
+        }
+        const size_t plane = (size_t)Sy * Sx;
+        mask[((size_t)b * g + lane) * plane + pp] = lk >= ld ? 1.f : 0.f;  // ties keep (utils.py:60)
+        if (logits) {
+            logits[((size_t)b * G2 + lane) * plane + pp] = lk;
+            logits[((size_t)b * G2 + g + lane) * plane + pp] = ld;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- a4 / a11
+struct IdxGeom {
+    int B, S, Ho, Wo, stride, Hi, Wi;
+};
+
+__device__ __forceinline__ int nearest_src(int i, float scale, int S) {
+    // ATen nearest: min(int(floorf(dst * scale)), in - 1), scale = float(in) / float(out)
+    const int s = (int)floorf((float)i * scale);
+    return s < S - 1 ? s : S - 1;
+}
+
+// fills s_m3[Ho*Wo] (bytes) for image b; returns nothing. all threads participate.
+__device__ __forceinline__ void fill_mask3(const float* __restrict__ patch, const IdxGeom g, int b,
+                                           unsigned char* s_m3) {
+    const float sh = (float)g.S / (float)g.Ho, sw = (float)g.S / (float)g.Wo;
+    const int n = g.Ho * g.Wo;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / g.Wo, x = i - y * g.Wo;
+        const int sy = nearest_src(y, sh, g.S), sx = nearest_src(x, sw, g.S);
+        s_m3[i] = patch[((size_t)b * g.S + sy) * g.S + sx] > 0.5f ? 1 : 0;
+    }
+}
+
+__device__ __forceinline__ bool mask1_at(const unsigned char* s_m3, const IdxGeom g, int iy, int ix) {
+    // set output pixels (oy,ox) with |iy - oy*s| <= 1 and |ix - ox*s| <= 1
+    const int s = g.stride;
+    int oy0 = (iy - 1 + s - 1) / s, oy1 = (iy + 1) / s;   // ceil((iy-1)/s) for iy-1 >= 0 ; clamp below
+    if (iy - 1 < 0) oy0 = 0;
+    int ox0 = (ix - 1 + s - 1) / s, ox1 = (ix + 1) / s;
+    if (ix - 1 < 0) ox0 = 0;
+    oy1 = oy1 < g.Ho - 1 ? oy1 : g.Ho - 1;
+    ox1 = ox1 < g.Wo - 1 ? ox1 : g.Wo - 1;
+    bool any = false;
+    for (int oy = oy0; oy <= oy1; ++oy)
+        for (int ox = ox0; ox <= ox1; ++ox) any |= s_m3[oy * g.Wo + ox] != 0;
+    return any;
+}
+
+__global__ __launch_bounds__(256) void k_mask_count(const float* __restrict__ patch, const IdxGeom g,
+                                                     int32_t* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_bytes[];
+    unsigned char* s_m3 = s_bytes;
+    __shared__ int s_red[3];
+    const int b = blockIdx.x;
+    if (threadIdx.x < 3) s_red[threadIdx.x] = 0;
+    fill_mask3(patch, g, b, s_m3);
+    __syncthreads();
+    int c3 = 0, c1 = 0, cp = 0;
+    for (int i = threadIdx.x; i < g.Ho * g.Wo; i += 256) c3 += s_m3[i];
+    for (int i = threadIdx.x; i < g.Hi * g.Wi; i += 256) {
+        const int iy = i / g.Wi, ix = i - iy * g.Wi;
+        c1 += mask1_at(s_m3, g, iy, ix) ? 1 : 0;
+    }
+    for (int i = threadIdx.x; i < g.S * g.S; i += 256) cp += patch[(size_t)b * g.S * g.S + i] > 0.5f ? 1 : 0;
+    atomicAdd(&s_red[0], c3);   // integer LDS atomics: order-independent
+    atomicAdd(&s_red[1], c1);
+    atomicAdd(&s_red[2], cp);
+    __syncthreads();
+    if (threadIdx.x < 3) work[threadIdx.x * g.B + b] = s_red[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ patch, const IdxGeom g,
+                                                     const int32_t* __restrict__ work, int32_t* __restrict__ idx3,
+                                                     int32_t* __restrict__ pos3, int32_t* __restrict__ idx1,
+                                                     int32_t* __restrict__ pos1, int32_t* __restrict__ nbr,
+                                                     int32_t* __restrict__ cnt, int32_t* __restrict__ pre3,
+                                                     int32_t* __restrict__ pre1, float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_bytes[];
+    const int HWo = g.Ho * g.Wo, HWi = g.Hi * g.Wi;
+    int* s_pos3 = reinterpret_cast<int*>(s_bytes);
+    int* s_pos1 = s_pos3 + HWo;
+    unsigned char* s_m3 = reinterpret_cast<unsigned char*>(s_pos1 + HWi);
+    __shared__ int s_w[4];
+    __shared__ int s_base[3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+
+    // exclusive prefix over the images before b (and, in the last block, the grand totals)
+    if (tid < 3) s_base[tid] = 0;
+    __syncthreads();
+    {
+        int a3 = 0, a1 = 0, ap = 0;
+        const bool last = b == g.B - 1;
+        const int upto = last ? g.B : b;
+        for (int i = tid; i < upto; i += 256) {
+            const bool own = i == b;  // only in the last block
+            a3 += own ? 0 : work[i];
+            a1 += own ? 0 : work[g.B + i];
+            ap += work[2 * g.B + i] * ((last || i < b) ? 1 : 0);
+        }
+        atomicAdd(&s_base[0], a3);
+        atomicAdd(&s_base[1], a1);
+        atomicAdd(&s_base[2], ap);
+    }
+    fill_mask3(patch, g, b, s_m3);
+    __syncthreads();
+    const int base3 = s_base[0], base1 = s_base[1];
+    if (tid == 0) {
+        pre3[b] = base3;
+        pre1[b] = base1;
+        if (b == g.B - 1) {
+            const int tot3 = base3 + work[b], tot1 = base1 + work[g.B + b];
+            pre3[g.B] = tot3;
+            pre1[g.B] = tot1;
+            cnt[0] = tot3;
+            cnt[1] = tot1;
+            stats[0] = (float)s_base[2] / (float)((long)g.B * g.S * g.S);
+            stats[1] = (float)tot3 / (float)((long)g.B * HWo);
+            stats[2] = (float)tot1 / (float)((long)g.B * HWi);
+        }
+    }
+
+    int running = 0;
+    for (int i0 = 0; i0 < HWo; i0 += 256) {
+        const int i = i0 + tid;
+        const bool f = i < HWo && s_m3[i];
+        int tot;
+        const int r = block_rank(f, s_w, tot);
+        if (i < HWo) {
+            const int p = f ? base3 + running + r : -1;
+            s_pos3[i] = p;
+            pos3[(size_t)b * HWo + i] = p;
+            if (f) idx3[p] = b * HWo + i;
+        }
+        running += tot;
+    }
+    running = 0;
+    for (int i0 = 0; i0 < HWi; i0 += 256) {
+        const int i = i0 + tid;
+        bool f = false;
+        if (i < HWi) {
+            const int iy = i / g.Wi, ix = i - iy * g.Wi;
+            f = mask1_at(s_m3, g, iy, ix);
+        }
+        int tot;
+        const int r = block_rank(f, s_w, tot);
+        if (i < HWi) {
+            const int p = f ? base1 + running + r : -1;
+            s_pos1[i] = p;
+            pos1[(size_t)b * HWi + i] = p;
+            if (f) idx1[p] = b * HWi + i;
+        }
+        running += tot;
+    }
+    __syncthreads();
+    for (int i = tid; i < HWo; i += 256) {
+        const int p = s_pos3[i];
+        if (p < 0) continue;
+        const int oy = i / g.Wo, ox = i - oy * g.Wo;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = oy * g.stride - 1 + t / 3, ix = ox * g.stride - 1 + t % 3;
+            const bool inb = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+            nbr[(size_t)p * 9 + t] = inb ? s_pos1[iy * g.Wi + ix] : -1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- K2 / K5
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, int ld_src,
+                                                      const int32_t* __restrict__ rows,
+                                                      const int32_t* __restrict__ count, int cap, int C4,
+                                                      float* __restrict__ packed, int ld_packed) {
+    const int n = count ? min(*count, cap) : cap;
+    const long total = (long)n * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / C4), q = (int)(i - (long)r * C4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)rows[r] * ld_src + q * 4);
+        *reinterpret_cast<f32x4*>(packed + (size_t)r * ld_packed + q * 4) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_add_relu(const float* __restrict__ packed, int ld_packed,
+                                                           const int32_t* __restrict__ rows,
+                                                           const int32_t* __restrict__ count, int cap, int C4,
+                                                           const float* identity, int ld_id, float* out,
+                                                           int ld_out) {
+    const int n = count ? min(*count, cap) : cap;
+    const long total = (long)n * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / C4), q = (int)(i - (long)r * C4);
+        const size_t row = (size_t)rows[r];
+        f32x4 v = *reinterpret_cast<const f32x4*>(packed + (size_t)r * ld_packed + q * 4);
+        const f32x4 id = *reinterpret_cast<const f32x4*>(identity + row * ld_id + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + id[e], 0.f);
+        *reinterpret_cast<f32x4*>(out + row * ld_out + q * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- a2
+// partial[b][s][c] = sum over rows of split s of x[b][row][c]   (deterministic two-stage GAP)
+__global__ __launch_bounds__(256) void k_gap_partial(const float* __restrict__ x, int HW, int C, int splits,
+                                                      float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float s_f[];
+    const int b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int Q = C >> 2;
+    const int per = ceil_div(HW, splits);
+    const int r0 = s * per, r1 = min(r0 + per, HW);
+    const int RL = Q >= 256 ? 1 : 256 / Q;            // row lanes
+    const int rl = Q >= 256 ? 0 : tid / Q;
+    const float* xb = x + (size_t)b * HW * C;
+    for (int q0 = 0; q0 < Q; q0 += 256) {
+        const int q = q0 + (Q >= 256 ? tid : tid % Q);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (q < Q && rl < RL)
+            for (int r = r0 + rl; r < r1; r += RL) acc += *reinterpret_cast<const f32x4*>(xb + (size_t)r * C + q * 4);
+        if (RL > 1) {
+            __syncthreads();
+            if (rl < RL) *reinterpret_cast<f32x4*>(s_f + ((size_t)rl * Q + q) * 4) = acc;
+            __syncthreads();
+            if (rl == 0) {
+                for (int k = 1; k < RL; ++k) acc += *reinterpret_cast<const f32x4*>(s_f + ((size_t)k * Q + q) * 4);
+            }
+        }
+        if (q < Q && rl == 0)
+            *reinterpret_cast<f32x4*>(partial + ((size_t)b * splits + s) * C + q * 4) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ partial, int HW, int C, int splits,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      int hidden, int G, int gran, const float* __restrict__ mask_in,
+                                                      float* __restrict__ mask, float* __restrict__ logits,
+                                                      int32_t* __restrict__ ch_idx, int32_t* __restrict__ ch_cnt) {
+    extern __shared__ __attribute__((aligned(16))) float s_f[];
+    float* s_gap = s_f;                 // [C]
+    float* s_hid = s_gap + C;           // [max(hidden,1)]
+    float* s_log = s_hid + (hidden > 0 ? hidden : 1);  // [2G]
+    __shared__ int s_w[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G2 = 2 * G;
+    if (!mask_in) {
+        const float inv = 1.f / (float)HW;
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
+            s_gap[c] = s * inv;
+        }
+        __syncthreads();
+        const int n1 = hidden > 0 ? hidden : G2;     // outputs of the first (or only) layer
+        float* dst1 = hidden > 0 ? s_hid : s_log;
+        for (int o = wave; o < n1; o += 4) {
+            float a = 0.f;
+            for (int c = lane; c < C; c += 64) a += w1[(size_t)o * C + c] * s_gap[c];
+            a = wave_sum(a);
+            if (lane == 0) {
+                a += b1[o];
+                dst1[o] = hidden > 0 ? fmaxf(a, 0.f) : a;
+            }
+        }
+        __syncthreads();
+        if (hidden > 0) {
+            for (int o = tid; o < G2; o += 256) {
+                float a = b2[o];
+                for (int j = 0; j < hidden; ++j) a += w2[(size_t)o * hidden + j] * s_hid[j];
+                s_log[o] = a;
+            }
+            __syncthreads();
+        }
+        for (int j = tid; j < G; j += 256) mask[(size_t)b * G + j] = s_log[j] >= s_log[G + j] ? 1.f : 0.f;
+        if (logits)
+            for (int o = tid; o < G2; o += 256) logits[(size_t)b * G2 + o] = s_log[o];
+    } else {
+        for (int j = tid; j < G; j += 256) mask[(size_t)b * G + j] = mask_in[(size_t)b * G + j];
+    }
+    __syncthreads();
+    // ordered compaction of the active channels (group j owns [j*gran, (j+1)*gran))
+    const int width = G * gran;
+    int running = 0;
+    for (int c0 = 0; c0 < width; c0 += 256) {
+        const int c = c0 + tid;
+        bool f = false;
+        if (c < width) {
+            const int j = c / gran;
+            f = mask_in ? mask_in[(size_t)b * G + j] > 0.5f : s_log[j] >= s_log[G + j];
+        }
+        int tot;
+        const int r = block_rank(f, s_w, tot);
+        if (f) ch_idx[(size_t)b * width + running + r] = c;
+        running += tot;
+    }
+    if (tid == 0) ch_cnt[b] = running;
+}
+
+}  // namespace ldn
+
+using namespace ldn;
+
+extern "C" const char* ldn_last_error(void) { return g_err; }
+extern "C" int ldn_version(void) { return 100; }
+extern "C" int ldn_device_cus(int* cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        set_error("ldn_device_cus: no HIP device");
+        return LDN_EHIP;
+    }
+    *cus = prop.multiProcessorCount;
+    return LDN_OK;
+}
+
+extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w, const float* bias,
+                                  int g, int S, float* mask, float* logits, void* stream) {
+    LDN_REQUIRE(x && w && bias && mask, "ldn_spatial_masker: null pointer");
+    LDN_REQUIRE(g >= 1 && g <= 4, "ldn_spatial_masker: mask groups must be 1..4 (got %d)", g);
+    LDN_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C > 0 && S > 0, "ldn_spatial_masker: bad shape");
+    const bool pooled = S < Hi;
+    const long jobs = (long)B * (pooled ? S * S : Hi * Wi);
+    hipLaunchKernelGGL(k_spatial_masker, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, B, Hi, Wi, C, w, bias, g, S, mask, logits);
+    LDN_CHECK_LAUNCH("k_spatial_masker");
+    return LDN_OK;
+}
+
+extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Ho, int Wo, int stride, int32_t* idx3,
+                                 int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
+                                 int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work,
+                                 void* stream) {
+    LDN_REQUIRE(patch_mask && idx3 && pos3 && idx1 && pos1 && nbr && cnt && img_prefix3 && img_prefix1 && stats && work,
+                "ldn_mask_to_index: null pointer");
+    LDN_REQUIRE(B > 0 && S > 0 && Ho > 0 && Wo > 0 && stride >= 1, "ldn_mask_to_index: bad shape");
+    LDN_REQUIRE((long)B * Ho * stride * Wo * stride < (1l << 31), "ldn_mask_to_index: index space exceeds int32");
+    IdxGeom g{B, S, Ho, Wo, stride, Ho * stride, Wo * stride};
+    const size_t lds1 = (size_t)Ho * Wo;
+    const size_t lds2 = (size_t)Ho * Wo * 5 + (size_t)g.Hi * g.Wi * 4;
+    LDN_REQUIRE(lds2 <= 150 * 1024, "ldn_mask_to_index: feature map %dx%d too large for the LDS-resident index build", g.Hi, g.Wi);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mask_index), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        configured = true;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_mask_count, dim3(B), dim3(256), lds1, st, patch_mask, g, work);
+    LDN_CHECK_LAUNCH("k_mask_count");
+    hipLaunchKernelGGL(k_mask_index, dim3(B), dim3(256), lds2, st, patch_mask, g, work, idx3, pos3, idx1, pos1, nbr,
+                       cnt, img_prefix3, img_prefix1, stats);
+    LDN_CHECK_LAUNCH("k_mask_index");
+    return LDN_OK;
+}
+
+static unsigned stream_grid(long work_items) {
+    long blocks = (work_items + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+extern "C" int ldn_gather_rows(const float* src, int ld_src, const int32_t* rows, const int32_t* count, int cap,
+                               int C, float* packed, int ld_packed, void* stream) {
+    LDN_REQUIRE(src && rows && packed, "ldn_gather_rows: null pointer");
+    LDN_REQUIRE(C > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_packed % 4 == 0, "ldn_gather_rows: C and strides must be multiples of 4");
+    if (cap <= 0) return LDN_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3(stream_grid((long)cap * (C / 4))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, ld_src, rows, count, cap, C / 4, packed, ld_packed);
+    LDN_CHECK_LAUNCH("k_gather_rows");
+    return LDN_OK;
+}
+
+extern "C" int ldn_scatter_add_relu(const float* packed, int ld_packed, const int32_t* rows, const int32_t* count,
+                                    int cap, int C, const float* identity, int ld_id, float* out, int ld_out,
+                                    void* stream) {
+    LDN_REQUIRE(packed && rows && identity && out, "ldn_scatter_add_relu: null pointer");
+    LDN_REQUIRE(C > 0 && C % 4 == 0 && ld_packed % 4 == 0 && ld_id % 4 == 0 && ld_out % 4 == 0,
+                "ldn_scatter_add_relu: C and strides must be multiples of 4");
+    if (cap <= 0) return LDN_OK;
+    hipLaunchKernelGGL(k_scatter_add_relu, dim3(stream_grid((long)cap * (C / 4))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), packed, ld_packed, rows, count, cap, C / 4, identity, ld_id,
+                       out, ld_out);
+    LDN_CHECK_LAUNCH("k_scatter_add_relu");
+    return LDN_OK;
+}
+
+extern "C" int ldn_channel_masker_splits(int HW) {
+    int s = HW / 256;
+    if (s < 1) s = 1;
+    if (s > 16) s = 16;
+    return s;
+}
+
+extern "C" int ldn_channel_masker(const float* x, int B, int HW, int C, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, int hidden, int G, int gran, const float* mask_in,
+                                  float* mask, float* logits, int32_t* ch_idx, int32_t* ch_cnt, float* work,
+                                  void* stream) {
+    LDN_REQUIRE(mask && ch_idx && ch_cnt, "ldn_channel_masker: null output pointer");
+    LDN_REQUIRE(B > 0 && G > 0 && gran > 0, "ldn_channel_masker: bad shape");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int splits = ldn_channel_masker_splits(HW);
+    if (!mask_in) {
+        LDN_REQUIRE(x && w1 && b1 && work, "ldn_channel_masker: null pointer");
+        LDN_REQUIRE(hidden == 0 || (w2 && b2), "ldn_channel_masker: two-layer masker needs w2/b2");
+        LDN_REQUIRE(HW > 0 && C > 0 && C % 4 == 0, "ldn_channel_masker: C must be a positive multiple of 4");
+        const int Q = C / 4;
+        const size_t lds = Q >= 256 ? 0 : (size_t)(256 / Q) * Q * 4 * sizeof(float);
+        hipLaunchKernelGGL(k_gap_partial, dim3(splits, B), dim3(256), lds, st, x, HW, C, splits, work);
+        LDN_CHECK_LAUNCH("k_gap_partial");
+    }
+    const size_t lds2 = (size_t)(C + (hidden > 0 ? hidden : 1) + 2 * G) * sizeof(float);
+    hipLaunchKernelGGL(k_channel_mlp, dim3(B), dim3(256), lds2, st, work, HW, C, splits, w1, b1, w2, b2, hidden, G, gran,
+                       mask_in, mask, logits, ch_idx, ch_cnt);
+    LDN_CHECK_LAUNCH("k_channel_mlp");
+    return LDN_OK;
+}

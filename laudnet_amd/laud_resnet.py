@@ -1,0 +1,560 @@
+"""LAUD-ResNet on the MI355X HIP path: host-side mirror of the reference's nn.Module surface.
+
+Same class names, constructor kwargs, sub-module attribute names (hence state_dict keys/shapes),
+`forward(x, temperature)` 7-tuple and `get_optim_policies()` as the reference's
+imagenet_classification/models/laud_resnet.py + models/utils.py, so its checkpoints load unchanged
+(SURVEY.md 8b).  What differs is how a block is executed: instead of dense conv x mask emulation
+(laud_resnet.py:115-133) the dynamic bottleneck runs only the active work through libldn_hip.so:
+
+  spatial / layer : patch mask -> ldn_mask_to_index -> conv1 on the dilated pixel list (gather on load)
+                    -> 3x3 conv through the neighbour table -> 1x1 conv + BN + residual scatter-add + ReLU
+  channel         : GAP+MLP masker -> per-image active-channel lists -> three ragged per-image GEMMs
+                    (output-, input/output-, input-channel subsets), pre-BN mask constants folded into
+                    image-independent shift tables (DESIGN.md "channel algebra")
+
+The hot path has NO PyTorch/CPU fallback: training mode, CPU tensors or a missing library raise.
+Build-only extension (default off): `forced_spatial_mask` / `forced_channel_mask` on a block inject
+masks for "identical inputs/masks" parity runs (mask_override).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import LdnError
+
+__all__ = ["uni_resnet50", "uni_resnet101", "ResNet", "Bottleneck", "Masker_spatial", "Masker_channel_MLP",
+           "Masker_channel_conv_linear", "ExpandMask"]
+
+
+def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):
+    return nn.Conv2d(in_planes, out_planes, 3, stride=stride, padding=dilation, groups=groups, bias=False,
+                     dilation=dilation)
+
+
+def conv1x1(in_planes, out_planes, stride=1, bias=False):
+    return nn.Conv2d(in_planes, out_planes, 1, stride=stride, bias=bias)
+
+
+def _fold_bn(bn: nn.BatchNorm2d):
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias - bn.running_mean * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+def _eval_only(module: nn.Module, x: torch.Tensor):
+    if module.training:
+        raise LdnError("laudnet_amd implements the eval-mode (inference) hot path only; call model.eval() "
+                       "(training-mode Gumbel masks are SURVEY 8f-4, not built)")
+    if not x.is_cuda:
+        raise LdnError("laudnet_amd has no CPU path: move the model and input to a HIP device")
+
+
+class _PrepCache(nn.Module):
+    """Mixin: lazily built, device-resident folded weights; dropped when parameters may have changed."""
+
+    def _init_cache(self):
+        self._prep = None
+        self.register_load_state_dict_post_hook(lambda m, _k: m._drop_cache())
+
+    def _drop_cache(self):
+        self._prep = None
+
+    def train(self, mode: bool = True):
+        self._prep = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **kw):
+        self._prep = None
+        return super()._apply(fn, *a, **kw)
+
+
+# ------------------------------------------------------------------------------------------- maskers
+class Masker_spatial(_PrepCache):
+    """models/utils.py:35-65.  HIP: ldn_spatial_masker."""
+
+    def __init__(self, in_channels, mask_channel_group, mask_size):
+        super().__init__()
+        self.mask_channel_group = mask_channel_group
+        self.mask_size = mask_size
+        self.conv = conv1x1(in_channels, mask_channel_group * 2, bias=True)
+        self.conv_flops_pp = self.conv.weight.shape[0] * self.conv.weight.shape[1] + self.conv.weight.shape[1]
+        self.conv.bias.data[:mask_channel_group] = 5.0
+        self.conv.bias.data[mask_channel_group + 1:] = 0.0
+        self._init_cache()
+
+    def flops_for(self, x):
+        if self.mask_size < x.shape[2]:
+            h = w = self.mask_size
+        else:
+            h, w = x.shape[2], x.shape[3]
+        return x.shape[1] * h * w + self.conv_flops_pp * h * w
+
+    def forward(self, x, temperature, want_logits=False):
+        _eval_only(self, x)
+        if self._prep is None:
+            with torch.no_grad():
+                self._prep = (self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1).float().contiguous(),
+                              self.conv.bias.detach().float().contiguous())
+        w, b = self._prep
+        mask, logits = ops.spatial_masker(ops.as_nhwc(x), w, b, self.mask_channel_group, self.mask_size, want_logits)
+        out = (mask, mask.mean(), self.flops_for(x))
+        return out + (logits,) if want_logits else out
+
+
+class ExpandMask(nn.Module):
+    """models/utils.py:67-89.  Parameter-free; in the HIP path the dilation is part of ldn_mask_to_index
+    (the dilated mask IS conv1's gather list).  forward() is kept for API parity (one mask group)."""
+
+    def __init__(self, stride, padding=1, mask_channel_group=1):
+        super().__init__()
+        self.stride, self.padding, self.mask_channel_group = stride, padding, mask_channel_group
+
+    def forward(self, x):
+        if x.shape[1] != 1 or self.padding not in (0, 1) or (self.padding == 0 and self.stride != 1):
+            raise LdnError("ExpandMask on the HIP path supports one mask group and (stride,1)/(1,0) dilation")
+        if self.padding == 0:
+            return x > 0.5
+        b, _, h, w = x.shape
+        ix = ops.mask_to_index(x[:, 0].float().contiguous(), h, w, self.stride)
+        return (ix.pos1 >= 0).view(b, 1, h * self.stride, w * self.stride)
+
+
+class Masker_channel_MLP(_PrepCache):
+    """models/utils.py:92-131.  HIP: ldn_channel_masker (GAP + MLP + >= + active-channel list)."""
+
+    def __init__(self, in_channels, channel_dyn_group, layers=2, reduction=16):
+        super().__init__()
+        assert layers in [1, 2]
+        self.channel_dyn_group = channel_dyn_group
+        width = max(channel_dyn_group // reduction, 16)
+        self.conv = nn.Sequential(nn.Linear(in_channels, width), nn.ReLU(),
+                                  nn.Linear(width, channel_dyn_group * 2, bias=True)) if layers == 2 \
+            else nn.Linear(in_channels, channel_dyn_group * 2, bias=True)
+        self.conv_flops = in_channels * width + width * channel_dyn_group * 2 if layers == 2 \
+            else in_channels * channel_dyn_group * 2
+        last = self.conv[-1] if layers == 2 else self.conv
+        last.bias.data[:channel_dyn_group] = 2.0
+        last.bias.data[channel_dyn_group + 1:] = -2.0
+        self.layers = layers
+        self._init_cache()
+
+    def flops_for(self, x):
+        return x.shape[1] * x.shape[2] * x.shape[3] + self.conv_flops
+
+    def _weights(self):
+        if self._prep is None:
+            with torch.no_grad():
+                f = lambda t: t.detach().float().contiguous()
+                if self.layers == 2:
+                    self._prep = (f(self.conv[0].weight), f(self.conv[0].bias), f(self.conv[2].weight),
+                                  f(self.conv[2].bias))
+                else:
+                    self._prep = (f(self.conv.weight), f(self.conv.bias), None, None)
+        return self._prep
+
+    def lists(self, x, gran, mask_in=None, want_logits=False):
+        """-> (mask [B,G], ch_idx [B,G*gran], ch_cnt [B], logits)"""
+        if mask_in is not None:
+            return ops.channel_masker(None, None, None, None, None, self.channel_dyn_group, gran,
+                                      mask_in=mask_in.float().contiguous())
+        w1, b1, w2, b2 = self._weights()
+        return ops.channel_masker(ops.as_nhwc(x), w1, b1, w2, b2, self.channel_dyn_group, gran, want_logits=want_logits)
+
+    def forward(self, x, temperature):
+        _eval_only(self, x)
+        mask, _, _, _ = self.lists(x, 1)
+        return mask, torch.mean(mask), self.flops_for(x)
+
+
+class Masker_channel_conv_linear(_PrepCache):
+    """models/utils.py:133-169: 1x1 conv + BN + ReLU on the full map, GAP, Linear.
+    HIP: dense ldn_conv_image for the 1x1 conv, then ldn_channel_masker with a single linear layer."""
+
+    def __init__(self, in_channels, channel_dyn_group, reduction=16):
+        super().__init__()
+        self.channel_dyn_group = channel_dyn_group
+        mid = in_channels // reduction
+        self.conv = nn.Sequential(conv1x1(in_channels, mid), nn.BatchNorm2d(mid), nn.ReLU())
+        self.linear = nn.Linear(mid, channel_dyn_group * 2, bias=True)
+        self.linear.bias.data[:channel_dyn_group] = 2.0
+        self.linear.bias.data[channel_dyn_group + 1:] = -2.0
+        self.masker_flops = in_channels * in_channels // reduction + mid * channel_dyn_group * 2
+        self.mid = mid
+        self._init_cache()
+
+    def flops_for(self, x):
+        return self.mid * x.shape[2] * x.shape[3] + self.masker_flops
+
+    def lists(self, x, gran, mask_in=None, want_logits=False):
+        if mask_in is not None:
+            return ops.channel_masker(None, None, None, None, None, self.channel_dyn_group, gran,
+                                      mask_in=mask_in.float().contiguous())
+        if self.mid % 4 != 0:
+            raise LdnError("Masker_channel_conv_linear on the HIP path needs in_channels//reduction % 4 == 0")
+        if self._prep is None:
+            with torch.no_grad():
+                sc, sh = _fold_bn(self.conv[1])
+                self._prep = (self.conv[0].weight.detach().reshape(self.mid, 1, -1).float().contiguous(), sc, sh,
+                              self.linear.weight.detach().float().contiguous(),
+                              self.linear.bias.detach().float().contiguous())
+        w, sc, sh, lw, lb = self._prep
+        xn = ops.as_nhwc(x)
+        b, h, wd, _ = xn.shape
+        y = torch.empty(b, h, wd, self.mid, device=x.device, dtype=torch.float32)
+        ops.conv_image(xn, w, sc, sh, y, relu=1)
+        return ops.channel_masker(y, lw, lb, None, None, self.channel_dyn_group, gran, want_logits=want_logits)
+
+    def forward(self, x, temperature):
+        _eval_only(self, x)
+        mask, _, _, _ = self.lists(x, 1)
+        return mask, torch.mean(mask), self.flops_for(x)
+
+
+# ------------------------------------------------------------------------------------------- block
+class Bottleneck(_PrepCache):
+    """models/laud_resnet.py:24-165, executed sparsely on the HIP path."""
+    expansion = 4
+    __constants__ = ["downsample"]
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, group_width=1, dilation=1, norm_layer=None,
+                 spatial_mask_channel_group=1, channel_dyn_granularity=1, output_size=56,
+                 mask_spatial_granularity=1, dyn_mode="both", channel_masker="conv_linear",
+                 channel_masker_layers=2, reduction=16):
+        super().__init__()
+        assert dyn_mode in ["channel", "spatial", "both", "layer"]
+        assert channel_masker in ["conv_linear", "MLP"]
+        self.dyn_mode = dyn_mode
+        if norm_layer is None:
+            norm_layer = nn.BatchNorm2d
+        width = int(planes * (64 / 64.)) * group_width
+        assert channel_dyn_granularity <= width
+        channel_dyn_group = width // channel_dyn_granularity
+        self.conv1 = conv1x1(inplanes, width)
+        self.bn1 = norm_layer(width)
+        self.conv2 = conv3x3(width, width, stride, group_width, dilation)
+        self.bn2 = norm_layer(width)
+        self.conv3 = conv1x1(width, planes * self.expansion)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self.width = width
+        self.channel_dyn_granularity = channel_dyn_granularity
+
+        self.conv1_flops_per_pixel = inplanes * width
+        self.conv2_flops_per_pixel = width * width * 9 // self.conv2.groups
+        self.conv3_flops_per_pixel = width * planes * self.expansion
+        if self.downsample is not None:
+            self.downsample_flops = inplanes * planes * self.expansion
+
+        self.output_size = output_size
+        self.mask_spatial_granularity = mask_spatial_granularity
+        self.mask_size = self.output_size // self.mask_spatial_granularity if dyn_mode != "layer" else 1
+        self.masker_spatial = None
+        self.masker_channel = None
+        if dyn_mode in ["spatial", "layer", "both"]:
+            self.masker_spatial = Masker_spatial(inplanes, spatial_mask_channel_group, self.mask_size)
+            self.mask_expander2 = ExpandMask(stride=1, padding=0, mask_channel_group=spatial_mask_channel_group)
+            self.mask_expander1 = ExpandMask(stride=stride, padding=1, mask_channel_group=spatial_mask_channel_group)
+        if dyn_mode in ["channel", "both"]:
+            if channel_masker == "conv_linear":
+                self.masker_channel = Masker_channel_conv_linear(inplanes, channel_dyn_group, reduction=reduction)
+            else:
+                self.masker_channel = Masker_channel_MLP(inplanes, channel_dyn_group, layers=channel_masker_layers,
+                                                         reduction=reduction)
+        # build-only hooks (default off)
+        self.forced_spatial_mask = None
+        self.forced_channel_mask = None
+        self.inplace_residual = False   # set by ResNet for its own intermediate tensors
+        self._init_cache()
+
+    # ---- folded, device-resident parameters -------------------------------------------------
+    def _prepare(self, device):
+        if self.conv2.groups != 1 or self.conv2.dilation[0] != 1:
+            raise LdnError("HIP path: grouped / dilated conv2 (ResNeXt, dilated ResNet) is not built")
+        with torch.no_grad():
+            W = self.width
+            p = {}
+            p["w1"] = self.conv1.weight.detach().reshape(W, 1, -1).float().contiguous()
+            p["w2"] = self.conv2.weight.detach().permute(0, 2, 3, 1).reshape(W, 9, W).float().contiguous()
+            p["w3"] = self.conv3.weight.detach().reshape(-1, 1, W).float().contiguous()
+            p["s1"], p["t1"] = _fold_bn(self.bn1)
+            p["s2"], p["t2"] = _fold_bn(self.bn2)
+            p["s3"], p["t3"] = _fold_bn(self.bn3)
+            if self.downsample is not None:
+                dconv, dbn = self.downsample[0], self.downsample[1]
+                p["wd"] = dconv.weight.detach().reshape(dconv.out_channels, 1, -1).float().contiguous()
+                p["sd"], p["td"] = _fold_bn(dbn)
+                p["ds_stride"] = dconv.stride[0]
+            if self.dyn_mode in ("channel", "both"):
+                # Channel algebra: a masked channel k of conv1's output is the CONSTANT
+                # c1[k] = relu(t1[k]) (mask applied before BN, laud_resnet.py:116-118).  Writing
+                # h1 = u1 + c1 with u1 = 0 on masked channels makes conv2 = W2[A,A] (*) u1 + (W2 (*) c1),
+                # whose second term does not depend on the image: 16 border classes x W shifts.
+                c1 = torch.relu(p["t1"])
+                c2 = torch.relu(p["t2"])
+                wc = torch.einsum("okyx,k->oyx", self.conv2.weight.detach().float(), c1)  # [W,3,3]
+                tab = torch.empty(16, W, device=wc.device)
+                for cls in range(16):
+                    rb, cb = cls // 4, cls % 4
+                    ys = [ky for ky in range(3) if not ((ky == 0 and rb & 1) or (ky == 2 and rb & 2))]
+                    xs = [kx for kx in range(3) if not ((kx == 0 and cb & 1) or (kx == 2 and cb & 2))]
+                    v = wc[:, ys][:, :, xs].sum(dim=(1, 2))
+                    tab[cls] = p["t2"] + p["s2"] * v
+                p["c1"], p["c2"], p["t2_tab"] = c1.contiguous(), c2.contiguous(), tab.contiguous()
+                bias3 = self.conv3.weight.detach().reshape(-1, W).float() @ c2
+                p["t3c"] = (p["t3"] + p["s3"] * bias3).contiguous()
+            self._prep = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in p.items()}
+        return self._prep
+
+    # ---- execution ----------------------------------------------------------------------------
+    def _run_channel(self, x, p):
+        B, Cin, Hi, Wi = x.shape
+        W, gran = self.width, self.channel_dyn_granularity
+        Ho, Wo = (Hi - 1) // self.stride + 1, (Wi - 1) // self.stride + 1
+        xn = ops.as_nhwc(x)
+        mask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
+        dev = x.device
+        h1 = torch.empty(B, Hi, Wi, W, device=dev, dtype=torch.float32)
+        ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1)
+        h2 = torch.empty(B, Ho, Wo, W, device=dev, dtype=torch.float32)
+        ops.conv_image(h1, p["w2"], p["s2"], p["t2_tab"], h2, ksize=3, stride=self.stride, k_idx=idx, k_cnt=cnt,
+                       kgran=gran, n_idx=idx, n_cnt=cnt, post_sub=p["c2"], relu=1)
+        cout = p["w3"].shape[0]
+        if self.downsample is not None:
+            identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
+            ops.conv_image(xn, p["wd"], p["sd"], p["td"], identity, stride=p["ds_stride"], relu=0)
+            out = identity
+        else:
+            identity = xn
+            out = xn if self.inplace_residual else torch.empty_like(xn)
+        ops.conv_image(h2, p["w3"], p["s3"], p["t3c"], out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1,
+                       residual=identity)
+        return ops.from_nhwc(out), mask
+
+    def _run_spatial(self, x, p):
+        B, Cin, Hi, Wi = x.shape
+        W = self.width
+        Ho = Wo = self.output_size
+        if Hi != Ho * self.stride or Wi != Wo * self.stride:
+            raise LdnError(f"Bottleneck: input {Hi}x{Wi} does not match output_size {Ho} * stride {self.stride}")
+        ms = self.masker_spatial
+        if ms.mask_channel_group != 1:
+            raise LdnError("HIP path: spatial_mask_channel_group > 1 is not built (all shipped configs use 1)")
+        xn = ops.as_nhwc(x)
+        if self.forced_spatial_mask is not None:
+            patch = self.forced_spatial_mask.to(device=x.device, dtype=torch.float32).contiguous()
+        else:
+            patch = ms(x, 1.0)[0]
+        ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, self.stride)
+        dev = x.device
+        x2d = xn.reshape(B * Hi * Wi, Cin)
+        h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
+        ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
+        h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
+        ops.conv_rows(h1, p["w2"], p["s2"], p["t2"], h2, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3)
+        cout = p["w3"].shape[0]
+        if self.downsample is not None:
+            out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
+            ops.conv_rows(x2d, p["wd"], p["sd"], p["td"], out2d, a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev),
+                          taps=1, m_cap=ix.cap3, relu=2, relu_if_neg=ix.pos3)
+            resid = out2d
+        elif self.inplace_residual:
+            resid = out2d = x2d          # x >= 0 (post-ReLU) inside the network: inactive pixels pass through
+        else:
+            resid, out2d = x2d, torch.relu(x2d)
+        ops.conv_rows(h2, p["w3"], p["s3"], p["t3"], out2d, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
+                      out_rows=ix.idx3, residual2d=resid)
+        return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), patch, ix
+
+    def _ds_rows(self, B, Hi, Wi, Ho, Wo, s, dev):
+        key = (B, Hi, Wi, s, str(dev))
+        cache = self.__dict__.setdefault("_ds_cache", {})
+        if key not in cache:
+            b = torch.arange(B, device=dev).view(B, 1, 1)
+            y = torch.arange(Ho, device=dev).view(1, Ho, 1) * s
+            xx = torch.arange(Wo, device=dev).view(1, 1, Wo) * s
+            cache[key] = ((b * Hi + y) * Wi + xx).reshape(-1).to(torch.int32).contiguous()
+        return cache[key]
+
+    def forward(self, x, temperature=1.0):
+        x, s3_list, s2_list, s1_list, cs_list, perc_list, flops = x
+        _eval_only(self, x)
+        if self.dyn_mode == "both":
+            raise LdnError("HIP path: dyn_mode='both' (channel AND spatial in one block) is not built yet "
+                           "(SURVEY 8f-2); use 'channel', 'spatial' or 'layer'")
+        p = self._prep if self._prep is not None else self._prepare(x.device)
+        one = lambda: torch.tensor(1.0, device=x.device)
+        if self.dyn_mode == "channel":
+            out, cmask = self._run_channel(x, p)
+            cs = cmask.mean()
+            s1, s2, s3 = one(), one(), one()
+            c_flops, s_flops = self.masker_channel.flops_for(x), 0
+        else:
+            out, patch, ix = self._run_spatial(x, p)
+            s3, s2, s1 = ix.stats[0], ix.stats[1], ix.stats[2]
+            cs = one()
+            c_flops, s_flops = 0, self.masker_spatial.flops_for(x)
+
+        # FLOPs bookkeeping, laud_resnet.py:112-147 (conv1 runs at the input resolution)
+        px_in = x.shape[2] * x.shape[3]
+        px_out = out.shape[2] * out.shape[3]
+        sparse = c_flops + s_flops
+        dense = c_flops + s_flops
+        dense += self.conv1_flops_per_pixel * px_in
+        sparse = sparse + self.conv1_flops_per_pixel * px_in * cs * s1
+        dense += self.conv2_flops_per_pixel * px_out
+        sparse = sparse + self.conv2_flops_per_pixel * px_out * cs ** 2 * s2
+        dense += self.conv3_flops_per_pixel * px_out
+        sparse = sparse + self.conv3_flops_per_pixel * px_out * cs * s3
+        if self.downsample is not None:
+            dense += self.downsample_flops * px_out
+            sparse = sparse + self.downsample_flops * px_out
+        flops = flops + sparse
+        perc = sparse / dense
+
+        def push(lst, v):
+            v = v.reshape(1)
+            return v if lst is None else torch.cat((lst, v), dim=0)
+
+        return (out, push(s3_list, s3), push(s2_list, s2), push(s1_list, s1), push(cs_list, cs),
+                push(perc_list, perc), flops)
+
+
+# ------------------------------------------------------------------------------------------- model
+class ResNet(nn.Module):
+    """models/laud_resnet.py:167-363."""
+
+    def __init__(self, block, layers, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
+                 replace_stride_with_dilation=None, norm_layer=None, width_mult=1., input_size=224,
+                 spatial_mask_channel_group=[1, 1, 1, 1], mask_spatial_granularity=[1, 1, 1, 1],
+                 channel_dyn_granularity=[1, 1, 1, 1], dyn_mode=["both", "both", "both", "both"],
+                 channel_masker=["MLP", "MLP", "MLP", "MLP"], channel_masker_layers=[1, 1, 1, 1],
+                 reduction_ratio=[16, 16, 16, 16], lr_mult=1.0, **kwargs):
+        super().__init__()
+        self.dyn_mode = dyn_mode
+        assert lr_mult is not None
+        self.lr_mult = lr_mult
+        if norm_layer is None:
+            norm_layer = nn.BatchNorm2d
+        self._norm_layer = norm_layer
+        self.inplanes = int(64 * width_mult)
+        self.dilation = 1
+        if replace_stride_with_dilation is None:
+            replace_stride_with_dilation = [False, False, False]
+        if len(replace_stride_with_dilation) != 3:
+            raise ValueError("replace_stride_with_dilation should be None or a 3-element tuple, got {}".format(
+                replace_stride_with_dilation))
+        self.groups = groups
+        self.base_width = width_per_group
+        self.conv1 = nn.Conv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(self.inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        dil = [False] + list(replace_stride_with_dilation)
+        for i, (mult, stride, down) in enumerate(((64, 1, 4), (128, 2, 8), (256, 2, 16), (512, 2, 32))):
+            setattr(self, f"layer{i + 1}", self._make_layer(
+                block, int(mult * width_mult), layers[i], stride=stride, dilate=dil[i],
+                output_size=input_size // down, spatial_mask_channel_group=spatial_mask_channel_group[i],
+                mask_spatial_granularity=mask_spatial_granularity[i],
+                channel_dyn_granularity=channel_dyn_granularity[i], dyn_mode=dyn_mode[i],
+                channel_masker=channel_masker[i], channel_masker_layers=channel_masker_layers[i],
+                reduction_ratio=reduction_ratio[i]))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(int(512 * width_mult * block.expansion), num_classes)
+
+        for name, m in self.named_modules():
+            if isinstance(m, nn.Conv2d) and "masker" not in name:
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
+        # the network owns its intermediate activations: blocks without a downsample branch may update
+        # the residual stream in place (their input is post-ReLU, hence >= 0)
+        for m in self.modules():
+            if isinstance(m, Bottleneck) and m.downsample is None:
+                m.inplace_residual = True
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilate=False, output_size=56,
+                    spatial_mask_channel_group=1, mask_spatial_granularity=1, channel_dyn_granularity=1,
+                    dyn_mode="both", channel_masker="MLP", channel_masker_layers=1, reduction_ratio=16):
+        norm_layer = self._norm_layer
+        downsample = None
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
+                                       norm_layer(planes * block.expansion))
+        common = dict(group_width=self.groups, norm_layer=norm_layer, output_size=output_size,
+                      spatial_mask_channel_group=spatial_mask_channel_group,
+                      mask_spatial_granularity=mask_spatial_granularity,
+                      channel_dyn_granularity=channel_dyn_granularity, dyn_mode=dyn_mode,
+                      channel_masker=channel_masker, channel_masker_layers=channel_masker_layers,
+                      reduction=reduction_ratio)
+        mods = [block(inplanes=self.inplanes, planes=planes, stride=stride, downsample=downsample,
+                      dilation=previous_dilation, **common)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            mods.append(block(self.inplanes, planes, dilation=self.dilation, **common))
+        return nn.ModuleList(mods)
+
+    def forward(self, x, temperature):
+        _eval_only(self, x)
+        c_in = x.shape[1]
+        # static stem (laud_resnet.py:318-324): plain library ops, channels-last so the blocks see NHWC rows
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = self.relu(self.bn1(self.conv1(x)))
+        flops = c_in * x.shape[1] * x.shape[2] * x.shape[3] * self.conv1.weight.shape[2] * self.conv1.weight.shape[3]
+        x = self.maxpool(x)
+        flops += x.shape[1] * x.shape[2] * x.shape[3] * 9
+
+        perc, stages = None, []
+        for i in range(4):
+            state = (x, None, None, None, None, perc, flops)
+            for blk in getattr(self, f"layer{i + 1}"):
+                state = blk(state, temperature)
+            x, s3, s2, s1, cs, perc, flops = state
+            stages.append((s3, s2, s1, cs))
+
+        x = self.avgpool(x)
+        flops += x.shape[1] * x.shape[2] * x.shape[3]
+        x = torch.flatten(x, 1)
+        c_in = x.shape[1]
+        x = self.fc(x)
+        flops += c_in * x.shape[1]
+        cols = list(zip(*stages))
+        return x, list(cols[0]), list(cols[1]), list(cols[2]), list(cols[3]), perc, flops
+
+    def get_optim_policies(self):
+        backbone_params, masker_params = [], []
+        for name, m in self.named_modules():
+            dst = masker_params if "masker" in name else backbone_params
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                dst.extend(list(m.parameters(recurse=False)))
+            elif isinstance(m, nn.BatchNorm2d) or (isinstance(m, nn.BatchNorm1d) and dst is masker_params):
+                dst.extend(list(m.parameters(recurse=False)))
+        return [{"params": backbone_params, "lr_mult": self.lr_mult, "decay_mult": 1.0, "name": "backbone_params"},
+                {"params": masker_params, "lr_mult": 1.0, "decay_mult": 1.0, "name": "masker_params"}]
+
+
+def _resnet(arch, block, layers, pretrained, progress, **kwargs):
+    if pretrained:
+        raise LdnError("pretrained=True needs network access; load a state_dict explicitly")
+    return ResNet(block, layers, **kwargs)
+
+
+def uni_resnet50(pretrained=False, progress=True, **kwargs):
+    return _resnet("resnet50", Bottleneck, [3, 4, 6, 3], pretrained, progress, **kwargs)
+
+
+def uni_resnet101(pretrained=False, progress=True, **kwargs):
+    return _resnet("resnet101", Bottleneck, [3, 4, 23, 3], pretrained, progress, **kwargs)

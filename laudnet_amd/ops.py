@@ -1,0 +1,190 @@
+"""Tensor-level wrappers over the C ABI (include/ldn_hip.h).  PyTorch is used only for device
+memory and the current stream; every computation below runs in libldn_hip.so.  No fallbacks."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as L
+
+
+def _f32c(t, what):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise L.LdnError(f"{what}: expected a contiguous float32 tensor, got {t.dtype} strides {t.stride()}")
+    return t
+
+
+def _i32c(t, what):
+    if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+        raise L.LdnError(f"{what}: expected a contiguous int32 tensor")
+    return t
+
+
+def as_nhwc(x):
+    """[B,C,H,W] logical tensor -> contiguous [B,H,W,C] view (copying into channels_last if needed)."""
+    if x.dim() != 4:
+        raise L.LdnError("expected a 4-D NCHW tensor")
+    if x.dtype != torch.float32:
+        raise L.LdnError("laudnet_amd computes in float32")
+    x = x.contiguous(memory_format=torch.channels_last)
+    v = x.permute(0, 2, 3, 1)
+    if not v.is_contiguous():  # degenerate strides (C==1 or H*W==1): materialise
+        v = v.contiguous()
+    return v
+
+
+def from_nhwc(y):
+    """contiguous [B,H,W,C] -> [B,C,H,W] logical view (channels_last memory, no copy)."""
+    return y.permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------- a1
+def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False):
+    """Masker_spatial eval forward (models/utils.py:47-65).  x_nhwc [B,H,W,C]; weight [2g,C]; bias [2g].
+    Returns (mask [B,g,Sy,Sx] float {0,1}, logits [B,2g,Sy,Sx] or None)."""
+    L.require_device(x_nhwc, weight, bias)
+    lib = L.load()
+    B, H, W, C = x_nhwc.shape
+    pooled = mask_size < H
+    sy, sx = (mask_size, mask_size) if pooled else (H, W)
+    mask = torch.empty(B, groups, sy, sx, device=x_nhwc.device, dtype=torch.float32)
+    logits = torch.empty(B, 2 * groups, sy, sx, device=x_nhwc.device, dtype=torch.float32) if want_logits else None
+    L.check(lib.ldn_spatial_masker(L.ptr(_f32c(x_nhwc, "x")), B, H, W, C, L.ptr(_f32c(weight, "w")),
+                                   L.ptr(_f32c(bias, "bias")), groups, mask_size, L.ptr(mask), L.ptr(logits),
+                                   L.stream_ptr()), "ldn_spatial_masker")
+    return mask, logits
+
+
+# ---------------------------------------------------------------------------------------- a4/a11
+@dataclass
+class IndexSet:
+    idx3: torch.Tensor
+    pos3: torch.Tensor
+    idx1: torch.Tensor
+    pos1: torch.Tensor
+    nbr: torch.Tensor
+    cnt: torch.Tensor      # [2] = {#rows of mask3, #rows of mask1}
+    pre3: torch.Tensor     # [B+1]
+    pre1: torch.Tensor     # [B+1]
+    stats: torch.Tensor    # [3] = {mean patch mask, mean mask2, mean mask1}
+    cap3: int
+    cap1: int
+
+
+def mask_to_index(patch_mask, out_h, out_w, stride):
+    """patch_mask [B,S,S] float {0,1} -> packed index lists (see ldn_mask_to_index)."""
+    L.require_device(patch_mask)
+    lib = L.load()
+    if patch_mask.dim() != 3 or patch_mask.shape[1] != patch_mask.shape[2]:
+        raise L.LdnError("mask_to_index: patch_mask must be [B,S,S]")
+    B, S, _ = patch_mask.shape
+    dev = patch_mask.device
+    cap3, cap1 = B * out_h * out_w, B * out_h * stride * out_w * stride
+    i32 = dict(device=dev, dtype=torch.int32)
+    ix = IndexSet(idx3=torch.empty(cap3, **i32), pos3=torch.empty(cap3, **i32), idx1=torch.empty(cap1, **i32),
+                  pos1=torch.empty(cap1, **i32), nbr=torch.empty(cap3 * 9, **i32), cnt=torch.empty(2, **i32),
+                  pre3=torch.empty(B + 1, **i32), pre1=torch.empty(B + 1, **i32),
+                  stats=torch.empty(3, device=dev, dtype=torch.float32), cap3=cap3, cap1=cap1)
+    work = torch.empty(3 * B, **i32)
+    L.check(lib.ldn_mask_to_index(L.ptr(_f32c(patch_mask, "patch_mask")), B, S, out_h, out_w, stride, L.ptr(ix.idx3),
+                                  L.ptr(ix.pos3), L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr), L.ptr(ix.cnt),
+                                  L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr()),
+            "ldn_mask_to_index")
+    return ix
+
+
+# ---------------------------------------------------------------------------------------- K2/K5
+def gather_rows(src2d, rows, count=None, cap=None):
+    L.require_device(src2d, rows)
+    lib = L.load()
+    cap = rows.numel() if cap is None else cap
+    C = src2d.shape[1]
+    out = torch.empty(cap, C, device=src2d.device, dtype=torch.float32)
+    L.check(lib.ldn_gather_rows(L.ptr(_f32c(src2d, "src")), src2d.stride(0), L.ptr(_i32c(rows, "rows")),
+                                L.ptr(_i32c(count, "count")), cap, C, L.ptr(out), C, L.stream_ptr()), "ldn_gather_rows")
+    return out
+
+
+def scatter_add_relu(packed, rows, identity2d, out2d=None, count=None, cap=None):
+    L.require_device(packed, rows, identity2d)
+    lib = L.load()
+    cap = rows.numel() if cap is None else cap
+    out2d = identity2d if out2d is None else out2d
+    C = packed.shape[1]
+    L.check(lib.ldn_scatter_add_relu(L.ptr(_f32c(packed, "packed")), packed.stride(0), L.ptr(_i32c(rows, "rows")),
+                                     L.ptr(_i32c(count, "count")), cap, C, L.ptr(_f32c(identity2d, "identity")),
+                                     identity2d.stride(0), L.ptr(_f32c(out2d, "out")), out2d.stride(0),
+                                     L.stream_ptr()), "ldn_scatter_add_relu")
+    return out2d
+
+
+# ---------------------------------------------------------------------------------------- a7 rows
+def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None, m_cap=None, relu=1,
+              relu_if_neg=None, out_rows=None, residual2d=None):
+    """Packed-row convolution (see ldn_conv_rows).  a2d [rows,lda>=cin]; w [cout,taps,cin]; out2d [rows,ldo]."""
+    L.require_device(a2d, w, out2d)
+    lib = L.load()
+    cout, t, cin = w.shape
+    if t != taps:
+        raise L.LdnError(f"conv_rows: weight has {t} taps, expected {taps}")
+    if m_cap is None:
+        m_cap = a2d.shape[0] if a_rows is None else a_rows.numel() // taps
+    L.check(lib.ldn_conv_rows(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")), taps,
+                              L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(_f32c(w, "w")), cin, cout,
+                              L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,
+                              L.ptr(_i32c(relu_if_neg, "relu_if_neg")), L.ptr(_i32c(out_rows, "out_rows")),
+                              L.ptr(residual2d), residual2d.stride(0) if residual2d is not None else 0,
+                              L.ptr(_f32c(out2d, "out")), out2d.stride(0), L.stream_ptr()), "ldn_conv_rows")
+    return out2d
+
+
+# ---------------------------------------------------------------------------------------- a2
+def channel_masker(x_nhwc, w1, b1, w2, b2, groups, gran, mask_in=None, want_logits=False):
+    """Masker_channel_MLP eval forward + active channel lists (see ldn_channel_masker).
+    Returns (mask [B,G], ch_idx [B,G*gran] int32, ch_cnt [B] int32, logits [B,2G] or None)."""
+    lib = L.load()
+    dev = x_nhwc.device if x_nhwc is not None else mask_in.device
+    L.require_device(x_nhwc, mask_in)
+    if mask_in is not None:
+        B = mask_in.shape[0]
+        HW = C = hidden = 0
+        work = None
+    else:
+        B, H, W, C = x_nhwc.shape
+        HW = H * W
+        hidden = 0 if w2 is None else w1.shape[0]
+        splits = lib.ldn_channel_masker_splits(HW)
+        work = torch.empty(B * splits * C, device=dev, dtype=torch.float32)
+    width = groups * gran
+    mask = torch.empty(B, groups, device=dev, dtype=torch.float32)
+    idx = torch.empty(B, width, device=dev, dtype=torch.int32)
+    cnt = torch.empty(B, device=dev, dtype=torch.int32)
+    logits = torch.empty(B, 2 * groups, device=dev, dtype=torch.float32) if (want_logits and mask_in is None) else None
+    L.check(lib.ldn_channel_masker(L.ptr(x_nhwc), B, HW, C, L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), hidden, groups,
+                                   gran, L.ptr(_f32c(mask_in, "mask_in") if mask_in is not None else None), L.ptr(mask),
+                                   L.ptr(logits), L.ptr(idx), L.ptr(cnt), L.ptr(work), L.stream_ptr()),
+            "ldn_channel_masker")
+    return mask, idx, cnt, logits
+
+
+# ---------------------------------------------------------------------------------------- a7 image
+def conv_image(a_nhwc, w, scale, shift, out_nhwc, *, ksize=1, stride=1, k_idx=None, k_cnt=None, kgran=1, n_idx=None,
+               n_cnt=None, post_sub=None, relu=1, residual=None):
+    """Per-image channel-subset convolution (see ldn_conv_image).
+    a_nhwc [B,Hi,Wi,lda]; w [cout,ksize*ksize,cin]; shift [cout] or [16,cout]; out_nhwc [B,Ho,Wo,ldo]."""
+    L.require_device(a_nhwc, w, out_nhwc)
+    lib = L.load()
+    B, Hi, Wi, lda = a_nhwc.shape
+    _, Ho, Wo, ldo = out_nhwc.shape
+    cout, t, cin = w.shape
+    if t != ksize * ksize:
+        raise L.LdnError("conv_image: weight taps do not match ksize")
+    classes = 1 if shift.dim() == 1 else shift.shape[0]
+    L.check(lib.ldn_conv_image(L.ptr(_f32c(a_nhwc, "a")), lda, B, Hi, Wi, ksize, stride, Ho, Wo, L.ptr(_f32c(w, "w")),
+                               cin, cout, L.ptr(_i32c(k_idx, "k_idx")), L.ptr(_i32c(k_cnt, "k_cnt")), kgran,
+                               L.ptr(_i32c(n_idx, "n_idx")), L.ptr(_i32c(n_cnt, "n_cnt")),
+                               L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), classes, L.ptr(post_sub),
+                               relu, L.ptr(residual), residual.shape[-1] if residual is not None else 0,
+                               L.ptr(_f32c(out_nhwc, "out")), ldo, L.stream_ptr()), "ldn_conv_image")
+    return out_nhwc

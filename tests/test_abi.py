@@ -1,0 +1,72 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/ldn_hip.h declares; the Python mirror keeps the reference's state_dict surface; the product path
+refuses to run without a HIP device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "ldn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from laudnet_amd import build, _lib
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"libldn_hip.so does not export {n}"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES and include/ldn_hip.h disagree"
+    assert _lib.load().ldn_version() >= 100
+
+
+def test_argument_validation_without_gpu():
+    from laudnet_amd import _lib
+    lib = _lib.load()
+    # NULL pointers / bad shapes are rejected before any launch
+    assert lib.ldn_conv_rows(None, 0, None, 1, None, 10, None, 8, 8, None, None, 1, None, None, None, 0, None, 8, None) == -1
+    assert b"null" in lib.ldn_last_error()
+    assert lib.ldn_gather_rows(None, 4, None, None, 1, 3, None, 4, None) == -1
+    assert lib.ldn_channel_masker_splits(3136) >= 1
+
+
+@pytest.mark.parametrize("name", ["r50_spatial_g1", "r101_channel2222", "r101_spatial4421", "r101_layer", "r50_mixed"])
+def test_state_dict_surface_matches_reference(name):
+    import laudnet_amd
+    fx = load_golden("full_tiny.pt")[name]
+    model = getattr(laudnet_amd, fx["factory"])(**fx["kw"])
+    assert list(model.state_dict().keys()) == fx["keys"]
+    assert sum(p.numel() for p in model.parameters()) == fx["n_params"]
+    pol = model.get_optim_policies()
+    assert [g["name"] for g in pol] == ["backbone_params", "masker_params"]
+    assert sum(p.numel() for g in pol for p in g["params"]) == fx["n_params"]
+
+
+def test_no_cpu_fallback():
+    import laudnet_amd
+    fx = load_golden("full_tiny.pt")["r50_spatial_g1"]
+    model = laudnet_amd.uni_resnet50(**fx["kw"]).eval()
+    with pytest.raises(laudnet_amd.LdnError):
+        model(torch.zeros(1, 3, 224, 224), 1.0)
+    with pytest.raises(laudnet_amd.LdnError):
+        model.train()(torch.zeros(1, 3, 224, 224), 1.0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "laudnet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"

@@ -1,0 +1,112 @@
+"""GPU parity of the HIP-backed nn.Modules (laudnet_amd.laud_resnet) against the golden fixtures produced by
+the reference, and against the oracle.  Tolerance: 1e-3 absolute on fp32 activations/logits (BASELINE.json
+north_star); gather index lists bit-exact (tests/test_hip_ops.py)."""
+import pytest
+import torch
+
+from fill import fill_state_dict, seeded_randn
+from helpers import (assert_tuple_close, block_input, full_model_blocks, injected_masks_for, load_golden, make_block,
+                     start_state)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3  # north_star: outputs within 1e-3 fp32 of the reference PyTorch masked-conv path
+
+BLOCKS = {**load_golden("blocks_s1.pt"), **load_golden("blocks_s2.pt")}
+FULL = load_golden("full_tiny.pt")
+BUILT = sorted(n for n in BLOCKS if BLOCKS[n]["kw"]["dyn_mode"] != "both"
+               and BLOCKS[n]["kw"]["spatial_mask_channel_group"] == 1)
+
+
+def _hip_block(fx):
+    from laudnet_amd.laud_resnet import Bottleneck
+    return make_block(Bottleneck, fx).to(DEV)
+
+
+@pytest.mark.parametrize("name", BUILT)
+def test_block_injected_masks(name):
+    fx = BLOCKS[name]
+    blk = _hip_block(fx)
+    blk.forced_spatial_mask = fx.get("spatial_mask")
+    blk.forced_channel_mask = None if fx.get("channel_mask") is None else fx["channel_mask"].to(DEV)
+    with torch.no_grad():
+        got = blk(start_state(block_input(fx).to(DEV)), 1.0)
+    torch.cuda.synchronize()
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=TOL, what=name + " out")
+    assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what=name + " stats")
+    assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what=name + " flops")
+
+
+@pytest.mark.parametrize("name", BUILT)
+def test_block_own_masker(name):
+    """Masks produced by the HIP maskers.  A mask bit may legitimately flip at a numerical near-tie, so the
+    block output is compared only if the masks agree with the reference's (they do for these fixtures)."""
+    fx = BLOCKS[name]
+    blk = _hip_block(fx)
+    x = block_input(fx).to(DEV)
+    with torch.no_grad():
+        if blk.masker_spatial is not None:
+            m = blk.masker_spatial(x, 1.0)[0]
+            assert torch.equal(m.cpu(), fx["masker_spatial_mask"]), "spatial masker decision differs"
+        if blk.masker_channel is not None:
+            m = blk.masker_channel(x, 1.0)[0]
+            assert torch.equal(m.cpu(), fx["masker_channel_mask"]), "channel masker decision differs"
+        got = blk(start_state(x), 1.0)
+    assert_tuple_close(got[:1], fx["masker_run"][:1], atol=TOL, what=name + " out")
+    assert_tuple_close(got[1:6], fx["masker_run"][1:6], atol=1e-6, what=name + " stats")
+
+
+def test_block_inplace_matches_out_of_place():
+    fx = BLOCKS["spatial_g4_s1"]
+    blk = _hip_block(fx)
+    blk.forced_spatial_mask = fx["spatial_mask"]
+    x = block_input(fx).to(DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        a = blk(start_state(x.clone(memory_format=torch.channels_last)), 1.0)[0].clone()
+        blk.inplace_residual = True
+        b = blk(start_state(x), 1.0)[0]
+    assert torch.equal(a, b)
+
+
+def test_training_and_cpu_raise():
+    from laudnet_amd import LdnError
+    fx = BLOCKS["layer_s1"]
+    blk = _hip_block(fx)
+    with pytest.raises(LdnError):
+        blk.train()(start_state(block_input(fx).to(DEV)), 1.0)
+    with pytest.raises(LdnError):
+        blk.eval().cpu()(start_state(block_input(fx)), 1.0)
+
+
+FULL_BUILT = sorted(n for n in FULL if "both" not in FULL[n]["kw"]["dyn_mode"])
+
+
+def _hip_model(fx):
+    import laudnet_amd
+    model = getattr(laudnet_amd, fx["factory"])(**fx["kw"]).eval()
+    assert list(model.state_dict().keys()) == fx["keys"]
+    model.load_state_dict(fill_state_dict(model.state_dict(), fx["seed"]))
+    x = seeded_randn((fx["batch"], 3, fx["kw"]["input_size"], fx["kw"]["input_size"]), fx["x_seed"])
+    return model.to(DEV), x.to(DEV)
+
+
+@pytest.mark.parametrize("name", FULL_BUILT)
+def test_full_model_injected(name):
+    fx = FULL[name]
+    model, x = _hip_model(fx)
+    blocks = full_model_blocks(model)
+    # same recipe as make_golden.injected_masks_for, via the oracle-style attribute names
+    from fill import seeded_bernoulli
+    for i, (bname, blk) in enumerate(blocks):
+        if blk.masker_spatial is not None:
+            ms, g = blk.masker_spatial.mask_size, blk.masker_spatial.mask_channel_group
+            blk.forced_spatial_mask = seeded_bernoulli((fx["batch"], g, ms, ms), 0.5, fx["mask_seed"] + 2 * i)
+        if blk.masker_channel is not None:
+            blk.forced_channel_mask = seeded_bernoulli((fx["batch"], blk.masker_channel.channel_dyn_group), 0.62,
+                                                       fx["mask_seed"] + 2 * i + 1).to(DEV)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    torch.cuda.synchronize()
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=TOL, what=name + " logits")
+    assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what=name + " stats")
+    assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what=name + " flops")

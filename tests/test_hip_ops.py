@@ -1,0 +1,264 @@
+"""GPU parity tests of the C-ABI ops (through laudnet_amd.ops -> libldn_hip.so) against the oracle.
+Integer/index work must be bit-exact; fp32 work within the tolerance written at each assert."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fill import seeded_bernoulli, seeded_randn
+from oracle import index_ref as IR
+from oracle import torch_ref as TR
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from laudnet_amd import ops as _ops, load_library
+    load_library()  # raises if libldn_hip.so is missing -- no fallback
+    return _ops
+
+
+# ------------------------------------------------------------------ index work (bit-exact)
+@pytest.mark.parametrize("B,S,Ho,stride,p", [
+    (3, 14, 14, 1, 0.5), (3, 3, 14, 1, 0.5), (2, 3, 14, 2, 0.4), (4, 1, 7, 1, 0.5), (4, 1, 7, 2, 0.5),
+    (2, 7, 28, 2, 0.5), (5, 14, 56, 1, 0.3), (2, 9, 28, 1, 0.5), (2, 56, 56, 1, 0.5), (8, 7, 7, 2, 0.0),
+    (8, 7, 7, 2, 1.0), (1, 14, 56, 2, 0.5), (300, 2, 7, 1, 0.5),
+])
+def test_mask_to_index(ops, B, S, Ho, stride, p):
+    patch = seeded_bernoulli((B, S, S), p, 7 + B + S + Ho)
+    ix = ops.mask_to_index(patch.to(DEV), Ho, Ho, stride)
+    torch.cuda.synchronize()
+    m3 = IR.upsample_patch_mask(patch.numpy() > 0.5, Ho)
+    m1 = IR.dilate_mask(m3, stride, 1)
+    idx3, pre3 = IR.nonzero_rows(m3)
+    idx1, pre1 = IR.nonzero_rows(m1)
+    cnt = ix.cnt.cpu().numpy()
+    assert cnt[0] == len(idx3) and cnt[1] == len(idx1)
+    assert np.array_equal(ix.idx3.cpu().numpy()[:cnt[0]], idx3)
+    assert np.array_equal(ix.idx1.cpu().numpy()[:cnt[1]], idx1)
+    assert np.array_equal(ix.pre3.cpu().numpy(), pre3) and np.array_equal(ix.pre1.cpu().numpy(), pre1)
+    assert np.array_equal(ix.pos3.cpu().numpy(), IR.position_map(m3).reshape(-1))
+    assert np.array_equal(ix.pos1.cpu().numpy(), IR.position_map(m1).reshape(-1))
+    nbr = ix.nbr.cpu().numpy().reshape(-1, 9)[:cnt[0]]
+    assert np.array_equal(nbr, IR.neighbour_table(m3, m1, stride))
+    stats = ix.stats.cpu().numpy()
+    want = np.array([patch.mean().item(), m3.mean(), m1.mean()], dtype=np.float32)
+    assert np.allclose(stats, want, atol=1e-6)
+
+
+def test_gather_scatter(ops):
+    rows_total, C = 500, 64
+    src = seeded_randn((rows_total, C), 3).to(DEV)
+    rows = torch.randperm(rows_total, generator=torch.Generator().manual_seed(1))[:123].sort().values.to(torch.int32)
+    count = torch.tensor([100], dtype=torch.int32, device=DEV)
+    packed = ops.gather_rows(src, rows.to(DEV), count=count)
+    assert torch.equal(packed[:100].cpu(), src.cpu()[rows[:100].long()])
+    ident = seeded_randn((rows_total, C), 4).to(DEV)
+    out = ident.clone()
+    ops.scatter_add_relu(packed, rows.to(DEV), ident, out, count=count)
+    want = ident.cpu().clone()
+    want[rows[:100].long()] = torch.relu(ident.cpu()[rows[:100].long()] + packed[:100].cpu())
+    assert torch.equal(out.cpu(), want)
+
+
+# ------------------------------------------------------------------ maskers
+@pytest.mark.parametrize("cin,g,S,hin", [(16, 1, 4, 8), (16, 1, 8, 8), (16, 2, 4, 8), (8, 1, 3, 14), (8, 1, 1, 7),
+                                         (256, 1, 7, 56), (64, 1, 14, 56)])
+def test_spatial_masker(ops, cin, g, S, hin):
+    torch.manual_seed(cin + S)
+    ref = TR.SpatialMaskerRef(cin, g, S).eval()
+    with torch.no_grad():
+        ref.conv.weight.normal_()
+        ref.conv.bias.normal_()
+    x = F.relu(seeded_randn((4, cin, hin, hin), 5))
+    with torch.no_grad():
+        want_logits = ref.logits(x).reshape(4, 2 * g, *ref.logits(x).shape[-2:])
+        want_mask = (want_logits[:, :g] >= want_logits[:, g:]).float()
+    xn = x.to(DEV).permute(0, 2, 3, 1).contiguous()
+    mask, logits = ops.spatial_masker(xn, ref.conv.weight.detach().reshape(2 * g, cin).to(DEV).contiguous(),
+                                      ref.conv.bias.detach().to(DEV), g, S, want_logits=True)
+    assert torch.allclose(logits.cpu(), want_logits, atol=1e-4, rtol=1e-5)  # fp32 reduction-order tolerance
+    margin = (want_logits[:, :g] - want_logits[:, g:]).abs()
+    differs = mask.cpu() != want_mask
+    assert not bool((differs & (margin > 1e-4)).any()), "mask decisions may differ only at near-ties"
+
+
+def test_spatial_masker_tie_keeps(ops):
+    x = torch.rand(1, 2, 2, 4, device=DEV)
+    mask, _ = ops.spatial_masker(x, torch.zeros(2, 4, device=DEV), torch.zeros(2, device=DEV), 1, 2)
+    assert float(mask.min()) == 1.0  # models/utils.py:60: >= keeps ties
+
+
+@pytest.mark.parametrize("cin,G,layers,gran,hw", [(32, 8, 2, 1, 6), (32, 8, 1, 2, 6), (256, 32, 2, 2, 56),
+                                                  (1024, 128, 2, 2, 14), (2048, 256, 2, 2, 7), (64, 16, 2, 4, 9)])
+def test_channel_masker(ops, cin, G, layers, gran, hw):
+    torch.manual_seed(G + layers)
+    ref = TR.ChannelMaskerMLPRef(cin, G, layers=layers).eval()
+    with torch.no_grad():
+        for prm in ref.parameters():
+            prm.normal_()
+    B = 5
+    x = F.relu(seeded_randn((B, cin, hw, hw), 6))
+    with torch.no_grad():
+        want_logits = ref.logits(x).reshape(B, 2 * G)
+    if layers == 2:
+        w1, b1, w2, b2 = ref.conv[0].weight, ref.conv[0].bias, ref.conv[2].weight, ref.conv[2].bias
+    else:
+        w1, b1, w2, b2 = ref.conv.weight, ref.conv.bias, None, None
+    d = lambda t: None if t is None else t.detach().to(DEV).contiguous()
+    xn = x.to(DEV).permute(0, 2, 3, 1).contiguous()
+    mask, idx, cnt, logits = ops.channel_masker(xn, d(w1), d(b1), d(w2), d(b2), G, gran, want_logits=True)
+    scale = want_logits.abs().max().item()
+    assert torch.allclose(logits.cpu(), want_logits, atol=2e-5 * max(scale, 1.0), rtol=1e-5)
+    want_mask = (want_logits[:, :G] >= want_logits[:, G:]).float()
+    margin = (want_logits[:, :G] - want_logits[:, G:]).abs()
+    assert not bool(((mask.cpu() != want_mask) & (margin > 1e-4 * max(scale, 1.0))).any())
+    # the lists must be exactly the lists of the mask the kernel decided on
+    widx, wcnt = IR.channel_lists(mask.cpu().numpy(), G * gran)
+    assert np.array_equal(cnt.cpu().numpy(), wcnt)
+    got = idx.cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[b, :wcnt[b]], widx[b, :wcnt[b]])
+    # injected-mask variant: lists only
+    m_in = seeded_bernoulli((B, G), 0.6, 9)
+    mask2, idx2, cnt2, _ = ops.channel_masker(None, None, None, None, None, G, gran, mask_in=m_in.to(DEV))
+    widx, wcnt = IR.channel_lists(m_in.numpy(), G * gran)
+    assert torch.equal(mask2.cpu(), m_in) and np.array_equal(cnt2.cpu().numpy(), wcnt)
+    for b in range(B):
+        assert np.array_equal(idx2.cpu().numpy()[b, :wcnt[b]], widx[b, :wcnt[b]])
+
+
+# ------------------------------------------------------------------ packed-row convolution
+def _affine(c, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(300, 64, 64), (1000, 256, 64), (257, 64, 256), (129, 8, 16), (64, 36, 200),
+                                           (5000, 128, 128)])
+def test_conv_rows_1x1_gather(ops, rows, cin, cout):
+    a = seeded_randn((rows, cin), 1)
+    w = seeded_randn((cout, 1, cin), 2) * (2.0 / cin) ** 0.5
+    sc, sh = _affine(cout, 3)
+    perm = torch.randperm(rows, generator=torch.Generator().manual_seed(4))[: rows * 2 // 3].sort().values
+    count = torch.tensor([len(perm) - 5], dtype=torch.int32)
+    out = torch.full((rows, cout), -7.0, device=DEV)
+    ops.conv_rows(a.to(DEV), w.to(DEV), sc.to(DEV), sh.to(DEV), out, a_rows=perm.to(torch.int32).to(DEV), taps=1,
+                  m_count=count.to(DEV), m_cap=rows, relu=1)
+    n = int(count)
+    want = torch.relu((a[perm[:n]].double() @ w[:, 0].double().T) * sc.double() + sh.double()).float()
+    assert torch.allclose(out[:n].cpu(), want, atol=1e-4, rtol=1e-4)   # fp32 MFMA vs fp64 reference
+    assert bool((out[n:] == -7.0).all()), "rows beyond the device-side count must not be written"
+
+
+@pytest.mark.parametrize("B,H,C,cout,stride", [(2, 14, 16, 16, 1), (3, 14, 64, 64, 2), (2, 7, 128, 128, 1)])
+def test_conv_rows_3x3_table_scatter(ops, B, H, C, cout, stride):
+    """Full spatial-mode slice at op level: mask -> index -> 3x3 through the neighbour table, and the final
+    1x1 with residual scatter-add, against F.conv2d on masked dense tensors."""
+    Ho = H // stride if stride > 1 else H
+    Hi = Ho * stride
+    patch = seeded_bernoulli((B, Ho, Ho), 0.5, 11)
+    ix = ops.mask_to_index(patch.to(DEV), Ho, Ho, stride)
+    h1_dense = seeded_randn((B, C, Hi, Hi), 12)
+    m1 = torch.from_numpy(IR.dilate_mask(patch.numpy() > 0.5, stride, 1)).float().unsqueeze(1)
+    idx1 = ix.idx1[: int(ix.cnt[1])].long().cpu()
+    h1_rows = h1_dense.permute(0, 2, 3, 1).reshape(-1, C)
+    packed_h1 = torch.zeros(ix.cap1, C)
+    packed_h1[: len(idx1)] = h1_rows[idx1]
+    w = seeded_randn((cout, C, 3, 3), 13) * (2.0 / (9 * C)) ** 0.5
+    sc, sh = _affine(cout, 14)
+    out = torch.zeros(ix.cap3, cout, device=DEV)
+    ops.conv_rows(packed_h1.to(DEV), w.permute(0, 2, 3, 1).reshape(cout, 9, C).contiguous().to(DEV), sc.to(DEV),
+                  sh.to(DEV), out, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1)
+    dense = F.conv2d((h1_dense * m1).double(), w.double(), stride=stride, padding=1)
+    dense = torch.relu(dense * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
+    idx3 = ix.idx3[: int(ix.cnt[0])].long().cpu()
+    want = dense.permute(0, 2, 3, 1).reshape(-1, cout)[idx3]
+    assert torch.allclose(out[: len(idx3)].cpu(), want, atol=1e-4, rtol=1e-4)
+    # scatter-add epilogue
+    ident = seeded_randn((B * Ho * Ho, cout), 15)
+    res = ident.clone().to(DEV)
+    w3 = seeded_randn((cout, 1, cout), 16) * (2.0 / cout) ** 0.5
+    ops.conv_rows(out, w3.to(DEV), sc.to(DEV), sh.to(DEV), res, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
+                  out_rows=ix.idx3, residual2d=res)
+    want_full = ident.clone()
+    y = (want.double() @ w3[:, 0].double().T) * sc.double() + sh.double()
+    want_full[idx3] = torch.relu(ident[idx3].double() + y).float()
+    assert torch.allclose(res.cpu(), want_full, atol=2e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ per-image convolution
+@pytest.mark.parametrize("B,H,cin,cout,ksize,stride", [
+    (2, 14, 64, 64, 1, 1), (3, 14, 32, 48, 3, 1), (2, 28, 64, 128, 1, 2), (2, 14, 16, 16, 3, 2), (9, 7, 128, 256, 3, 1),
+    (2, 56, 64, 64, 3, 1), (2, 13, 8, 24, 3, 2),
+])
+def test_conv_image_dense(ops, B, H, cin, cout, ksize, stride):
+    x = seeded_randn((B, cin, H, H), 21)
+    w = seeded_randn((cout, cin, ksize, ksize), 22) * (2.0 / (cin * ksize * ksize)) ** 0.5
+    sc, sh = _affine(cout, 23)
+    Ho = (H - 1) // stride + 1
+    out = torch.empty(B, Ho, Ho, cout, device=DEV)
+    resid = seeded_randn((B, Ho, Ho, cout), 24)
+    ops.conv_image(x.permute(0, 2, 3, 1).contiguous().to(DEV),
+                   w.permute(0, 2, 3, 1).reshape(cout, ksize * ksize, cin).contiguous().to(DEV), sc.to(DEV), sh.to(DEV),
+                   out, ksize=ksize, stride=stride, relu=1, residual=resid.to(DEV))
+    want = F.conv2d(x.double(), w.double(), stride=stride, padding=ksize // 2)
+    want = want * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    want = torch.relu(want.permute(0, 2, 3, 1) + resid.double()).float()
+    assert torch.allclose(out.cpu(), want, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,cin,W,gran,stride", [(3, 14, 64, 16, 1, 1), (3, 14, 32, 16, 2, 2), (4, 7, 128, 64, 4, 1),
+                                                    (2, 28, 64, 32, 2, 1), (5, 14, 256, 256, 2, 1)])
+def test_conv_image_channel_subsets(ops, B, H, cin, W, gran, stride):
+    """conv1 (output subset) -> conv2 (input+output subsets, border-class shift table) -> conv3 (input subset),
+    against the dense-emulation algebra of laud_resnet.py:115-133 (mask before BN)."""
+    G = W // gran
+    gm = seeded_bernoulli((B, G), 0.6, 31)
+    gm[0] = 0.0          # an image with no active channel
+    gm[1] = 1.0          # an image with all channels
+    blk = TR.BottleneckRef(cin, W, stride=stride, downsample=None, dyn_mode="channel", channel_dyn_granularity=gran,
+                           channel_masker="MLP", output_size=H // stride).eval()
+    TR.randomize_bn_(blk, 5)
+    with torch.no_grad():
+        for m in (blk.conv1, blk.conv2, blk.conv3):
+            m.weight.normal_(0, (2.0 / (m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3])) ** 0.5)
+    x = F.relu(seeded_randn((B, cin, H, H), 32))
+    cm = TR.broadcast_channel_mask(gm, W)
+    with torch.no_grad():
+        h1 = F.relu(blk.bn1(blk.conv1(x) * cm))
+        h2 = F.relu(blk.bn2(blk.conv2(h1) * cm))
+        y3 = blk.bn3(blk.conv3(h2))
+    # HIP path with the folded tables of laudnet_amd.laud_resnet.Bottleneck._prepare
+    from laudnet_amd.laud_resnet import Bottleneck
+    hb = Bottleneck(cin, W, stride=stride, downsample=None, dyn_mode="channel", channel_dyn_granularity=gran,
+                    channel_masker="MLP", output_size=H // stride).eval()
+    hb.load_state_dict(blk.state_dict())
+    hb = hb.to(DEV)
+    p = hb._prepare(torch.device(DEV))
+    _, idx, cnt, _ = ops.channel_masker(None, None, None, None, None, G, gran, mask_in=gm.to(DEV))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    Ho = (H - 1) // stride + 1
+    g1 = torch.full((B, H, H, W), float("nan"), device=DEV)
+    ops.conv_image(xn, p["w1"], p["s1"], p["t1"], g1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1)
+    g2 = torch.full((B, Ho, Ho, W), float("nan"), device=DEV)
+    ops.conv_image(g1, p["w2"], p["s2"], p["t2_tab"], g2, ksize=3, stride=stride, k_idx=idx, k_cnt=cnt, kgran=gran,
+                   n_idx=idx, n_cnt=cnt, post_sub=p["c2"], relu=1)
+    g3 = torch.empty(B, Ho, Ho, 4 * W, device=DEV)
+    ops.conv_image(g2, p["w3"], p["s3"], p["t3c"], g3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=0)
+    # unpack the left-packed h1/h2 and compare on the active channels
+    cidx, ccnt = idx.cpu().long(), cnt.cpu()
+    c1, c2 = p["c1"].cpu(), p["c2"].cpu()
+    for b in range(B):
+        n = int(ccnt[b])
+        ch = cidx[b, :n]
+        want1 = h1[b, ch].permute(1, 2, 0) - c1[ch]
+        assert torch.allclose(g1[b, :, :, :n].cpu(), want1, atol=1e-4, rtol=1e-4), f"conv1 image {b}"
+        want2 = h2[b, ch].permute(1, 2, 0) - c2[ch]
+        assert torch.allclose(g2[b, :, :, :n].cpu(), want2, atol=2e-4, rtol=1e-4), f"conv2 image {b}"
+        pad_hi = min((n + 3) // 4 * 4, W)
+        assert bool((g1[b, :, :, n:pad_hi] == 0).all()) and bool((g2[b, :, :, n:pad_hi] == 0).all())
+    assert torch.allclose(g3.cpu(), y3.permute(0, 2, 3, 1), atol=5e-4, rtol=1e-4)

@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the LAUDNet dynamic-inference hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one eval forward of the headline model over one synthetic batch that is already resident in HBM:
+LAUD-ResNet101, channel granularity 2-2-2-2, MLP(2) maskers, target FLOPs ratio 0.5, 224x224, batch 256 per GPU
+(BASELINE.json configs[1]).  Everything inside Bottleneck.forward runs in libldn_hip.so (maskers included --
+the masks are produced by the maskers inside the timed region, nothing is injected or cached); the static stem,
+average pool and classifier are library ops.  Weights are seeded random (no checkpoints offline), BN statistics
+randomised; the channel maskers' keep-bias is calibrated once, before timing, so that the realised FLOPs ratio is
+the "target-0.5" operating point of the released model.
+
+One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
+  roofline     : dominant kernel (the per-image channel-subset 3x3 conv, k_conv_image) -- algorithmic FLOPs per
+                 launch / mean launch duration measured with HIP events on the launch stream during the timed steps
+  cpu_baseline : the oracle (dense-emulation restatement of the reference, torch CPU) timed on the host cores on
+                 a bounded sample of the same workload
+and, unless --no-dense, `dense_emulation_gpu`: the same oracle run on the same GPU through PyTorch-ROCm
+(the "reference dense-emulation PyTorch path" the north star's >=5x is quoted against).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    "channel": dict(name="LAUD-ResNet101 channel-2222 target-0.5 @224",
+                    kw=dict(dyn_mode=["channel"] * 4, channel_dyn_granularity=[2, 2, 2, 2], channel_masker=["MLP"] * 4,
+                            channel_masker_layers=[2, 2, 2, 2], reduction_ratio=[16] * 4), p_channel=0.62, p_spatial=None),
+    "spatial": dict(name="LAUD-ResNet101 spatial S=4-4-2-1 target-0.5 @224",
+                    kw=dict(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[4, 4, 2, 1]), p_channel=None, p_spatial=0.5),
+    "layer": dict(name="LAUD-ResNet101 layer-skip target-0.5 @224",
+                  kw=dict(dyn_mode=["layer"] * 4), p_channel=None, p_spatial=0.5),
+}
+
+
+def blocks_of(model):
+    for s in (1, 2, 3, 4):
+        for blk in getattr(model, f"layer{s}"):
+            yield blk
+
+
+def calibrate_maskers(model, x, p_channel, p_spatial):
+    """One sequential pass: shift each masker's keep-logit bias so that the requested fraction of units is kept on
+    this batch (a trained checkpoint would bring its own operating point; none is available offline)."""
+    import torch.nn.functional as F
+    with torch.no_grad():
+        h = x.contiguous(memory_format=torch.channels_last)
+        h = model.maxpool(model.relu(model.bn1(model.conv1(h))))
+        state = (h, None, None, None, None, None, torch.tensor(0.0, device=x.device))
+        for blk in blocks_of(model):
+            if blk.masker_channel is not None and p_channel is not None:
+                mk = blk.masker_channel
+                G = mk.channel_dyn_group
+                _, _, _, logits = mk.lists(state[0], blk.channel_dyn_granularity, want_logits=True)
+                diff = (logits[:, :G] - logits[:, G:]).flatten().float()
+                shift = -torch.quantile(diff.cpu(), 1.0 - p_channel).item()
+                last = mk.conv[-1] if mk.layers == 2 else mk.conv
+                last.bias.data[:G] += shift
+                mk._drop_cache()
+            if blk.masker_spatial is not None and p_spatial is not None:
+                ms = blk.masker_spatial
+                g = ms.mask_channel_group
+                _, _, _, logits = ms(state[0], 1.0, want_logits=True)
+                diff = (logits[:, :g] - logits[:, g:]).flatten().float()
+                shift = -torch.quantile(diff.cpu(), 1.0 - p_spatial).item()
+                ms.conv.bias.data[:g] += shift
+                ms._drop_cache()
+            state = blk(state, 1.0)
+
+
+class KernelTimer:
+    """HIP-event timing of selected launches on the launch stream (torch's current stream == the stream the C ABI
+    is given).  Enabled only around the dominant kernel; two event records per launch."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, fn, select):
+        def timed(*a, **kw):
+            if not select(a, kw):
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            a_t, w = a[0], a[1]
+            self.records.append((e0, e1, kw.get("k_cnt"), kw.get("n_cnt"), tuple(a[4].shape), tuple(w.shape)))
+            return out
+        return timed
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot_ms, tot_flops, n = 0.0, 0.0, 0
+        for e0, e1, kc, nc, oshape, wshape in self.records:
+            B, Ho, Wo, _ = oshape
+            cout, taps, cin = wshape
+            kb = kc.double() if kc is not None else torch.full((B,), float(cin), dtype=torch.float64)
+            nb = nc.double() if nc is not None else torch.full((B,), float(cout), dtype=torch.float64)
+            tot_flops += float((2.0 * Ho * Wo * taps * kb.cpu() * nb.cpu()).sum())
+            tot_ms += e0.elapsed_time(e1)
+            n += 1
+        return n, tot_ms, tot_flops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="channel")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-emulation GPU baseline")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    args = ap.parse_args()
+
+    import laudnet_amd
+    from laudnet_amd import distributed as D
+    from laudnet_amd import ops
+    from fill import fill_state_dict, seeded_randn
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    laudnet_amd.load_library()   # fail loudly if the HIP extension is missing
+
+    wl = WORKLOADS[args.workload]
+    kw = dict(wl["kw"], num_classes=1000, input_size=224)
+    model = laudnet_amd.uni_resnet101(**kw).eval()
+    sd = fill_state_dict(model.state_dict(), 1)
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    torch.backends.cudnn.benchmark = True
+    x = seeded_randn((args.batch, 3, 224, 224), 1000 + rank).to(dev).contiguous(memory_format=torch.channels_last)
+    calibrate_maskers(model, x, wl["p_channel"], wl["p_spatial"])
+    calibrated_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    def step():
+        with torch.no_grad():
+            return D.gather_outputs(model(x, 1.0))
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+
+    timer = KernelTimer()
+    orig_conv_image = ops.conv_image
+    ops.conv_image = timer.wrap(orig_conv_image, lambda a, k: k.get("ksize", 1) == 3)
+
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.conv_image = orig_conv_image
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    images = world * args.batch * args.steps
+    flops_perc = out[5].float().mean().item()
+    flops_per_img = out[6].item()
+    result = {
+        "metric": "images/sec, LAUD-ResNet101 @224 bs256 (dynamic-inference hot path)",
+        "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded randn images, seeded random weights, randomised BN stats)",
+        "config": {"workload": wl["name"] + f" bs{args.batch}/GPU, masks produced by the maskers in the timed region",
+                   "batch_per_gpu": args.batch, "global_batch": world * args.batch,
+                   "parallelism": f"dp{world} (batch shards, all-gather logits + all-reduce stats over RCCL)",
+                   "mean_block_flops_ratio": round(flops_perc, 4), "module_macs_per_image": flops_per_img},
+    }
+
+    n, ms, flops = timer.summary()
+    if n:
+        achieved = flops / (ms * 1e-3) / 1e12
+        result["roofline"] = {"kernel": "k_conv_image (3x3 per-image channel-subset conv, fp32 MFMA)", "bound": "mfma",
+                              "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launches": n,
+                              "avg_launch_us": 1e3 * ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9}
+
+    if rank == 0 and world == 1:
+        from oracle import torch_ref as TR
+        ref = TR.resnet101_ref(**kw).eval()
+        ref.load_state_dict(calibrated_sd)
+        if not args.no_dense:
+            try:
+                refg = ref.to(dev).to(memory_format=torch.channels_last)
+                with torch.no_grad():
+                    for _ in range(2):
+                        want = refg(x, 1.0)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    reps = 3
+                    for _ in range(reps):
+                        want = refg(x, 1.0)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / reps
+                err = (out[0] - want[0]).abs().max().item()
+                result["dense_emulation_gpu"] = {"value": args.batch / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt,
+                                                 "kind": "oracle dense emulation, PyTorch-ROCm fp32 channels_last, same GPU",
+                                                 "max_abs_logit_diff_vs_hip": err,
+                                                 "logit_scale": want[0].abs().max().item()}
+                result["realised_speedup_vs_dense_emulation"] = result["value"] / (args.batch / dt)
+                ref = ref.cpu()
+            except Exception as e:  # the baseline is informative only
+                result["dense_emulation_gpu"] = {"error": repr(e)[:200]}
+        if not args.no_cpu:
+            cores = os.cpu_count() or 1
+            torch.set_num_threads(cores)
+            xc = x[: args.cpu_batch].cpu().contiguous()
+            ref = ref.cpu()
+            with torch.no_grad():
+                ref(xc[:2], 1.0)
+                t0 = time.perf_counter()
+                reps = 0
+                while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+                    ref(xc, 1.0)
+                    reps += 1
+                dt = (time.perf_counter() - t0) / reps
+            result["cpu_baseline"] = {"value": args.cpu_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+                                      "sample": f"{reps} forward passes of batch {args.cpu_batch} (same model/weights/inputs), "
+                                                f"oracle dense emulation in torch fp32 on {cores} threads"}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,7 +8,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libldn_hip.so")
+LIB_PATH = os.environ.get("LDN_LIB_PATH", os.path.join(_PKG, "libldn_hip.so"))  # override: kernel tuning only
 
 _P = C.c_void_p
 _I = C.c_int

@@ -9,6 +9,7 @@
 namespace ldn {
 
 void set_error(const char* fmt, ...);
+bool allow_dynamic_lds(const void* kernel, size_t bytes);
 
 #define LDN_REQUIRE(cond, ...)                  \
     do {                                        \

@@ -4,12 +4,9 @@
 //                  the whole batch; A rows are gathered on load through an index list (1x1) or a
 //                  9-neighbour table (3x3); the epilogue applies the folded BN (+ReLU) and either writes
 //                  packed rows or scatter-adds into the NHWC residual stream.
-//   k_conv_image : channel mode.  One ragged GEMM per image: the image's active channel list selects
-//                  weight rows (output subset) and/or weight columns (input subset) while the weight tile
-//                  is staged; activations are "left-packed" (column i of image b = channel k_idx[b][i]).
-//                  Without index lists it is a plain dense NHWC 1x1/3x3 conv (downsample branch).
+//   (channel mode lives in ldn_conv_image.hip)
 //
-// Both share one main loop: 256 threads = 4 wave64; block tile BM x BN, K chunk 32; A and B tiles are
+// Main loop: 256 threads = 4 wave64; block tile BM x BN, K chunk 32; A and B tiles are
 // K-contiguous in memory (NHWC pixels rows, [cout][tap][cin] weights) so both are staged with 16-byte
 // loads into LDS rows padded to 36 floats (144 B: ds_write_b128 and ds_read_b128 are conflict-free), double
 // buffered with one barrier per chunk; v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD) accumulates
@@ -186,211 +183,12 @@ __global__ __launch_bounds__(256) void k_conv_rows(const RowsArgs p) {
 }
 
 // =====================================================================================================
-// image family
-// =====================================================================================================
-struct ImgArgs {
-    const float* a; int lda;
-    int B, Hi, Wi, ksize, stride, Ho, Wo;
-    const float* w; int cin, cout;
-    const int32_t* k_idx; const int32_t* k_cnt;
-    const int32_t* n_idx; const int32_t* n_cnt;
-    const float* scale; const float* shift; int shift_classes;
-    const float* post_sub; int relu;
-    const float* residual; int ldr;
-    float* out; int ldo;
-    int ntn;
-};
-
-// KV = how many consecutive packed K positions are guaranteed to be consecutive channels (1, 2 or 4)
-template <class C, int KV>
-__global__ __launch_bounds__(256) void k_conv_image(const ImgArgs p) {
-    constexpr int BM = C::BM, BN = C::BN;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + 2 * BM * LDT;
-    int* s_pix = reinterpret_cast<int*>(smem + C::LDS_FLOATS);  // [BM] (oy<<16|ox) or -1
-    int* s_cls = s_pix + BM;                                     // [BM] border class * cout
-    int* s_nch = s_cls + BM;                                     // [BN] channel of tile column, -1 pad, -2 skip
-    int* s_kidx = s_nch + BN;                                    // [cin] (only with k_idx)
-
-    const int tid = threadIdx.x;
-    const int bid = blockIdx.x;
-    // image-major-inner order: with B % 8 == 0 every tile of image b runs on XCD b % 8, whose L2 then
-    // holds that image's activations; the (shared) weights are resident in every XCD's L2.
-    const int b = bid % p.B;
-    const int t = bid / p.B;
-    const int nt = t % p.ntn, mt = t / p.ntn;
-    const int HWo = p.Ho * p.Wo;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int Kb = p.k_idx ? p.k_cnt[b] : p.cin;
-    const int Nb = p.n_idx ? p.n_cnt[b] : p.cout;
-    const int Nb4 = min(round_up(Nb, 4), p.cout);
-    if (n0 >= Nb4 || m0 >= HWo) return;
-    const int T = p.ksize * p.ksize;
-    const int pad = p.ksize >> 1;
-
-    for (int i = tid; i < BM; i += 256) {
-        const int m = m0 + i;
-        int pix = -1, cls = 0;
-        if (m < HWo) {
-            const int oy = m / p.Wo, ox = m - oy * p.Wo;
-            pix = (oy << 16) | ox;
-            if (p.shift_classes > 1) {
-                const int top = oy * p.stride - pad < 0, bot = oy * p.stride + pad >= p.Hi;
-                const int lef = ox * p.stride - pad < 0, rig = ox * p.stride + pad >= p.Wi;
-                cls = ((top | (bot << 1)) * 4 + (lef | (rig << 1))) * p.cout;
-            }
-        }
-        s_pix[i] = pix;
-        s_cls[i] = cls;
-    }
-    for (int i = tid; i < BN; i += 256) {
-        const int j = n0 + i;
-        s_nch[i] = j < Nb ? (p.n_idx ? p.n_idx[(size_t)b * p.cout + j] : j) : (j < Nb4 ? -1 : -2);
-    }
-    if (p.k_idx)
-        for (int i = tid; i < Kb; i += 256) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
-    __syncthreads();
-
-    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
-    f32x4 ra[C::AI], rb[C::BI];
-    long aoff[C::AI];   // element offset of this thread's A rows for the current tap, -1 = zero row
-    long boff[C::BI];   // element offset of w[ch_n][tap][0], -1 = zero row
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const int Kb4 = p.k_idx ? round_up(Kb, 4) : p.cin;
-
-    auto set_tap = [&](int tap) {
-        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
-#pragma unroll
-        for (int u = 0; u < C::AI; ++u) {
-            const int pix = s_pix[lrow + 32 * u];
-            long off = -1;
-            if (pix >= 0) {
-                const int iy = (pix >> 16) * p.stride + ky - pad, ix = (pix & 0xffff) * p.stride + kx - pad;
-                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-                    off = ((long)(b * p.Hi + iy) * p.Wi + ix) * p.lda;
-            }
-            aoff[u] = off;
-        }
-#pragma unroll
-        for (int u = 0; u < C::BI; ++u) {
-            const int chn = s_nch[lrow + 32 * u];
-            boff[u] = chn >= 0 ? ((long)chn * T + tap) * p.cin : -1;
-        }
-    };
-    auto gload = [&](int c0) {
-        const int c = c0 + lc4;
-#pragma unroll
-        for (int u = 0; u < C::AI; ++u)
-            ra[u] = (aoff[u] >= 0 && c < Kb4) ? *reinterpret_cast<const f32x4*>(p.a + aoff[u] + c) : zero4;
-#pragma unroll
-        for (int u = 0; u < C::BI; ++u) {
-            f32x4 v = zero4;
-            if (boff[u] >= 0 && c < Kb) {
-                const float* wr = p.w + boff[u];
-                if (!p.k_idx) {
-                    v = *reinterpret_cast<const f32x4*>(wr + c);
-                } else if (KV == 4) {
-                    v = *reinterpret_cast<const f32x4*>(wr + s_kidx[c]);
-                } else if (KV == 2) {
-                    const float2 lo = *reinterpret_cast<const float2*>(wr + s_kidx[c]);
-                    v[0] = lo.x; v[1] = lo.y;
-                    if (c + 2 < Kb) {
-                        const float2 hi = *reinterpret_cast<const float2*>(wr + s_kidx[c + 2]);
-                        v[2] = hi.x; v[3] = hi.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c + e < Kb) v[e] = wr[s_kidx[c + e]];
-                }
-            }
-            rb[u] = v;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < C::AI; ++u)
-            *reinterpret_cast<f32x4*>(As + buf * BM * LDT + (lrow + 32 * u) * LDT + lc4) = ra[u];
-#pragma unroll
-        for (int u = 0; u < C::BI; ++u)
-            *reinterpret_cast<f32x4*>(Bs + buf * BN * LDT + (lrow + 32 * u) * LDT + lc4) = rb[u];
-    };
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / C::WGN, wn = wave % C::WGN;
-    const int l31 = lane & 31, h = lane >> 5;
-    f32x16 acc[C::TM][C::TN];
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int cpt = ceil_div(Kb, BK);
-    const int nch = T * cpt;
-    if (nch > 0) {
-        int tap = 0, c0 = 0;
-        set_tap(0);
-        gload(0);
-        lstore(0);
-        c0 += BK;
-        if (c0 >= Kb) { c0 = 0; tap = 1; if (tap < T) set_tap(tap); }
-        __syncthreads();
-        for (int ch = 0; ch < nch; ++ch) {
-            const bool more = ch + 1 < nch;
-            if (more) gload(c0);
-            mma_chunk<C>(As + (ch & 1) * BM * LDT, Bs + (ch & 1) * BN * LDT, acc, wm * C::WM, wn * C::WN, l31, h);
-            if (more) {
-                lstore((ch + 1) & 1);
-                c0 += BK;
-                if (c0 >= Kb) { c0 = 0; ++tap; if (tap < T) set_tap(tap); }
-            }
-            __syncthreads();
-        }
-    }
-
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j) {
-        const int col = wn * C::WN + j * 32 + l31;
-        const int chn = s_nch[col];
-        if (chn == -2) continue;
-        const int n = n0 + col;
-        const float sc = chn >= 0 ? p.scale[chn] : 0.f;
-        const float ps = (chn >= 0 && p.post_sub) ? p.post_sub[chn] : 0.f;
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * C::WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (s_pix[row] < 0) continue;
-                const size_t orow = (size_t)b * HWo + m0 + row;
-                float v = 0.f;
-                if (chn >= 0) {
-                    v = acc[i][j][r] * sc + p.shift[s_cls[row] + chn];
-                    if (p.residual) v += p.residual[orow * p.ldr + n];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    v -= ps;
-                }
-                p.out[orow * p.ldo + n] = v;
-            }
-        }
-    }
-}
-
-// =====================================================================================================
 // host side
 // =====================================================================================================
 template <class C>
 static int launch_rows(const RowsArgs& a, hipStream_t st) {
     const size_t lds = C::LDS_FLOATS * sizeof(float) + (size_t)C::BM * (a.taps + 1) * sizeof(int);
-    static bool configured = false;  // per instantiation
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        configured = true;
-    }
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_conv_rows<C>), lds), "k_conv_rows: cannot reserve %zu B of LDS", lds);
     RowsArgs p = a;
     p.ntn = ceil_div(a.cout, C::BN);
     const int mt8 = round_up(ceil_div(a.m_cap, C::BM), kXcds);
@@ -398,32 +196,6 @@ static int launch_rows(const RowsArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_conv_rows<C>, dim3(grid), dim3(256), lds, st, p);
     LDN_CHECK_LAUNCH("k_conv_rows");
     return LDN_OK;
-}
-
-template <class C, int KV>
-static int launch_image(const ImgArgs& a, hipStream_t st) {
-    const size_t lds = C::LDS_FLOATS * sizeof(float) +
-                       (size_t)(2 * C::BM + C::BN + (a.k_idx ? a.cin : 0)) * sizeof(int);
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_image<C, KV>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        configured = true;
-    }
-    ImgArgs p = a;
-    p.ntn = ceil_div(a.cout, C::BN);
-    const int mtn = ceil_div(a.Ho * a.Wo, C::BM);
-    const unsigned grid = (unsigned)a.B * mtn * p.ntn;
-    hipLaunchKernelGGL((k_conv_image<C, KV>), dim3(grid), dim3(256), lds, st, p);
-    LDN_CHECK_LAUNCH("k_conv_image");
-    return LDN_OK;
-}
-
-template <class C>
-static int launch_image_kv(const ImgArgs& a, int kv, hipStream_t st) {
-    if (kv >= 4) return launch_image<C, 4>(a, st);
-    if (kv >= 2) return launch_image<C, 2>(a, st);
-    return launch_image<C, 1>(a, st);
 }
 
 }  // namespace ldn
@@ -450,49 +222,4 @@ extern "C" int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int
     if (cout > 64) return launch_rows<TileCfg<128, 128, 2, 2>>(p, st);
     if (cout > 32) return launch_rows<TileCfg<128, 64, 2, 2>>(p, st);
     return launch_rows<TileCfg<128, 32, 4, 1>>(p, st);
-}
-
-extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, int stride, int Ho, int Wo,
-                              const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt,
-                              int kgran, const int32_t* n_idx, const int32_t* n_cnt, const float* scale,
-                              const float* shift, int shift_classes, const float* post_sub, int relu,
-                              const float* residual, int ldr, float* out, int ldo, void* stream) {
-    LDN_REQUIRE(a && w && scale && shift && out, "ldn_conv_image: null pointer");
-    LDN_REQUIRE(ksize == 1 || ksize == 3, "ldn_conv_image: ksize must be 1 or 3 (got %d)", ksize);
-    LDN_REQUIRE(stride >= 1 && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "ldn_conv_image: bad geometry");
-    LDN_REQUIRE((Ho - 1) * stride < Hi && (Wo - 1) * stride < Wi, "ldn_conv_image: output grid exceeds input");
-    LDN_REQUIRE(Ho < 65536 && Wo < 65536, "ldn_conv_image: spatial size too large");
-    LDN_REQUIRE(cin > 0 && cout > 0 && cin % 4 == 0, "ldn_conv_image: cin must be a positive multiple of 4 (got %d)", cin);
-    LDN_REQUIRE(lda % 4 == 0, "ldn_conv_image: lda must be a multiple of 4");
-    LDN_REQUIRE((k_idx == nullptr) == (k_cnt == nullptr) && (n_idx == nullptr) == (n_cnt == nullptr),
-                "ldn_conv_image: index list and count must be given together");
-    LDN_REQUIRE(shift_classes == 1 || shift_classes == 16, "ldn_conv_image: shift_classes must be 1 or 16");
-    LDN_REQUIRE(!k_idx || kgran >= 1, "ldn_conv_image: kgran must be >= 1");
-    LDN_REQUIRE(ldo >= cout, "ldn_conv_image: ldo < cout");
-    LDN_REQUIRE(!residual || ldr >= cout, "ldn_conv_image: ldr < cout");
-    LDN_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "ldn_conv_image: a/w must be 16-byte aligned");
-    ImgArgs p{a, lda, B, Hi, Wi, ksize, stride, Ho, Wo, w, cin, cout, k_idx, k_cnt, n_idx, n_cnt,
-              scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, 0};
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int kv = k_idx ? (kgran % 4 == 0 ? 4 : (kgran % 2 == 0 ? 2 : 1)) : 4;
-    const int hw = Ho * Wo;
-    // M tile: least padded rows per image, ties to the larger tile
-    int bm = 128;
-    if (hw < 512) {
-        int best = round_up(hw, 128);
-        for (int cand : {64, 32}) {
-            const int padded = round_up(hw, cand);
-            if (padded < best) { best = padded; bm = cand; }
-        }
-    }
-    if (bm == 128) {
-        if (cout > 64) return launch_image_kv<TileCfg<128, 128, 2, 2>>(p, kv, st);
-        if (cout > 32) return launch_image_kv<TileCfg<128, 64, 2, 2>>(p, kv, st);
-        return launch_image_kv<TileCfg<128, 32, 4, 1>>(p, kv, st);
-    }
-    if (bm == 64) {
-        if (cout > 64) return launch_image_kv<TileCfg<64, 128, 2, 2>>(p, kv, st);
-        return launch_image_kv<TileCfg<64, 64, 2, 2>>(p, kv, st);
-    }
-    return launch_image_kv<TileCfg<32, 128, 1, 4>>(p, kv, st);
 }

@@ -1,0 +1,446 @@
+// k_conv_image -- channel mode: one ragged fp32-MFMA GEMM per image (gfx950 / CDNA4).
+//
+// For image b the active channel list selects weight rows (output subset) and/or weight columns (input
+// subset) while the weight tile is staged; activations are "left-packed" (column i of image b = channel
+// k_idx[b][i]).  Without index lists it is a plain dense NHWC 1x1/3x3 conv (downsample branch, conv_linear
+// masker).  See include/ldn_hip.h:ldn_conv_image for the exact contract.
+//
+// Structure
+//   * Block = (image, MS*32 output pixels, up to NS*32 packed output columns), 256 threads = 4 wave64.
+//     Raggedness is handled at 32x32 MFMA-tile granularity in BOTH dimensions: the block's valid
+//     m-subtiles x n-subtiles (run-time counts) are dealt round-robin to the 4 waves, so a 68-pixel x
+//     159-channel remainder costs 3 x 5 = 15 tiles spread 4/4/4/3 instead of a padded 128 x 256 tile.
+//   * K is walked in chunks of 32 (per 3x3 tap).  Tiles live in LDS as unpadded 128-byte rows whose eight
+//     16-byte slots are XOR-swizzled with (row >> 1) & 7: conflict-free for the ds_read_b128 fragment reads
+//     and -- because the swizzle is applied to the SOURCE address -- compatible with global_load_lds, whose
+//     LDS destination is wave-uniform base + lane * 16.
+//   * A rows (NHWC pixels) and contiguous-K weight rows go HBM/L2 -> LDS directly (global_load_lds_dwordx4,
+//     no VGPR round trip, no ds_write); K-gathered weight rows (granularity 1/2) are staged through VGPRs.
+//   * Two LDS buffers, ONE barrier per chunk: the next chunk's loads are issued right after the barrier
+//     and land while the current chunk's MFMAs run; 2 workgroups per CU (<= 79 KiB each).
+//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles): lane (i, h) of a fragment read holds k = 8*g + 4*h + q,
+//     so one ds_read_b128 per operand feeds four MFMAs; the reads of group g+1 are issued before the MFMAs
+//     of group g.
+//   * Epilogue: folded-BN affine per lane-column, then a per-wave 32x32 transpose through LDS so residual
+//     loads and output stores are 16 B per lane along the channel axis.
+#include "ldn_common.h"
+
+#ifndef LDN_ABLATE
+#define LDN_ABLATE 0   // tuning only: 1 = no MFMA, 2 = no loads in the K loop (results are wrong)
+#endif
+
+namespace ldn {
+
+struct ImgArgs {
+    const float* a; int lda;
+    int B, Hi, Wi, ksize, stride, Ho, Wo;
+    const float* w; int cin, cout;
+    const int32_t* k_idx; const int32_t* k_cnt;
+    const int32_t* n_idx; const int32_t* n_cnt;
+    const float* scale; const float* shift; int shift_classes;
+    const float* post_sub; int relu;
+    const float* residual; int ldr;
+    float* out; int ldo;
+    int ntn;    // N blocks per image
+    int bn;     // columns per N block (multiple of 32, <= NS*32)
+};
+
+constexpr int BK = 32;   // K chunk = one 128-byte LDS row
+
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+#ifdef LDN_TRACE   // tuning only: per-block {start, end, hw_id, xcc_id, ntiles, t_mainloop_end} timestamps
+__device__ unsigned long long* g_trace = nullptr;
+#define LDN_TRACE_BEGIN unsigned long long tr_t0 = __builtin_amdgcn_s_memtime(), tr_bar = 0, tr_mma = 0, tr_iss = 0, tr_a = 0, tr_b = 0;
+#define LDN_TRACE_T(x) x = __builtin_amdgcn_s_memtime();
+#define LDN_TRACE_ADD(acc, a, b) acc += (b) - (a);
+#define LDN_TRACE_MID unsigned long long tr_t1 = __builtin_amdgcn_s_memtime();
+#define LDN_TRACE_END                                                                                     \
+    if (tid == 0 && g_trace) {                                                                            \
+        unsigned long long* r = g_trace + (size_t)blockIdx.x * 6;                                         \
+        r[0] = tr_t0; r[1] = __builtin_amdgcn_s_memtime();                                                \
+        r[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   /* HW_REG_HW_ID */          \
+        r[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  /* HW_REG_XCC_ID */         \
+        r[4] = ntiles | (tr_bar << 32); r[5] = (tr_mma << 32) | (tr_iss & 0xffffffffull);              \
+    }
+#else
+#define LDN_TRACE_BEGIN
+#define LDN_TRACE_T(x)
+#define LDN_TRACE_ADD(acc, a, b)
+#define LDN_TRACE_MID
+#define LDN_TRACE_END
+#endif
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+// MS x NS = m-subtiles x n-subtiles of 32 per block, MS + NS <= 9 (two 36 KiB buffers, 2 blocks per CU).
+// KV   = how many consecutive packed K positions are guaranteed to be consecutive channels (1, 2 or 4);
+//        KV == 4 (and the no-k_idx case) stages weights with global_load_lds, KV < 4 through VGPRs.
+// KSKIP= skip the empty 8-wide k groups of a partial chunk (pays when the per-tap K is short).
+template <int MS, int NS, int KV, bool KSKIP>
+__global__ __launch_bounds__(256, 2) void k_conv_image(const ImgArgs p) {
+    static_assert(MS >= 4 && MS + NS <= 9, "LDS budget");
+    constexpr int ACC = (MS * NS + 3) / 4;
+    constexpr int BM = MS * 32, BNX = NS * 32;
+    constexpr int BUF = (BM + BNX) * BK;                   // floats per LDS buffer
+    constexpr bool BGLDS = KV == 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_sc = smem + 2 * BUF;                          // [BNX] BN scale of the column's channel
+    float* s_ps = s_sc + BNX;                              // [BNX] post-ReLU constant of the column's channel
+    int* s_pix = reinterpret_cast<int*>(s_ps + BNX);       // [BM] (oy<<16|ox) or -1
+    int* s_cls = s_pix + BM;                               // [BM] border class * cout
+    int* s_nch = s_cls + BM;                               // [BNX] channel of column, -1 zero pad, -2 skip
+    int* s_kidx = s_nch + BNX;                             // [cin] (only with k_idx)
+
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    // image-fastest block order: with B % 8 == 0 every block of image b runs on XCD b % 8, whose L2 then holds
+    // that image's activations; the (shared) weights are resident in every XCD's L2.
+    const int b = bid % p.B;
+    const int t = bid / p.B;
+    const int nt = t % p.ntn, mt = t / p.ntn;
+    const int HWo = p.Ho * p.Wo;
+    const int m0 = mt * BM, n0 = nt * p.bn;
+    const int Kb = p.k_idx ? p.k_cnt[b] : p.cin;
+    const int Nb = p.n_idx ? p.n_cnt[b] : p.cout;
+    const int Nb4 = min(round_up(Nb, 4), p.cout);
+    if (n0 >= Nb4 || m0 >= HWo) return;
+    const int T = p.ksize * p.ksize;
+    const int pad = p.ksize >> 1;
+    const int msub = ceil_div(min(HWo - m0, BM), 32);          // valid m-subtiles (1..MS)
+    const int nsub = ceil_div(min(Nb4 - n0, p.bn), 32);        // valid n-subtiles (1..NS)
+    const int ntiles = msub * nsub;
+    LDN_TRACE_BEGIN
+
+    for (int i = tid; i < BM; i += 256) {
+        const int m = m0 + i;
+        int pix = -1, cls = 0;
+        if (m < HWo) {
+            const int oy = m / p.Wo, ox = m - oy * p.Wo;
+            pix = (oy << 16) | ox;
+            if (p.shift_classes > 1) {
+                const int top = oy * p.stride - pad < 0, bot = oy * p.stride + pad >= p.Hi;
+                const int lef = ox * p.stride - pad < 0, rig = ox * p.stride + pad >= p.Wi;
+                cls = ((top | (bot << 1)) * 4 + (lef | (rig << 1))) * p.cout;
+            }
+        }
+        s_pix[i] = pix;
+        s_cls[i] = cls;
+    }
+    for (int i = tid; i < BNX; i += 256) {
+        const int j = n0 + i;
+        const bool in_block = i < p.bn;
+        const int chn = (in_block && j < Nb) ? (p.n_idx ? p.n_idx[(size_t)b * p.cout + j] : j)
+                                             : ((in_block && j < Nb4) ? -1 : -2);
+        s_nch[i] = chn;
+        s_sc[i] = chn >= 0 ? p.scale[chn] : 0.f;
+        s_ps[i] = (chn >= 0 && p.post_sub) ? p.post_sub[chn] : 0.f;
+    }
+    if (p.k_idx)
+        for (int i = tid; i < Kb; i += 256) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- staging coordinates: one wave instruction fills 8 rows x 8 slots (1 KiB); this thread moves physical
+    // slot (lane & 7) of row (wave + 4u) * 8 + (lane >> 3), i.e. logical slot qt = slot ^ ((row >> 1) & 7)
+    const int rg = lane >> 3, pslot = lane & 7;
+    const int qt = pslot ^ (((rg >> 1) + 4 * (wave & 1)) & 7);
+    const int kq = qt * 4;                                     // K offset of this thread's slot inside a chunk
+    long aoff[MS];   // element offset of this thread's A rows for the current tap, -1 = zero row
+    long boff[NS];   // element offset of w[ch_n][tap][0], -1 = zero row
+    f32x4 rb[NS];    // VGPR-staged weight slots (only when !BGLDS)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int Kb4 = p.k_idx ? round_up(Kb, 4) : p.cin;
+
+    auto set_tap = [&](int tap) {
+        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+#pragma unroll
+        for (int u = 0; u < MS; ++u) {
+            long off = -1;
+            if (u < msub) {
+                const int pix = s_pix[(wave + 4 * u) * 8 + rg];
+                if (pix >= 0) {
+                    const int iy = (pix >> 16) * p.stride + ky - pad, ix = (pix & 0xffff) * p.stride + kx - pad;
+                    if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+                        off = ((long)(b * p.Hi + iy) * p.Wi + ix) * p.lda;
+                }
+            }
+            aoff[u] = off;
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            long off = -1;
+            if (u < nsub) {
+                const int chn = s_nch[(wave + 4 * u) * 8 + rg];
+                if (chn >= 0) off = ((long)chn * T + tap) * p.cin;
+            }
+            boff[u] = off;
+        }
+    };
+    // issue the loads of chunk (current tap, c0) into LDS buffer `buf` (A always by LDS-DMA; B by LDS-DMA or VGPRs)
+    auto issue = [&](int c0, int buf) {
+        const int c = c0 + kq;
+        float* base = smem + buf * BUF;
+#pragma unroll
+        for (int u = 0; u < MS; ++u)
+            if (u < msub)
+                glds16((aoff[u] >= 0 && c < Kb4) ? p.a + aoff[u] + c : g_zero16, base + (wave + 4 * u) * 8 * BK);
+        // packed K position -> channel (same for every B row of this thread)
+        int k0 = c, k1 = c + 1, k2 = c + 2, k3 = c + 3;
+        if (p.k_idx && c < Kb) {
+            k0 = s_kidx[c];
+            if (KV == 2) k2 = c + 2 < Kb ? s_kidx[c + 2] : 0;
+            if (KV == 1) {
+                k1 = c + 1 < Kb ? s_kidx[c + 1] : 0;
+                k2 = c + 2 < Kb ? s_kidx[c + 2] : 0;
+                k3 = c + 3 < Kb ? s_kidx[c + 3] : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (u >= nsub) continue;
+            const bool ok = boff[u] >= 0 && c < Kb;
+            if (BGLDS) {
+                glds16(ok ? p.w + boff[u] + k0 : g_zero16, base + (BM + (wave + 4 * u) * 8) * BK);
+            } else {
+                f32x4 v = zero4;
+                if (ok) {
+                    const float* wr = p.w + boff[u];
+                    if (!p.k_idx) {
+                        v = *reinterpret_cast<const f32x4*>(wr + k0);
+                    } else if (KV == 2) {
+                        const float2 lo = *reinterpret_cast<const float2*>(wr + k0);
+                        v[0] = lo.x; v[1] = lo.y;
+                        if (c + 2 < Kb) {
+                            const float2 hi = *reinterpret_cast<const float2*>(wr + k2);
+                            v[2] = hi.x; v[3] = hi.y;
+                        }
+                    } else {
+                        v[0] = wr[k0];
+                        if (c + 1 < Kb) v[1] = wr[k1];
+                        if (c + 2 < Kb) v[2] = wr[k2];
+                        if (c + 3 < Kb) v[3] = wr[k3];
+                    }
+                }
+                rb[u] = v;
+            }
+        }
+    };
+    auto bstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+            if (u < nsub)
+                *reinterpret_cast<f32x4*>(smem + buf * BUF + (BM + (wave + 4 * u) * 8 + rg) * BK + pslot * 4) = rb[u];
+    };
+
+    // ---- MFMA tile assignment
+    const int l31 = lane & 31, h = lane >> 5;
+    const int swl = (l31 >> 1) & 7;
+    int so[BK / 8];                            // swizzled float offset of k group g for this lane
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) so[g] = ((2 * g + h) ^ swl) * 4;
+    f32x16 acc[ACC];
+    int a_off[ACC], b_off[ACC];
+#pragma unroll
+    for (int s = 0; s < ACC; ++s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+        const int tt = min(wave + 4 * s, ntiles - 1);   // tile tt -> (m-subtile tt % msub, n-subtile tt / msub)
+        const int nj = tt / msub, mi = tt - nj * msub;
+        a_off[s] = (mi * 32 + l31) * BK;
+        b_off[s] = (BM + nj * 32 + l31) * BK;
+    }
+    const int my_tiles = ntiles > wave ? (ntiles - wave + 3) / 4 : 0;   // tiles wave, wave+4, ... < ntiles
+
+    const int cpt = ceil_div(Kb, BK);
+    const int nch = T * cpt;
+    if (nch > 0) {
+        int tap = 0, c0 = 0;
+        auto advance = [&]() {
+            c0 += BK;
+            if (c0 >= Kb) { c0 = 0; ++tap; if (tap < T) set_tap(tap); }
+        };
+        set_tap(0);
+        issue(0, 0);
+        int kvalid = min(Kb, BK);              // valid K of the chunk in flight
+        advance();
+        for (int ch = 0; ch < nch; ++ch) {
+            const int buf = ch & 1;
+            if (!BGLDS) bstore(buf);
+            const int kgroups = ceil_div(kvalid, 8);   // 8-wide k groups that hold data in this chunk
+            LDN_TRACE_T(tr_a)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of chunk ch has landed
+            __syncthreads();
+            LDN_TRACE_T(tr_b)
+            LDN_TRACE_ADD(tr_bar, tr_a, tr_b)
+#if !(LDN_ABLATE & 2)
+            if (ch + 1 < nch) { kvalid = min(Kb - c0, BK); issue(c0, buf ^ 1); advance(); }
+#else
+            if (ch + 1 < nch) { kvalid = min(Kb - c0, BK); advance(); }
+#endif
+            LDN_TRACE_T(tr_a)
+            LDN_TRACE_ADD(tr_iss, tr_b, tr_a)
+            const float* tb = smem + buf * BUF;
+            f32x4 af = *reinterpret_cast<const f32x4*>(tb + a_off[0] + so[0]);
+            f32x4 bf = *reinterpret_cast<const f32x4*>(tb + b_off[0] + so[0]);
+#pragma unroll
+            for (int s = 0; s < ACC; ++s) {
+                if (s < my_tiles) {
+#pragma unroll
+                    for (int g = 0; g < BK / 8; ++g) {
+                        f32x4 an = af, bn = bf;
+                        if (g + 1 < BK / 8) {
+                            an = *reinterpret_cast<const f32x4*>(tb + a_off[s] + so[g + 1]);
+                            bn = *reinterpret_cast<const f32x4*>(tb + b_off[s] + so[g + 1]);
+                        } else if (s + 1 < ACC) {   // offsets of unused slots are clamped to a valid tile
+                            an = *reinterpret_cast<const f32x4*>(tb + a_off[s + 1] + so[0]);
+                            bn = *reinterpret_cast<const f32x4*>(tb + b_off[s + 1] + so[0]);
+                        }
+                        if (!KSKIP || g < kgroups) {
+#if LDN_ABLATE & 1
+                            asm volatile("" ::"v"(af), "v"(bf));
+#else
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bf[q], acc[s], 0, 0, 0);
+#endif
+                        }
+                        // pin the schedule: the two fragment reads of the NEXT group first, then this group's 4 MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        af = an;
+                        bf = bn;
+                    }
+                }
+            }
+            LDN_TRACE_T(tr_b)
+            LDN_TRACE_ADD(tr_mma, tr_a, tr_b)
+        }
+        __syncthreads();   // every wave is done with both buffers before buffer 0 becomes the epilogue scratch
+    }
+
+    LDN_TRACE_MID
+    // ---- epilogue
+    float* scratch = smem + wave * (32 * 32);
+    const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+#pragma unroll
+    for (int s = 0; s < ACC; ++s) {
+        const int tt = wave + 4 * s;
+        if (tt >= ntiles) continue;
+        const int nj = tt / msub, mi = tt - nj * msub;
+        const int col = nj * 32 + l31;
+        const int chn = s_nch[col];
+        const float sc = s_sc[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = chn >= 0 ? acc[s][r] * sc + p.shift[s_cls[mi * 32 + row] + chn] : 0.f;
+            scratch[row * 32 + l31] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int ccol = nj * 32 + tc4;
+        if (s_nch[ccol] != -2) {
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(s_ps + ccol);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = mi * 32 + trow + 8 * it;
+                if (s_pix[row] < 0) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (trow + 8 * it) * 32 + tc4);
+                const size_t orow = (size_t)b * HWo + m0 + row;
+                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + orow * p.ldr + n0 + ccol);
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                v -= ps;
+                *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + n0 + ccol) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    LDN_TRACE_END
+}
+
+// ---------------------------------------------------------------------------------------------- host
+template <int MS, int NS, int KV, bool KSKIP>
+static int launch_k(const ImgArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)2 * (MS + NS) * 32 * BK * sizeof(float) + (size_t)(2 * NS * 32) * sizeof(float) +
+                       (size_t)(2 * MS * 32 + NS * 32 + (p.k_idx ? p.cin : 0)) * sizeof(int);
+    LDN_REQUIRE(lds <= 80 * 1024, "k_conv_image: %zu B of LDS exceed the 80 KiB per-block budget (cin too large for k_idx)", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_conv_image<MS, NS, KV, KSKIP>), lds),
+                "k_conv_image: cannot reserve %zu B of LDS", lds);
+    const int mtn = ceil_div(p.Ho * p.Wo, MS * 32);
+    const unsigned grid = (unsigned)p.B * mtn * p.ntn;
+    hipLaunchKernelGGL((k_conv_image<MS, NS, KV, KSKIP>), dim3(grid), dim3(256), lds, st, p);
+    LDN_CHECK_LAUNCH("k_conv_image");
+    return LDN_OK;
+}
+
+template <int MS, int NS, int KV>
+static int launch_skip(const ImgArgs& p, hipStream_t st) {
+    if (p.cin <= 128) return launch_k<MS, NS, KV, true>(p, st);
+    return launch_k<MS, NS, KV, false>(p, st);
+}
+
+template <int KV>
+static int launch_shape(const ImgArgs& a, hipStream_t st) {
+    ImgArgs p = a;
+    const int nsubs = ceil_div(a.cout, 32);
+    // n-subtiles per N block.  Ragged N (n_idx): the first block takes up to 5 subtiles (160 columns), most
+    // images of a 256-wide layer need only that one.  Dense N: 4 subtiles (128 columns) when several blocks.
+    const int per = a.n_idx ? min(nsubs, 5) : min(nsubs, nsubs > 5 ? 4 : 5);
+    p.bn = per * 32;
+    p.ntn = ceil_div(a.cout, p.bn);
+    if (per <= 2) return launch_skip<7, 2, KV>(p, st);
+    if (per == 3) return launch_skip<6, 3, KV>(p, st);
+    if (per == 4) return launch_skip<5, 4, KV>(p, st);
+    return launch_skip<4, 5, KV>(p, st);
+}
+
+}  // namespace ldn
+
+using namespace ldn;
+
+#ifdef LDN_TRACE
+extern "C" int ldn_debug_set_trace(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#endif
+
+extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, int stride, int Ho, int Wo,
+                              const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt,
+                              int kgran, const int32_t* n_idx, const int32_t* n_cnt, const float* scale,
+                              const float* shift, int shift_classes, const float* post_sub, int relu,
+                              const float* residual, int ldr, float* out, int ldo, void* stream) {
+    LDN_REQUIRE(a && w && scale && shift && out, "ldn_conv_image: null pointer");
+    LDN_REQUIRE(ksize == 1 || ksize == 3, "ldn_conv_image: ksize must be 1 or 3 (got %d)", ksize);
+    LDN_REQUIRE(stride >= 1 && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "ldn_conv_image: bad geometry");
+    LDN_REQUIRE((Ho - 1) * stride < Hi && (Wo - 1) * stride < Wi, "ldn_conv_image: output grid exceeds input");
+    LDN_REQUIRE(Ho < 65536 && Wo < 65536, "ldn_conv_image: spatial size too large");
+    LDN_REQUIRE(cin > 0 && cout > 0 && cin % 4 == 0, "ldn_conv_image: cin must be a positive multiple of 4 (got %d)", cin);
+    LDN_REQUIRE(lda % 4 == 0, "ldn_conv_image: lda must be a multiple of 4");
+    LDN_REQUIRE((k_idx == nullptr) == (k_cnt == nullptr) && (n_idx == nullptr) == (n_cnt == nullptr),
+                "ldn_conv_image: index list and count must be given together");
+    LDN_REQUIRE(shift_classes == 1 || shift_classes == 16, "ldn_conv_image: shift_classes must be 1 or 16");
+    LDN_REQUIRE(!k_idx || kgran >= 1, "ldn_conv_image: kgran must be >= 1");
+    LDN_REQUIRE(ldo >= cout && ldo % 4 == 0 && cout % 4 == 0, "ldn_conv_image: cout and ldo must be multiples of 4, ldo >= cout");
+    LDN_REQUIRE(!(n_idx && residual), "ldn_conv_image: residual with an output-channel subset is not supported");
+    LDN_REQUIRE((uintptr_t)out % 16 == 0 && (!residual || ((uintptr_t)residual % 16 == 0 && ldr % 4 == 0)),
+                "ldn_conv_image: out/residual must be 16-byte aligned with strides that are multiples of 4");
+    LDN_REQUIRE(!residual || ldr >= cout, "ldn_conv_image: ldr < cout");
+    LDN_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "ldn_conv_image: a/w must be 16-byte aligned");
+    ImgArgs p{a, lda, B, Hi, Wi, ksize, stride, Ho, Wo, w, cin, cout, k_idx, k_cnt, n_idx, n_cnt,
+              scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, 0, 0};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int kv = k_idx ? (kgran % 4 == 0 ? 4 : (kgran % 2 == 0 ? 2 : 1)) : 4;
+    if (kv >= 4) return launch_shape<4>(p, st);
+    if (kv >= 2) return launch_shape<2>(p, st);
+    return launch_shape<1>(p, st);
+}

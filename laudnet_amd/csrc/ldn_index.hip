@@ -14,6 +14,16 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Raise a kernel's dynamic-LDS ceiling above the 64 KiB default when a launch needs it (gfx950: 160 KiB/CU).
+bool allow_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -422,12 +432,7 @@ extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Ho, 
     const size_t lds1 = (size_t)Ho * Wo;
     const size_t lds2 = (size_t)Ho * Wo * 5 + (size_t)g.Hi * g.Wi * 4;
     LDN_REQUIRE(lds2 <= 150 * 1024, "ldn_mask_to_index: feature map %dx%d too large for the LDS-resident index build", g.Hi, g.Wi);
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mask_index), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        configured = true;
-    }
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_mask_index), lds2), "k_mask_index: cannot reserve %zu B of LDS", lds2);
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_mask_count, dim3(B), dim3(256), lds1, st, patch_mask, g, work);
     LDN_CHECK_LAUNCH("k_mask_count");

@@ -107,6 +107,7 @@ def test_full_model_injected(name):
     with torch.no_grad():
         got = model(x, 1.0)
     torch.cuda.synchronize()
-    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=TOL, what=name + " logits")
+    # seeded-random 50/101-layer nets let logits grow to O(1e3): 1e-3 absolute plus fp32 round-off relative
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=TOL, rtol=1e-5, what=name + " logits")
     assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what=name + " stats")
     assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what=name + " flops")

@@ -109,8 +109,11 @@ int ldn_channel_masker(const float* x, int B, int HW, int C, const float* w1, co
  *   if residual: v += residual[b,p,j] ; if relu: v = max(v,0) ; if post_sub: v -= post_sub[o]
  *   out[b,p,j] = v for j < Nb (= n_cnt[b] or cout); columns Nb..roundup4(Nb)-1 are written 0.
  * A columns are "left-packed": column i of image b is channel k_idx[b,i].
- * kgran: every run of `kgran` consecutive k_idx entries is a run of consecutive channels
- * (the channel_dyn_granularity); must divide every k_cnt. */
+ * Weight layout: without k_idx, w is n-major  [cout][ksize*ksize][cin]  (rows gathered through n_idx);
+ *                with k_idx,    w is k-major  [ksize*ksize][cin][cout]  (rows gathered through k_idx, columns
+ *                through n_idx) -- every fetch then stays inside one row of the weight matrix.
+ * kgran: the channel granularity of the index lists (channel_dyn_granularity): every run of `kgran` consecutive
+ * list entries is a run of consecutive channels; must divide every count. */
 int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, int stride, int Ho, int Wo,
                    const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt, int kgran,
                    const int32_t* n_idx, const int32_t* n_cnt, const float* scale, const float* shift,

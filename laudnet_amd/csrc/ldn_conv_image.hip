@@ -5,24 +5,29 @@
 // k_idx[b][i]).  Without index lists it is a plain dense NHWC 1x1/3x3 conv (downsample branch, conv_linear
 // masker).  See include/ldn_hip.h:ldn_conv_image for the exact contract.
 //
-// Structure
-//   * Block = (image, MS*32 output pixels, up to NS*32 packed output columns), 256 threads = 4 wave64.
-//     Raggedness is handled at 32x32 MFMA-tile granularity in BOTH dimensions: the block's valid
-//     m-subtiles x n-subtiles (run-time counts) are dealt round-robin to the 4 waves, so a 68-pixel x
-//     159-channel remainder costs 3 x 5 = 15 tiles spread 4/4/4/3 instead of a padded 128 x 256 tile.
-//   * K is walked in chunks of 32 (per 3x3 tap).  Tiles live in LDS as unpadded 128-byte rows whose eight
-//     16-byte slots are XOR-swizzled with (row >> 1) & 7: conflict-free for the ds_read_b128 fragment reads
-//     and -- because the swizzle is applied to the SOURCE address -- compatible with global_load_lds, whose
-//     LDS destination is wave-uniform base + lane * 16.
-//   * A rows (NHWC pixels) and contiguous-K weight rows go HBM/L2 -> LDS directly (global_load_lds_dwordx4,
-//     no VGPR round trip, no ds_write); K-gathered weight rows (granularity 1/2) are staged through VGPRs.
-//   * Two LDS buffers, ONE barrier per chunk: the next chunk's loads are issued right after the barrier
-//     and land while the current chunk's MFMAs run; 2 workgroups per CU (<= 79 KiB each).
-//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles): lane (i, h) of a fragment read holds k = 8*g + 4*h + q,
-//     so one ds_read_b128 per operand feeds four MFMAs; the reads of group g+1 are issued before the MFMAs
-//     of group g.
-//   * Epilogue: folded-BN affine per lane-column, then a per-wave 32x32 transpose through LDS so residual
-//     loads and output stores are 16 B per lane along the channel axis.
+// What bounds this kernel (measured): a CU can pull only ~10 B/clk from L2/HBM (miss-queue x
+// latency), i.e. ~6 TB/s for the chip, while its four fp32 MFMA pipes retire 256 FLOP/clk.  The tile a CU
+// works on must therefore carry >= ~50 FLOP per byte brought into the CU, and memory-instruction issue
+// (which stalls when the miss queue is full) must never sit in front of an MFMA in program order.  Hence:
+//
+//   * ONE workgroup per CU owning up to 160 KiB of LDS: tile = MS*32 output pixels (a whole 14x14 image at
+//     stage 3) x up to NS*32 packed output columns, K walked in chunks of 32 per 3x3 tap.
+//   * WAVE SPECIALISATION: 512 threads = 8 wave64.  Waves 4-7 (one per SIMD) are PRODUCERS: they issue all
+//     global loads of chunk c+1 and may stall on the memory pipeline for as long as it takes.  Waves 0-3
+//     (one per SIMD) are CONSUMERS: they only read LDS fragments and issue v_mfma_f32_32x32x2_f32, so each
+//     SIMD's matrix pipe is fed by a wave that never waits on memory.  Two LDS buffers, one s_barrier per
+//     chunk shared by both roles.
+//   * Raggedness at 32x32 MFMA-tile granularity in BOTH dimensions: the block's valid m-subtiles x
+//     n-subtiles (run-time counts) are dealt round-robin to the 4 consumer waves.
+//   * LDS tiles are unpadded 128-byte rows whose eight 16-byte slots are XOR-swizzled with (row >> 1) & 7:
+//     conflict-free for the ds_read_b128 fragment reads and -- the swizzle being applied to the SOURCE
+//     address -- compatible with global_load_lds (LDS destination = wave-uniform base + lane * 16).
+//     A rows (NHWC pixels) and contiguous-K weight rows go L2 -> LDS directly (LDS-DMA, no VGPR round trip);
+//     K-gathered weight rows (granularity 1/2) are staged through the producers' VGPRs.
+//   * fragment reads: lane (i, h) holds k = 8*g + 4*h + q, so one ds_read_b128 per operand feeds four MFMAs;
+//     the reads of group g+1 are pinned in front of the MFMAs of group g (sched_group_barrier).
+//   * Epilogue (consumers): folded-BN affine per lane-column, then a per-wave 32x32 transpose through LDS so
+//     residual loads and output stores are 16 B per lane along the channel axis.
 #include "ldn_common.h"
 
 #ifndef LDN_ABLATE
@@ -43,32 +48,20 @@ struct ImgArgs {
     float* out; int ldo;
     int ntn;    // N blocks per image
     int bn;     // columns per N block (multiple of 32, <= NS*32)
+    int bm;     // pixels per M block (multiple of 32, <= MS*32; balanced over the image)
 };
 
 constexpr int BK = 32;   // K chunk = one 128-byte LDS row
 
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
-#ifdef LDN_TRACE   // tuning only: per-block {start, end, hw_id, xcc_id, ntiles, t_mainloop_end} timestamps
+#ifdef LDN_TRACE   // tuning only: per-block timestamps {t0, t1, hw_id, xcc_id, ntiles | barrier wait, mma | issue}
 __device__ unsigned long long* g_trace = nullptr;
-#define LDN_TRACE_BEGIN unsigned long long tr_t0 = __builtin_amdgcn_s_memtime(), tr_bar = 0, tr_mma = 0, tr_iss = 0, tr_a = 0, tr_b = 0;
 #define LDN_TRACE_T(x) x = __builtin_amdgcn_s_memtime();
 #define LDN_TRACE_ADD(acc, a, b) acc += (b) - (a);
-#define LDN_TRACE_MID unsigned long long tr_t1 = __builtin_amdgcn_s_memtime();
-#define LDN_TRACE_END                                                                                     \
-    if (tid == 0 && g_trace) {                                                                            \
-        unsigned long long* r = g_trace + (size_t)blockIdx.x * 6;                                         \
-        r[0] = tr_t0; r[1] = __builtin_amdgcn_s_memtime();                                                \
-        r[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   /* HW_REG_HW_ID */          \
-        r[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  /* HW_REG_XCC_ID */         \
-        r[4] = ntiles | (tr_bar << 32); r[5] = (tr_mma << 32) | (tr_iss & 0xffffffffull);              \
-    }
 #else
-#define LDN_TRACE_BEGIN
 #define LDN_TRACE_T(x)
 #define LDN_TRACE_ADD(acc, a, b)
-#define LDN_TRACE_MID
-#define LDN_TRACE_END
 #endif
 
 __device__ __forceinline__ void glds16(const float* src, float* lds_dst_wave_base) {
@@ -76,17 +69,35 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_dst_wave_bas
                                      (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
 
-// MS x NS = m-subtiles x n-subtiles of 32 per block, MS + NS <= 9 (two 36 KiB buffers, 2 blocks per CU).
-// KV   = how many consecutive packed K positions are guaranteed to be consecutive channels (1, 2 or 4);
-//        KV == 4 (and the no-k_idx case) stages weights with global_load_lds, KV < 4 through VGPRs.
+// workgroup barrier that also publishes this wave's LDS-DMA / ds_write traffic
+__device__ __forceinline__ void block_sync() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// MS x NS = m-subtiles x n-subtiles of 32 per block (two LDS buffers of (MS+NS)*4 KiB).
+// BMODE= weight layout / staging path:
+//        B_NK  : w[cout][taps][cin] ("n-major"), no K gather.  Tile rows = output channels (gathered through
+//                n_idx for free: a row is a pointer), 128 contiguous bytes of K per row            -> LDS-DMA
+//        B_KN4 : w[taps][cin][cout] ("k-major"), used whenever the INPUT channels are gathered (k_idx): tile
+//                rows = the chunk's 32 packed k positions (row gather, free), columns = output channels,
+//                contiguous or gathered in aligned runs of >= 4                                    -> LDS-DMA
+//        B_KN2 / B_KN1 : same layout, output channels gathered in aligned pairs / singly           -> VGPRs
+//        (k-major keeps every weight fetch inside one or a few 128-byte lines of a single row; the n-major
+//         layout with a K gather touched ~2.6x more lines than it used)
 // KSKIP= skip the empty 8-wide k groups of a partial chunk (pays when the per-tap K is short).
-template <int MS, int NS, int KV, bool KSKIP>
-__global__ __launch_bounds__(256, 2) void k_conv_image(const ImgArgs p) {
-    static_assert(MS >= 4 && MS + NS <= 9, "LDS budget");
-    constexpr int ACC = (MS * NS + 3) / 4;
+enum { B_NK = 0, B_KN4 = 1, B_KN2 = 2, B_KN1 = 3 };
+
+template <int MS, int NS, int BMODE, bool KSKIP, int MINW>
+__global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
+    static_assert(MS >= 4 && MS + NS <= 18, "LDS budget");
+    constexpr int ACC = (MS * NS + 3) / 4;                 // 32x32 accumulators per consumer wave
     constexpr int BM = MS * 32, BNX = NS * 32;
     constexpr int BUF = (BM + BNX) * BK;                   // floats per LDS buffer
-    constexpr bool BGLDS = KV == 4;
+    constexpr bool BGLDS = BMODE == B_NK || BMODE == B_KN4;
+    constexpr bool KN = BMODE != B_NK;
+    constexpr int BSL = BNX / 4;                           // 16-byte slots per k-major B row
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_sc = smem + 2 * BUF;                          // [BNX] BN scale of the column's channel
     float* s_ps = s_sc + BNX;                              // [BNX] post-ReLU constant of the column's channel
@@ -103,19 +114,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_image(const ImgArgs p) {
     const int t = bid / p.B;
     const int nt = t % p.ntn, mt = t / p.ntn;
     const int HWo = p.Ho * p.Wo;
-    const int m0 = mt * BM, n0 = nt * p.bn;
+    const int m0 = mt * p.bm, n0 = nt * p.bn;
     const int Kb = p.k_idx ? p.k_cnt[b] : p.cin;
     const int Nb = p.n_idx ? p.n_cnt[b] : p.cout;
     const int Nb4 = min(round_up(Nb, 4), p.cout);
     if (n0 >= Nb4 || m0 >= HWo) return;
     const int T = p.ksize * p.ksize;
     const int pad = p.ksize >> 1;
-    const int msub = ceil_div(min(HWo - m0, BM), 32);          // valid m-subtiles (1..MS)
+    const int msub = ceil_div(min(HWo - m0, p.bm), 32);        // valid m-subtiles (1..MS)
     const int nsub = ceil_div(min(Nb4 - n0, p.bn), 32);        // valid n-subtiles (1..NS)
     const int ntiles = msub * nsub;
-    LDN_TRACE_BEGIN
+#ifdef LDN_TRACE
+    unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime(), tr_t0 = __builtin_amdgcn_s_memtime(), tr_bar = 0, tr_mma = 0, tr_iss = 0, tr_a = 0, tr_b = 0;
+#endif
 
-    for (int i = tid; i < BM; i += 256) {
+    for (int i = tid; i < BM; i += 512) {
         const int m = m0 + i;
         int pix = -1, cls = 0;
         if (m < HWo) {
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_image(const ImgArgs p) {
         s_pix[i] = pix;
         s_cls[i] = cls;
     }
-    for (int i = tid; i < BNX; i += 256) {
+    for (int i = tid; i < BNX; i += 512) {
         const int j = n0 + i;
         const bool in_block = i < p.bn;
         const int chn = (in_block && j < Nb) ? (p.n_idx ? p.n_idx[(size_t)b * p.cout + j] : j)
@@ -140,104 +153,138 @@ __global__ __launch_bounds__(256, 2) void k_conv_image(const ImgArgs p) {
         s_ps[i] = (chn >= 0 && p.post_sub) ? p.post_sub[chn] : 0.f;
     }
     if (p.k_idx)
-        for (int i = tid; i < Kb; i += 256) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
+        for (int i = tid; i < Kb; i += 512) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
     __syncthreads();
 
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- staging coordinates: one wave instruction fills 8 rows x 8 slots (1 KiB); this thread moves physical
-    // slot (lane & 7) of row (wave + 4u) * 8 + (lane >> 3), i.e. logical slot qt = slot ^ ((row >> 1) & 7)
-    const int rg = lane >> 3, pslot = lane & 7;
-    const int qt = pslot ^ (((rg >> 1) + 4 * (wave & 1)) & 7);
-    const int kq = qt * 4;                                     // K offset of this thread's slot inside a chunk
-    long aoff[MS];   // element offset of this thread's A rows for the current tap, -1 = zero row
-    long boff[NS];   // element offset of w[ch_n][tap][0], -1 = zero row
-    f32x4 rb[NS];    // VGPR-staged weight slots (only when !BGLDS)
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const int Kb4 = p.k_idx ? round_up(Kb, 4) : p.cin;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cpt = ceil_div(Kb, BK);
+    const int nch = T * cpt;
 
-    auto set_tap = [&](int tap) {
-        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+    if (wave8 >= 4) {
+        // ================================================================ producers (waves 4..7)
+        const int wave = wave8 - 4;
+        // one wave instruction fills 8 rows x 8 slots (1 KiB); this thread moves physical slot (lane & 7) of row
+        // (wave + 4u) * 8 + (lane >> 3), i.e. logical slot qt = slot ^ ((row >> 1) & 7)
+        const int rg = lane >> 3, pslot = lane & 7;
+        const int qt = pslot ^ (((rg >> 1) + 4 * (wave & 1)) & 7);
+        const int kq = qt * 4;                                 // K offset of this thread's slot inside a chunk
+        long aoff[MS];   // element offset of this thread's A rows for the current tap, -1 = zero row
+        long boff[NS];   // B_NK: element offset of w[ch_n][tap][0], -1 = zero row
+        int cur_tap = 0;
+        f32x4 rb[NS];    // VGPR-staged weight slots (only when !BGLDS)
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const int Kb4 = p.k_idx ? round_up(Kb, 4) : p.cin;
+
+        auto set_tap = [&](int tap) {
+            const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
 #pragma unroll
-        for (int u = 0; u < MS; ++u) {
-            long off = -1;
-            if (u < msub) {
-                const int pix = s_pix[(wave + 4 * u) * 8 + rg];
-                if (pix >= 0) {
-                    const int iy = (pix >> 16) * p.stride + ky - pad, ix = (pix & 0xffff) * p.stride + kx - pad;
-                    if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-                        off = ((long)(b * p.Hi + iy) * p.Wi + ix) * p.lda;
-                }
-            }
-            aoff[u] = off;
-        }
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            long off = -1;
-            if (u < nsub) {
-                const int chn = s_nch[(wave + 4 * u) * 8 + rg];
-                if (chn >= 0) off = ((long)chn * T + tap) * p.cin;
-            }
-            boff[u] = off;
-        }
-    };
-    // issue the loads of chunk (current tap, c0) into LDS buffer `buf` (A always by LDS-DMA; B by LDS-DMA or VGPRs)
-    auto issue = [&](int c0, int buf) {
-        const int c = c0 + kq;
-        float* base = smem + buf * BUF;
-#pragma unroll
-        for (int u = 0; u < MS; ++u)
-            if (u < msub)
-                glds16((aoff[u] >= 0 && c < Kb4) ? p.a + aoff[u] + c : g_zero16, base + (wave + 4 * u) * 8 * BK);
-        // packed K position -> channel (same for every B row of this thread)
-        int k0 = c, k1 = c + 1, k2 = c + 2, k3 = c + 3;
-        if (p.k_idx && c < Kb) {
-            k0 = s_kidx[c];
-            if (KV == 2) k2 = c + 2 < Kb ? s_kidx[c + 2] : 0;
-            if (KV == 1) {
-                k1 = c + 1 < Kb ? s_kidx[c + 1] : 0;
-                k2 = c + 2 < Kb ? s_kidx[c + 2] : 0;
-                k3 = c + 3 < Kb ? s_kidx[c + 3] : 0;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            if (u >= nsub) continue;
-            const bool ok = boff[u] >= 0 && c < Kb;
-            if (BGLDS) {
-                glds16(ok ? p.w + boff[u] + k0 : g_zero16, base + (BM + (wave + 4 * u) * 8) * BK);
-            } else {
-                f32x4 v = zero4;
-                if (ok) {
-                    const float* wr = p.w + boff[u];
-                    if (!p.k_idx) {
-                        v = *reinterpret_cast<const f32x4*>(wr + k0);
-                    } else if (KV == 2) {
-                        const float2 lo = *reinterpret_cast<const float2*>(wr + k0);
-                        v[0] = lo.x; v[1] = lo.y;
-                        if (c + 2 < Kb) {
-                            const float2 hi = *reinterpret_cast<const float2*>(wr + k2);
-                            v[2] = hi.x; v[3] = hi.y;
-                        }
-                    } else {
-                        v[0] = wr[k0];
-                        if (c + 1 < Kb) v[1] = wr[k1];
-                        if (c + 2 < Kb) v[2] = wr[k2];
-                        if (c + 3 < Kb) v[3] = wr[k3];
+            for (int u = 0; u < MS; ++u) {
+                long off = -1;
+                if (u < msub) {
+                    const int pix = s_pix[(wave + 4 * u) * 8 + rg];
+                    if (pix >= 0) {
+                        const int iy = (pix >> 16) * p.stride + ky - pad, ix = (pix & 0xffff) * p.stride + kx - pad;
+                        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+                            off = ((long)(b * p.Hi + iy) * p.Wi + ix) * p.lda;
                     }
                 }
-                rb[u] = v;
+                aoff[u] = off;
             }
-        }
-    };
-    auto bstore = [&](int buf) {
+            if (!KN) {
 #pragma unroll
-        for (int u = 0; u < NS; ++u)
-            if (u < nsub)
-                *reinterpret_cast<f32x4*>(smem + buf * BUF + (BM + (wave + 4 * u) * 8 + rg) * BK + pslot * 4) = rb[u];
-    };
+                for (int u = 0; u < NS; ++u) {
+                    long off = -1;
+                    if (u < nsub) {
+                        const int chn = s_nch[(wave + 4 * u) * 8 + rg];
+                        if (chn >= 0) off = ((long)chn * T + tap) * p.cin;
+                    }
+                    boff[u] = off;
+                }
+            }
+            cur_tap = tap;
+        };
+        // issue the loads of chunk (current tap, c0) into LDS buffer `buf`
+        auto issue = [&](int c0, int buf) {
+            const int c = c0 + kq;
+            float* base = smem + buf * BUF;
+#pragma unroll
+            for (int u = 0; u < MS; ++u)
+                if (u < msub)
+                    glds16((aoff[u] >= 0 && c < Kb4) ? p.a + aoff[u] + c : g_zero16, base + (wave + 4 * u) * 8 * BK);
+            if (!KN) {
+                // n-major: row = output channel (wave+4u)*8+rg, this thread's slot = K offset kq of the chunk
+#pragma unroll
+                for (int u = 0; u < NS; ++u)
+                    if (u < nsub)
+                        glds16((boff[u] >= 0 && c < p.cin) ? p.w + boff[u] + c : g_zero16,
+                               base + (BM + (wave + 4 * u) * 8) * BK);
+            } else {
+                // k-major: the B tile is [32 k rows][BNX columns]; wave instruction (wave + 4u) covers 64 consecutive
+                // 16-byte slots; slot sid -> (k row sid / BSL, column group sid % BSL)
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    const int sid = (wave + 4 * u) * 64 + lane;
+                    const int r = sid / BSL, j = (sid - r * BSL) * 4;     // k row, first packed column
+                    const int kpos = c0 + r;
+                    const bool kok = kpos < Kb && j < nsub * 32;
+                    const float* wr = g_zero16;
+                    if (kok) wr = p.w + ((long)cur_tap * p.cin + (p.k_idx ? s_kidx[kpos] : kpos)) * p.cout;
+                    if (BMODE == B_KN4) {
+                        const int chn = kok ? s_nch[j] : -1;
+                        glds16(chn >= 0 ? wr + chn : g_zero16, base + BM * BK + (wave + 4 * u) * 256);
+                    } else {
+                        f32x4 v = zero4;
+                        if (kok) {
+                            if (BMODE == B_KN2) {
+                                const int c0n = s_nch[j], c2n = s_nch[j + 2];
+                                if (c0n >= 0) { const float2 lo = *reinterpret_cast<const float2*>(wr + c0n); v[0] = lo.x; v[1] = lo.y; }
+                                if (c2n >= 0) { const float2 hi = *reinterpret_cast<const float2*>(wr + c2n); v[2] = hi.x; v[3] = hi.y; }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int cn = s_nch[j + e];
+                                    if (cn >= 0) v[e] = wr[cn];
+                                }
+                            }
+                        }
+                        rb[u] = v;
+                    }
+                }
+            }
+        };
+        auto bstore = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u)
+                *reinterpret_cast<f32x4*>(smem + buf * BUF + BM * BK + ((wave + 4 * u) * 64 + lane) * 4) = rb[u];
+        };
 
-    // ---- MFMA tile assignment
+        if (nch > 0) {
+            int tap = 0, c0 = 0;
+            auto advance = [&]() {
+                c0 += BK;
+                if (c0 >= Kb) { c0 = 0; ++tap; if (tap < T) set_tap(tap); }
+            };
+            set_tap(0);
+            issue(0, 0);
+            advance();
+            for (int ch = 0; ch < nch; ++ch) {
+                const int buf = ch & 1;
+                if (!BGLDS) bstore(buf);
+                block_sync();                 // barrier(ch): chunk ch is in LDS; consumers are done with chunk ch-1
+#if !(LDN_ABLATE & 2)
+                if (ch + 1 < nch) { issue(c0, buf ^ 1); advance(); }
+#else
+                if (ch + 1 < nch) { advance(); }
+#endif
+            }
+            block_sync();                     // matches the consumers' final barrier
+        }
+        return;
+    }
+
+    // ==================================================================== consumers (waves 0..3)
+    const int wave = wave8;
     const int l31 = lane & 31, h = lane >> 5;
     const int swl = (l31 >> 1) & 7;
     int so[BK / 8];                            // swizzled float offset of k group g for this lane
@@ -252,41 +299,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_image(const ImgArgs p) {
         const int tt = min(wave + 4 * s, ntiles - 1);   // tile tt -> (m-subtile tt % msub, n-subtile tt / msub)
         const int nj = tt / msub, mi = tt - nj * msub;
         a_off[s] = (mi * 32 + l31) * BK;
-        b_off[s] = (BM + nj * 32 + l31) * BK;
+        b_off[s] = KN ? nj * 32 + l31 : (BM + nj * 32 + l31) * BK;
     }
     const int my_tiles = ntiles > wave ? (ntiles - wave + 3) / 4 : 0;   // tiles wave, wave+4, ... < ntiles
 
-    const int cpt = ceil_div(Kb, BK);
-    const int nch = T * cpt;
     if (nch > 0) {
-        int tap = 0, c0 = 0;
-        auto advance = [&]() {
-            c0 += BK;
-            if (c0 >= Kb) { c0 = 0; ++tap; if (tap < T) set_tap(tap); }
-        };
-        set_tap(0);
-        issue(0, 0);
-        int kvalid = min(Kb, BK);              // valid K of the chunk in flight
-        advance();
+        int cin_chunk = 0;                     // chunk index within the tap (for KSKIP)
         for (int ch = 0; ch < nch; ++ch) {
             const int buf = ch & 1;
-            if (!BGLDS) bstore(buf);
-            const int kgroups = ceil_div(kvalid, 8);   // 8-wide k groups that hold data in this chunk
+            const int kgroups = ceil_div(min(Kb - cin_chunk * BK, BK), 8);
+            if (++cin_chunk == cpt) cin_chunk = 0;
             LDN_TRACE_T(tr_a)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of chunk ch has landed
-            __syncthreads();
+            block_sync();                      // barrier(ch)
             LDN_TRACE_T(tr_b)
             LDN_TRACE_ADD(tr_bar, tr_a, tr_b)
-#if !(LDN_ABLATE & 2)
-            if (ch + 1 < nch) { kvalid = min(Kb - c0, BK); issue(c0, buf ^ 1); advance(); }
-#else
-            if (ch + 1 < nch) { kvalid = min(Kb - c0, BK); advance(); }
-#endif
-            LDN_TRACE_T(tr_a)
-            LDN_TRACE_ADD(tr_iss, tr_b, tr_a)
             const float* tb = smem + buf * BUF;
+            auto read_b = [&](int s, int g) -> f32x4 {
+                if (!KN) return *reinterpret_cast<const f32x4*>(tb + b_off[s] + so[g]);
+                f32x4 v;   // k-major tile: 4 consecutive k rows, this lane's column
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = tb[BM * BK + (g * 8 + h * 4 + q) * BNX + b_off[s]];
+                return v;
+            };
             f32x4 af = *reinterpret_cast<const f32x4*>(tb + a_off[0] + so[0]);
-            f32x4 bf = *reinterpret_cast<const f32x4*>(tb + b_off[0] + so[0]);
+            f32x4 bf = read_b(0, 0);
 #pragma unroll
             for (int s = 0; s < ACC; ++s) {
                 if (s < my_tiles) {
@@ -295,10 +331,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_image(const ImgArgs p) {
                         f32x4 an = af, bn = bf;
                         if (g + 1 < BK / 8) {
                             an = *reinterpret_cast<const f32x4*>(tb + a_off[s] + so[g + 1]);
-                            bn = *reinterpret_cast<const f32x4*>(tb + b_off[s] + so[g + 1]);
+                            bn = read_b(s, g + 1);
                         } else if (s + 1 < ACC) {   // offsets of unused slots are clamped to a valid tile
                             an = *reinterpret_cast<const f32x4*>(tb + a_off[s + 1] + so[0]);
-                            bn = *reinterpret_cast<const f32x4*>(tb + b_off[s + 1] + so[0]);
+                            bn = read_b(s + 1, 0);
                         }
                         if (!KSKIP || g < kgroups) {
 #if LDN_ABLATE & 1
@@ -309,21 +345,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_image(const ImgArgs p) {
                                 acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bf[q], acc[s], 0, 0, 0);
 #endif
                         }
-                        // pin the schedule: the two fragment reads of the NEXT group first, then this group's 4 MFMAs
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        // pin the schedule: the fragment reads of the NEXT group first, then this group's 4 MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x100, KN ? 5 : 2, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                         af = an;
                         bf = bn;
                     }
                 }
             }
-            LDN_TRACE_T(tr_b)
-            LDN_TRACE_ADD(tr_mma, tr_a, tr_b)
+            LDN_TRACE_T(tr_a)
+            LDN_TRACE_ADD(tr_mma, tr_b, tr_a)
         }
-        __syncthreads();   // every wave is done with both buffers before buffer 0 becomes the epilogue scratch
+        block_sync();   // every consumer is done with both buffers before buffer 0 becomes the epilogue scratch
     }
 
-    LDN_TRACE_MID
     // ---- epilogue
     float* scratch = smem + wave * (32 * 32);
     const int trow = lane >> 3, tc4 = (lane & 7) * 4;
@@ -364,43 +399,56 @@ __global__ __launch_bounds__(256, 2) void k_conv_image(const ImgArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    LDN_TRACE_END
+#ifdef LDN_TRACE
+    if (tid == 0 && g_trace) {
+        unsigned long long* r = g_trace + (size_t)blockIdx.x * 6;
+        r[0] = tr_t0; r[1] = __builtin_amdgcn_s_memtime();
+        r[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        r[3] = __builtin_amdgcn_s_memrealtime() - tr_r0;                        // 100 MHz ticks
+        r[4] = ntiles | (tr_bar << 32); r[5] = (tr_mma << 32) | (tr_iss & 0xffffffffull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- host
-template <int MS, int NS, int KV, bool KSKIP>
+template <int MS, int NS, int BMODE, bool KSKIP>
 static int launch_k(const ImgArgs& p, hipStream_t st) {
+    // blocks of <= 64 KiB LDS run two per CU (memory-bound early stages need the extra waves in flight)
+    constexpr int MINW = (MS + NS) <= 8 ? 4 : 2;
     const size_t lds = (size_t)2 * (MS + NS) * 32 * BK * sizeof(float) + (size_t)(2 * NS * 32) * sizeof(float) +
                        (size_t)(2 * MS * 32 + NS * 32 + (p.k_idx ? p.cin : 0)) * sizeof(int);
-    LDN_REQUIRE(lds <= 80 * 1024, "k_conv_image: %zu B of LDS exceed the 80 KiB per-block budget (cin too large for k_idx)", lds);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_conv_image<MS, NS, KV, KSKIP>), lds),
+    LDN_REQUIRE(lds <= 160 * 1024, "k_conv_image: %zu B of LDS exceed 160 KiB (cin too large for k_idx)", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_conv_image<MS, NS, BMODE, KSKIP, MINW>), lds),
                 "k_conv_image: cannot reserve %zu B of LDS", lds);
-    const int mtn = ceil_div(p.Ho * p.Wo, MS * 32);
+    ImgArgs q = p;
+    const int msubs = ceil_div(p.Ho * p.Wo, 32);
+    const int mtn = ceil_div(msubs, MS);              // M blocks per image, then balance their sizes
+    q.bm = ceil_div(msubs, mtn) * 32;
     const unsigned grid = (unsigned)p.B * mtn * p.ntn;
-    hipLaunchKernelGGL((k_conv_image<MS, NS, KV, KSKIP>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((k_conv_image<MS, NS, BMODE, KSKIP, MINW>), dim3(grid), dim3(512), lds, st, q);
     LDN_CHECK_LAUNCH("k_conv_image");
     return LDN_OK;
 }
 
-template <int MS, int NS, int KV>
-static int launch_skip(const ImgArgs& p, hipStream_t st) {
-    if (p.cin <= 128) return launch_k<MS, NS, KV, true>(p, st);
-    return launch_k<MS, NS, KV, false>(p, st);
-}
-
-template <int KV>
+template <int BMODE>
 static int launch_shape(const ImgArgs& a, hipStream_t st) {
     ImgArgs p = a;
     const int nsubs = ceil_div(a.cout, 32);
-    // n-subtiles per N block.  Ragged N (n_idx): the first block takes up to 5 subtiles (160 columns), most
-    // images of a 256-wide layer need only that one.  Dense N: 4 subtiles (128 columns) when several blocks.
-    const int per = a.n_idx ? min(nsubs, 5) : min(nsubs, nsubs > 5 ? 4 : 5);
+    const int hw = a.Ho * a.Wo;
+    // tile shape: as many output pixels as the LDS budget allows for the layer's width, so that every byte pulled
+    // into the CU is reused by as many MFMAs as possible (whole 14x14 / 7x7 images at stages 3 / 4)
+    int per;                                   // n-subtiles per N block
+    if (nsubs <= 4) per = nsubs;               // <= 128 columns: memory-bound layers, two 64 KiB blocks per CU
+    else if (hw <= 128) per = min(nsubs, 10);  // 7x7 images: wide N blocks (weights dominate the traffic)
+    else if (hw <= 256 && a.n_idx) per = min(nsubs, 6);   // 14x14 images: whole image x <= 192 columns per block
+    else per = 4;
     p.bn = per * 32;
     p.ntn = ceil_div(a.cout, p.bn);
-    if (per <= 2) return launch_skip<7, 2, KV>(p, st);
-    if (per == 3) return launch_skip<6, 3, KV>(p, st);
-    if (per == 4) return launch_skip<5, 4, KV>(p, st);
-    return launch_skip<4, 5, KV>(p, st);
+    // KSKIP (skip empty k groups of a partial chunk) only pays for the narrow layers, which use the small shapes
+    if (per <= 2) return launch_k<6, 2, BMODE, true>(p, st);
+    if (per <= 4) return launch_k<4, 4, BMODE, true>(p, st);
+    if (per <= 6) return launch_k<8, 6, BMODE, false>(p, st);
+    return launch_k<4, 10, BMODE, false>(p, st);
 }
 
 }  // namespace ldn
@@ -437,10 +485,11 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
     LDN_REQUIRE(!residual || ldr >= cout, "ldn_conv_image: ldr < cout");
     LDN_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "ldn_conv_image: a/w must be 16-byte aligned");
     ImgArgs p{a, lda, B, Hi, Wi, ksize, stride, Ho, Wo, w, cin, cout, k_idx, k_cnt, n_idx, n_cnt,
-              scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, 0, 0};
+              scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, 0, 0, 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int kv = k_idx ? (kgran % 4 == 0 ? 4 : (kgran % 2 == 0 ? 2 : 1)) : 4;
-    if (kv >= 4) return launch_shape<4>(p, st);
-    if (kv >= 2) return launch_shape<2>(p, st);
-    return launch_shape<1>(p, st);
+    if (!k_idx) return launch_shape<B_NK>(p, st);                    // w is [cout][taps][cin]
+    const int g = n_idx ? kgran : 4;                                 // w is [taps][cin][cout]
+    if (g % 4 == 0) return launch_shape<B_KN4>(p, st);
+    if (g % 2 == 0) return launch_shape<B_KN2>(p, st);
+    return launch_shape<B_KN1>(p, st);
 }

@@ -279,8 +279,15 @@ class Bottleneck(_PrepCache):
             W = self.width
             p = {}
             p["w1"] = self.conv1.weight.detach().reshape(W, 1, -1).float().contiguous()
-            p["w2"] = self.conv2.weight.detach().permute(0, 2, 3, 1).reshape(W, 9, W).float().contiguous()
-            p["w3"] = self.conv3.weight.detach().reshape(-1, 1, W).float().contiguous()
+            w2 = self.conv2.weight.detach().float()
+            w3 = self.conv3.weight.detach().float().reshape(-1, W)
+            if self.dyn_mode in ("channel", "both"):
+                # k-major [taps][cin][cout]: the per-image input-channel gather becomes a ROW gather
+                p["w2"] = w2.permute(2, 3, 1, 0).reshape(9, W, W).contiguous()
+                p["w3"] = w3.t().reshape(1, W, -1).contiguous()
+            else:
+                p["w2"] = w2.permute(0, 2, 3, 1).reshape(W, 9, W).contiguous()
+                p["w3"] = w3.reshape(-1, 1, W).contiguous()
             p["s1"], p["t1"] = _fold_bn(self.bn1)
             p["s2"], p["t2"] = _fold_bn(self.bn2)
             p["s3"], p["t3"] = _fold_bn(self.bn3)
@@ -323,7 +330,7 @@ class Bottleneck(_PrepCache):
         h2 = torch.empty(B, Ho, Wo, W, device=dev, dtype=torch.float32)
         ops.conv_image(h1, p["w2"], p["s2"], p["t2_tab"], h2, ksize=3, stride=self.stride, k_idx=idx, k_cnt=cnt,
                        kgran=gran, n_idx=idx, n_cnt=cnt, post_sub=p["c2"], relu=1)
-        cout = p["w3"].shape[0]
+        cout = p["w3"].shape[2]
         if self.downsample is not None:
             identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
             ops.conv_image(xn, p["wd"], p["sd"], p["td"], identity, stride=p["ds_stride"], relu=0)

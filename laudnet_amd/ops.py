@@ -172,12 +172,16 @@ def channel_masker(x_nhwc, w1, b1, w2, b2, groups, gran, mask_in=None, want_logi
 def conv_image(a_nhwc, w, scale, shift, out_nhwc, *, ksize=1, stride=1, k_idx=None, k_cnt=None, kgran=1, n_idx=None,
                n_cnt=None, post_sub=None, relu=1, residual=None):
     """Per-image channel-subset convolution (see ldn_conv_image).
-    a_nhwc [B,Hi,Wi,lda]; w [cout,ksize*ksize,cin]; shift [cout] or [16,cout]; out_nhwc [B,Ho,Wo,ldo]."""
+    a_nhwc [B,Hi,Wi,lda]; w [cout,ksize*ksize,cin] without k_idx, [ksize*ksize,cin,cout] (k-major) with k_idx;
+    shift [cout] or [16,cout]; out_nhwc [B,Ho,Wo,ldo]."""
     L.require_device(a_nhwc, w, out_nhwc)
     lib = L.load()
     B, Hi, Wi, lda = a_nhwc.shape
     _, Ho, Wo, ldo = out_nhwc.shape
-    cout, t, cin = w.shape
+    if k_idx is None:
+        cout, t, cin = w.shape
+    else:
+        t, cin, cout = w.shape
     if t != ksize * ksize:
         raise L.LdnError("conv_image: weight taps do not match ksize")
     classes = 1 if shift.dim() == 1 else shift.shape[0]

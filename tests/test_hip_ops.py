@@ -247,7 +247,7 @@ def test_conv_image_channel_subsets(ops, B, H, cin, W, gran, stride):
     g2 = torch.full((B, Ho, Ho, W), float("nan"), device=DEV)
     ops.conv_image(g1, p["w2"], p["s2"], p["t2_tab"], g2, ksize=3, stride=stride, k_idx=idx, k_cnt=cnt, kgran=gran,
                    n_idx=idx, n_cnt=cnt, post_sub=p["c2"], relu=1)
-    g3 = torch.empty(B, Ho, Ho, 4 * W, device=DEV)
+    g3 = torch.empty(B, Ho, Ho, 4 * W, device=DEV)  # p['w2'] / p['w3'] are k-major here (channel mode)
     ops.conv_image(g2, p["w3"], p["s3"], p["t3c"], g3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=0)
     # unpack the left-packed h1/h2 and compare on the active channels
     cidx, ccnt = idx.cpu().long(), cnt.cpu()

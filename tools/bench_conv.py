@@ -40,8 +40,8 @@ def main():
         h2 = torch.randn(B, H, H, W, device=dev)
         out = torch.empty(B, H, H, Cin, device=dev)
         w1 = torch.randn(W, 1, Cin, device=dev) * 0.05
-        w2 = torch.randn(W, 9, W, device=dev) * 0.05
-        w3 = torch.randn(Cin, 1, W, device=dev) * 0.05
+        w2 = torch.randn(9, W, W, device=dev) * 0.05      # k-major [taps][cin][cout]
+        w3 = torch.randn(1, W, Cin, device=dev) * 0.05    # k-major
         sW, tW = torch.rand(W, device=dev) + 0.5, torch.randn(W, device=dev) * 0.1
         sC, tC = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.1
         tab = torch.randn(16, W, device=dev) * 0.1

@@ -26,8 +26,8 @@ h1 = torch.randn(B, H, H, W, device=dev)
 h2 = torch.randn(B, H, H, W, device=dev)
 out = torch.empty(B, H, H, Cin, device=dev)
 w1 = torch.randn(W, 1, Cin, device=dev) * 0.05
-w2 = torch.randn(W, 9, W, device=dev) * 0.05
-w3 = torch.randn(Cin, 1, W, device=dev) * 0.05
+w2 = torch.randn(9, W, W, device=dev) * 0.05      # k-major [taps][cin][cout]
+w3 = torch.randn(1, W, Cin, device=dev) * 0.05    # k-major
 sW, tW = torch.rand(W, device=dev) + 0.5, torch.randn(W, device=dev) * 0.1
 sC, tC = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.1
 tab = torch.randn(16, W, device=dev) * 0.1
@@ -65,7 +65,7 @@ for nt_ in sorted(set(ntiles.tolist())):
 cu = ((xcc & 0xf) << 16) | (hw & 0xff00) | ((hw >> 13) & 7) << 4 | ((hw >> 12) & 1)
 cu_key = (xcc & 0xf) * 10000 + ((hw >> 13) & 7) * 1000 + ((hw >> 12) & 1) * 100 + ((hw >> 8) & 0xf)
 uk = np.unique(cu_key)
-print("distinct CUs seen:", len(uk))
+print("distinct CUs seen:", len(uk)); big = ntiles == ntiles.max(); print("shader clock GHz (memtime/realtime@100MHz) on largest blocks:", (dur[big] / np.maximum(xcc[big],1) * 0.1).mean())
 # concurrency per CU: sweep
 conc = []
 busy = []

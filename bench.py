@@ -108,7 +108,10 @@ class KernelTimer:
         tot_ms, tot_flops, n = 0.0, 0.0, 0
         for e0, e1, kc, nc, oshape, wshape in self.records:
             B, Ho, Wo, _ = oshape
-            cout, taps, cin = wshape
+            if kc is not None:      # k-major weights [taps][cin][cout] whenever the input channels are gathered
+                taps, cin, cout = wshape
+            else:
+                cout, taps, cin = wshape
             kb = kc.double() if kc is not None else torch.full((B,), float(cin), dtype=torch.float64)
             nb = nc.double() if nc is not None else torch.full((B,), float(cout), dtype=torch.float64)
             tot_flops += float((2.0 * Ho * Wo * taps * kb.cpu() * nb.cpu()).sum())
@@ -145,6 +148,9 @@ def main():
     kw = dict(wl["kw"], num_classes=1000, input_size=224)
     model = laudnet_amd.uni_resnet101(**kw).eval()
     sd = fill_state_dict(model.state_dict(), 1)
+    for k in sd:   # damp the residual branches (as zero_init_residual would) so 33 seeded-random blocks keep O(1) activations
+        if k.endswith("bn3.weight"):
+            sd[k] = sd[k] * 0.3
     model.load_state_dict(sd)
     model = model.to(dev)
     torch.backends.cudnn.benchmark = True
@@ -209,6 +215,11 @@ def main():
         if not args.no_dense:
             try:
                 refg = ref.to(dev).to(memory_format=torch.channels_last)
+                # parity on identical inputs AND masks: replay the masks the HIP maskers produced in the last step
+                for hb, rb in zip(blocks_of(model), (b for _, b in refg.blocks())):
+                    cm, sm = getattr(hb, "last_channel_mask", None), getattr(hb, "last_spatial_mask", None)
+                    rb.forced_channel_mask = None if cm is None else cm.clone()
+                    rb.forced_spatial_mask = None if sm is None else sm.clone()
                 with torch.no_grad():
                     for _ in range(2):
                         want = refg(x, 1.0)
@@ -222,22 +233,24 @@ def main():
                 err = (out[0] - want[0]).abs().max().item()
                 result["dense_emulation_gpu"] = {"value": args.batch / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt,
                                                  "kind": "oracle dense emulation, PyTorch-ROCm fp32 channels_last, same GPU",
-                                                 "max_abs_logit_diff_vs_hip": err,
+                                                 "max_abs_logit_diff_vs_hip_same_masks": err,
                                                  "logit_scale": want[0].abs().max().item()}
                 result["realised_speedup_vs_dense_emulation"] = result["value"] / (args.batch / dt)
                 ref = ref.cpu()
             except Exception as e:  # the baseline is informative only
                 result["dense_emulation_gpu"] = {"error": repr(e)[:200]}
         if not args.no_cpu:
-            cores = os.cpu_count() or 1
+            cores = min(os.cpu_count() or 1, 32)   # torch CPU convs stop scaling (and thrash) far below 256 threads
             torch.set_num_threads(cores)
+            for rb in (b for _, b in ref.blocks()):
+                rb.forced_channel_mask = rb.forced_spatial_mask = None
             xc = x[: args.cpu_batch].cpu().contiguous()
             ref = ref.cpu()
             with torch.no_grad():
                 ref(xc[:2], 1.0)
                 t0 = time.perf_counter()
                 reps = 0
-                while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+                while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 8):
                     ref(xc, 1.0)
                     reps += 1
                 dt = (time.perf_counter() - t0) / reps

@@ -340,6 +340,7 @@ class Bottleneck(_PrepCache):
             out = xn if self.inplace_residual else torch.empty_like(xn)
         ops.conv_image(h2, p["w3"], p["s3"], p["t3c"], out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1,
                        residual=identity)
+        self.last_channel_mask = mask       # kept for parity tooling (bench/tests feed it to the oracle)
         return ops.from_nhwc(out), mask
 
     def _run_spatial(self, x, p):
@@ -375,6 +376,7 @@ class Bottleneck(_PrepCache):
             resid, out2d = x2d, torch.relu(x2d)
         ops.conv_rows(h2, p["w3"], p["s3"], p["t3"], out2d, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
                       out_rows=ix.idx3, residual2d=resid)
+        self.last_spatial_mask = patch
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), patch, ix
 
     def _ds_rows(self, B, Hi, Wi, Ho, Wo, s, dev):
@@ -387,39 +389,51 @@ class Bottleneck(_PrepCache):
             cache[key] = ((b * Hi + y) * Wi + xx).reshape(-1).to(torch.int32).contiguous()
         return cache[key]
 
-    def forward(self, x, temperature=1.0):
-        x, s3_list, s2_list, s1_list, cs_list, perc_list, flops = x
+    def run_dynamic(self, x):
+        """Execute the block on the HIP path.  Returns (out, stats[4] = {s3, s2, s1, channel sparsity} as a device
+        tensor).  The FLOPs bookkeeping is separate (flops_terms) so a whole network can do it once, vectorised."""
         _eval_only(self, x)
         if self.dyn_mode == "both":
             raise LdnError("HIP path: dyn_mode='both' (channel AND spatial in one block) is not built yet "
                            "(SURVEY 8f-2); use 'channel', 'spatial' or 'layer'")
         p = self._prep if self._prep is not None else self._prepare(x.device)
-        one = lambda: torch.tensor(1.0, device=x.device)
         if self.dyn_mode == "channel":
             out, cmask = self._run_channel(x, p)
-            cs = cmask.mean()
-            s1, s2, s3 = one(), one(), one()
-            c_flops, s_flops = self.masker_channel.flops_for(x), 0
+            stats = torch.ones(4, device=x.device)
+            stats[3] = cmask.mean()
         else:
             out, patch, ix = self._run_spatial(x, p)
-            s3, s2, s1 = ix.stats[0], ix.stats[1], ix.stats[2]
-            cs = one()
-            c_flops, s_flops = 0, self.masker_spatial.flops_for(x)
+            stats = torch.cat((ix.stats, torch.ones(1, device=x.device)))
+        return out, stats
 
-        # FLOPs bookkeeping, laud_resnet.py:112-147 (conv1 runs at the input resolution)
-        px_in = x.shape[2] * x.shape[3]
-        px_out = out.shape[2] * out.shape[3]
-        sparse = c_flops + s_flops
-        dense = c_flops + s_flops
-        dense += self.conv1_flops_per_pixel * px_in
-        sparse = sparse + self.conv1_flops_per_pixel * px_in * cs * s1
-        dense += self.conv2_flops_per_pixel * px_out
-        sparse = sparse + self.conv2_flops_per_pixel * px_out * cs ** 2 * s2
-        dense += self.conv3_flops_per_pixel * px_out
-        sparse = sparse + self.conv3_flops_per_pixel * px_out * cs * s3
-        if self.downsample is not None:
-            dense += self.downsample_flops * px_out
-            sparse = sparse + self.downsample_flops * px_out
+    def flops_terms(self, x_shape):
+        """Shape-only constants of the bookkeeping of laud_resnet.py:112-147:
+        (masker flops, conv1, conv2, conv3, downsample) with conv1 counted at the INPUT resolution."""
+        _, _, hi, wi = x_shape
+        px_in = hi * wi
+        px_out = ((hi - 1) // self.stride + 1) * ((wi - 1) // self.stride + 1)
+        probe = torch.empty(x_shape, device="meta")
+        masker = 0
+        if self.masker_channel is not None:
+            masker += self.masker_channel.flops_for(probe)
+        if self.masker_spatial is not None:
+            masker += self.masker_spatial.flops_for(probe)
+        ds = self.downsample_flops * px_out if self.downsample is not None else 0
+        return (masker, self.conv1_flops_per_pixel * px_in, self.conv2_flops_per_pixel * px_out,
+                self.conv3_flops_per_pixel * px_out, ds)
+
+    def forward(self, x, temperature=1.0):
+        x, s3_list, s2_list, s1_list, cs_list, perc_list, flops = x
+        out, stats = self.run_dynamic(x)
+        s3, s2, s1, cs = stats[0], stats[1], stats[2], stats[3]
+        masker, c1, c2, c3, ds = self.flops_terms(x.shape)
+
+        # FLOPs bookkeeping, laud_resnet.py:112-147
+        dense = masker + c1 + c2 + c3 + ds
+        sparse = masker + c1 * cs * s1
+        sparse = sparse + c2 * cs ** 2 * s2
+        sparse = sparse + c3 * cs * s3
+        sparse = sparse + ds
         flops = flops + sparse
         perc = sparse / dense
 
@@ -524,22 +538,38 @@ class ResNet(nn.Module):
         x = self.maxpool(x)
         flops += x.shape[1] * x.shape[2] * x.shape[3] * 9
 
-        perc, stages = None, []
+        # dynamic blocks: each returns its 4 sparsities as a device vector; the FLOPs bookkeeping of
+        # laud_resnet.py:112-147,329-347 is done ONCE below on [n_blocks] vectors (no per-block scalar kernels)
+        stats, terms, sizes = [], [], []
         for i in range(4):
-            state = (x, None, None, None, None, perc, flops)
-            for blk in getattr(self, f"layer{i + 1}"):
-                state = blk(state, temperature)
-            x, s3, s2, s1, cs, perc, flops = state
-            stages.append((s3, s2, s1, cs))
+            layer = getattr(self, f"layer{i + 1}")
+            sizes.append(len(layer))
+            for blk in layer:
+                terms.append(blk.flops_terms(x.shape))
+                x, st = blk.run_dynamic(x)
+                stats.append(st)
+        st = torch.stack(stats)                                    # [n_blocks, 4] = s3, s2, s1, cs
+        key = (str(x.device), tuple(terms))
+        if getattr(self, "_terms_key", None) != key:
+            self._terms_key = key
+            self._terms = torch.tensor(terms, dtype=torch.float32, device=x.device)   # [n_blocks, 5]
+        tm = self._terms
+        s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+        sparse = tm[:, 0] + tm[:, 1] * cs * s1
+        sparse = sparse + tm[:, 2] * cs ** 2 * s2
+        sparse = sparse + tm[:, 3] * cs * s3
+        sparse = sparse + tm[:, 4]
+        perc = sparse / tm.sum(dim=1)
+        flops = flops + sparse.sum()
 
         x = self.avgpool(x)
-        flops += x.shape[1] * x.shape[2] * x.shape[3]
+        flops = flops + x.shape[1] * x.shape[2] * x.shape[3]
         x = torch.flatten(x, 1)
         c_in = x.shape[1]
         x = self.fc(x)
-        flops += c_in * x.shape[1]
-        cols = list(zip(*stages))
-        return x, list(cols[0]), list(cols[1]), list(cols[2]), list(cols[3]), perc, flops
+        flops = flops + c_in * x.shape[1]
+        split = lambda v: list(torch.split(v, sizes))
+        return x, split(s3), split(s2), split(s1), split(cs), perc, flops
 
     def get_optim_policies(self):
         backbone_params, masker_params = [], []

@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-emulation GPU baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (same kernels, no launch gaps)")
     args = ap.parse_args()
 
     import laudnet_amd
@@ -158,9 +159,14 @@ def main():
     calibrate_maskers(model, x, wl["p_channel"], wl["p_spatial"])
     calibrated_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
+    graphed = None
+    if args.graph:
+        from laudnet_amd.laud_resnet import GraphedForward
+        graphed = GraphedForward(model, x, 1.0)
+
     def step():
         with torch.no_grad():
-            return D.gather_outputs(model(x, 1.0))
+            return D.gather_outputs(graphed(x) if graphed is not None else model(x, 1.0))
 
     for _ in range(args.warmup):
         out = step()
@@ -197,7 +203,8 @@ def main():
         "config": {"workload": wl["name"] + f" bs{args.batch}/GPU, masks produced by the maskers in the timed region",
                    "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                    "parallelism": f"dp{world} (batch shards, all-gather logits + all-reduce stats over RCCL)",
-                   "mean_block_flops_ratio": round(flops_perc, 4), "module_macs_per_image": flops_per_img},
+                   "mean_block_flops_ratio": round(flops_perc, 4), "module_macs_per_image": flops_per_img,
+                   "launch": "hipGraph replay" if args.graph else "eager"},
     }
 
     n, ms, flops = timer.summary()

@@ -210,9 +210,13 @@ def main():
     n, ms, flops = timer.summary()
     if n:
         achieved = flops / (ms * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if args.workload == "channel" and args.batch == 256 and os.path.exists(tj):
+            traffic = json.load(open(tj))["traffic_bytes_per_launch"]
         result["roofline"] = {"kernel": "k_conv_image (3x3 per-image channel-subset conv, fp32 MFMA)", "bound": "mfma",
                               "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launches": n,
+                              "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": n,
                               "avg_launch_us": 1e3 * ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9}
 
     if rank == 0 and world == 1:

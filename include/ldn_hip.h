@@ -37,9 +37,10 @@ int ldn_device_cus(int* cus);
 /* ---- a1: Masker_spatial.forward, eval branch (models/utils.py:47-65) ------------------------
  * x [B,Hi,Wi,C] NHWC -> adaptive average pool to SxS (only if S < Hi, utils.py:48; bins
  * floor(i*H/S)..ceil((i+1)*H/S)) -> 1x1 conv C->2g (+bias) -> mask[b,j,y,x] = (l[j] >= l[g+j]).
- * logits [B,2g,S,S] may be NULL.  mask [B,g,S,S] fp32 {0,1}. */
+ * logits [B,2g,S,S] may be NULL.  mask [B,g,S,S] fp32 {0,1}.  work: float scratch of
+ * B * ldn_channel_masker_splits(Hi*Wi) * C entries, only needed for S == 1 (layer skip: whole-image window). */
 int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w /*[2g,C]*/,
-                       const float* bias /*[2g]*/, int g, int S, float* mask, float* logits, void* stream);
+                       const float* bias /*[2g]*/, int g, int S, float* mask, float* logits, float* work, void* stream);
 
 /* ---- a4/a11: F.interpolate(nearest) + ExpandMask x2 -> packed index lists -------------------
  * (laud_resnet.py:106-110, models/utils.py:74-89).  patch_mask [B,S,S] fp32 {0,1} (one mask

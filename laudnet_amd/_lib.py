@@ -18,7 +18,7 @@ SIGNATURES = {
     "ldn_last_error": ([], C.c_char_p),
     "ldn_version": ([], _I),
     "ldn_device_cus": ([C.POINTER(_I)], _I),
-    "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P], _I),
+    "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P], _I),
     "ldn_mask_to_index": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "ldn_gather_rows": ([_P, _I, _P, _P, _I, _I, _P, _I, _P], _I),
     "ldn_scatter_add_relu": ([_P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P], _I),

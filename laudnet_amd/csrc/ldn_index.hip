@@ -390,6 +390,43 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
     if (tid == 0) ch_cnt[b] = running;
 }
 
+// head of the whole-image spatial masker: one wave per image; gap = sum of the split partials / HW, then 2g dots
+__global__ __launch_bounds__(256) void k_spatial_head(const float* __restrict__ partial, int B, int HW, int C, int splits,
+                                                       const float* __restrict__ w, const float* __restrict__ bias, int g,
+                                                       float* __restrict__ mask, float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float inv = 1.f / (float)HW;
+    const int G2 = 2 * g;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
+        s *= inv;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < G2) acc[o] += w[o * C + c] * s;
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = wave_sum(acc[o]);
+    if (lane < g) {
+        float lk = 0.f, ld = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            if (o == lane) lk = acc[o] + bias[o];
+            if (o == lane + g) ld = acc[o] + bias[o];
+        }
+        mask[(size_t)b * g + lane] = lk >= ld ? 1.f : 0.f;
+        if (logits) {
+            logits[(size_t)b * G2 + lane] = lk;
+            logits[(size_t)b * G2 + g + lane] = ld;
+        }
+    }
+}
+
 }  // namespace ldn
 
 using namespace ldn;
@@ -408,11 +445,25 @@ extern "C" int ldn_device_cus(int* cus) {
 }
 
 extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w, const float* bias,
-                                  int g, int S, float* mask, float* logits, void* stream) {
+                                  int g, int S, float* mask, float* logits, float* work, void* stream) {
     LDN_REQUIRE(x && w && bias && mask, "ldn_spatial_masker: null pointer");
     LDN_REQUIRE(g >= 1 && g <= 4, "ldn_spatial_masker: mask groups must be 1..4 (got %d)", g);
     LDN_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C > 0 && S > 0, "ldn_spatial_masker: bad shape");
     const bool pooled = S < Hi;
+    if (pooled && S == 1 && Hi * Wi >= 64 && C % 4 == 0) {
+        // layer-skip masks (mask_size 1): the pooling window is the whole image -> two-stage deterministic GAP over
+        // many workgroups (one wave per image would walk 3136 pixels serially), then one wave per image for the head
+        LDN_REQUIRE(work, "ldn_spatial_masker: mask_size 1 needs the work buffer (B*splits*C floats)");
+        const int HW = Hi * Wi, splits = ldn_channel_masker_splits(HW), Q = C / 4;
+        const size_t lds = Q >= 256 ? 0 : (size_t)(256 / Q) * Q * 4 * sizeof(float);
+        hipLaunchKernelGGL(k_gap_partial, dim3(splits, B), dim3(256), lds, static_cast<hipStream_t>(stream), x, HW, C,
+                           splits, work);
+        LDN_CHECK_LAUNCH("k_gap_partial");
+        hipLaunchKernelGGL(k_spatial_head, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), work, B, HW,
+                           C, splits, w, bias, g, mask, logits);
+        LDN_CHECK_LAUNCH("k_spatial_head");
+        return LDN_OK;
+    }
     const long jobs = (long)B * (pooled ? S * S : Hi * Wi);
     hipLaunchKernelGGL(k_spatial_masker, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, B, Hi, Wi, C, w, bias, g, S, mask, logits);

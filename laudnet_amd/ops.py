@@ -50,8 +50,11 @@ def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False):
     sy, sx = (mask_size, mask_size) if pooled else (H, W)
     mask = torch.empty(B, groups, sy, sx, device=x_nhwc.device, dtype=torch.float32)
     logits = torch.empty(B, 2 * groups, sy, sx, device=x_nhwc.device, dtype=torch.float32) if want_logits else None
+    work = None
+    if pooled and mask_size == 1:
+        work = torch.empty(B * lib.ldn_channel_masker_splits(H * W) * C, device=x_nhwc.device, dtype=torch.float32)
     L.check(lib.ldn_spatial_masker(L.ptr(_f32c(x_nhwc, "x")), B, H, W, C, L.ptr(_f32c(weight, "w")),
-                                   L.ptr(_f32c(bias, "bias")), groups, mask_size, L.ptr(mask), L.ptr(logits),
+                                   L.ptr(_f32c(bias, "bias")), groups, mask_size, L.ptr(mask), L.ptr(logits), L.ptr(work),
                                    L.stream_ptr()), "ldn_spatial_masker")
     return mask, logits
 

@@ -66,7 +66,7 @@ def test_gather_scatter(ops):
 
 # ------------------------------------------------------------------ maskers
 @pytest.mark.parametrize("cin,g,S,hin", [(16, 1, 4, 8), (16, 1, 8, 8), (16, 2, 4, 8), (8, 1, 3, 14), (8, 1, 1, 7),
-                                         (256, 1, 7, 56), (64, 1, 14, 56)])
+                                         (256, 1, 7, 56), (64, 1, 14, 56), (64, 1, 1, 14), (256, 2, 1, 28)])
 def test_spatial_masker(ops, cin, g, S, hin):
     torch.manual_seed(cin + S)
     ref = TR.SpatialMaskerRef(cin, g, S).eval()

@@ -93,11 +93,14 @@ int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int taps, cons
  * channels [j*gran,(j+1)*gran), models/utils.py:18-25): ch_idx [B,width] left-packed ascending,
  * ch_cnt [B].  logits [B,2G] may be NULL.  If mask_in != NULL the masker arithmetic is skipped
  * and the lists are built from mask_in ("identical masks" parity runs).
- * work: float scratch of B*splits*C + B*C entries, splits = ldn_channel_masker_splits(HW). */
+ * work: float scratch of B*splits*C entries, splits = ldn_channel_masker_splits(HW).
+ * Fused GAP: if gap_partial != NULL it holds [B][gap_splits][C] partial channel sums of x already produced by
+ * ldn_conv_image(..., colsum) of the previous block; x and work are then unused (no extra pass over x). */
 int ldn_channel_masker_splits(int HW);
 int ldn_channel_masker(const float* x, int B, int HW, int C, const float* w1, const float* b1, const float* w2,
                        const float* b2, int hidden, int G, int gran, const float* mask_in, float* mask,
-                       float* logits, int32_t* ch_idx, int32_t* ch_cnt, float* work, void* stream);
+                       float* logits, int32_t* ch_idx, int32_t* ch_cnt, float* work, const float* gap_partial,
+                       int gap_splits, void* stream);
 
 /* ---- a7 (channel mode): per-image channel-subset convolution --------------------------------
  * (laud_resnet.py:115-144 with apply_channel_mask, models/utils.py:18-25; also the plain dense
@@ -109,6 +112,8 @@ int ldn_channel_masker(const float* x, int B, int HW, int C, const float* w1, co
  *         border class (top|bottom<<1)*4 + (left|right<<1) of the taps that fall outside
  *   if residual: v += residual[b,p,j] ; if relu: v = max(v,0) ; if post_sub: v -= post_sub[o]
  *   out[b,p,j] = v for j < Nb (= n_cnt[b] or cout); columns Nb..roundup4(Nb)-1 are written 0.
+ *   colsum (optional, dense output only) [B][ceil(Ho*Wo/32)][cout]: sum of out over each run of 32 pixels --
+ *   the global-average-pool partials the next block's channel masker needs (a2), fused into this epilogue.
  * A columns are "left-packed": column i of image b is channel k_idx[b,i].
  * Weight layout: without k_idx, w is n-major  [cout][ksize*ksize][cin]  (rows gathered through n_idx);
  *                with k_idx,    w is k-major  [ksize*ksize][cin][cout]  (rows gathered through k_idx, columns
@@ -119,7 +124,7 @@ int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, in
                    const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt, int kgran,
                    const int32_t* n_idx, const int32_t* n_cnt, const float* scale, const float* shift,
                    int shift_classes, const float* post_sub, int relu, const float* residual, int ldr,
-                   float* out, int ldo, void* stream);
+                   float* out, int ldo, float* colsum, void* stream);
 
 #ifdef __cplusplus
 }

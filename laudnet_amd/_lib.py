@@ -24,9 +24,9 @@ SIGNATURES = {
     "ldn_scatter_add_relu": ([_P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P], _I),
     "ldn_conv_rows": ([_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P], _I),
     "ldn_channel_masker_splits": ([_I], _I),
-    "ldn_channel_masker": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "ldn_channel_masker": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P], _I),
     "ldn_conv_image": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I,
-                        _P, _I, _P, _I, _P], _I),
+                        _P, _I, _P, _I, _P, _P], _I),
 }
 
 _lib = None

@@ -46,6 +46,7 @@ struct ImgArgs {
     const float* post_sub; int relu;
     const float* residual; int ldr;
     float* out; int ldo;
+    float* colsum;   // optional [B][ceil(HWo/32)][cout]: per 32-pixel subtile column sums of the output (fused GAP)
     int ntn;    // N blocks per image
     int bn;     // columns per N block (multiple of 32, <= NS*32)
     int bm;     // pixels per M block (multiple of 32, <= MS*32; balanced over the image)
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
         const int ccol = nj * 32 + tc4;
         if (s_nch[ccol] != -2) {
             const f32x4 ps = *reinterpret_cast<const f32x4*>(s_ps + ccol);
+            f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = mi * 32 + trow + 8 * it;
@@ -394,6 +396,21 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
                 }
                 v -= ps;
                 *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + n0 + ccol) = v;
+                csum += v;
+            }
+            if (p.colsum) {   // fused global-average-pool partials for the NEXT block's channel masker
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = csum[e];
+                    t += __shfl_xor(t, 8, 64);
+                    t += __shfl_xor(t, 16, 64);
+                    t += __shfl_xor(t, 32, 64);
+                    csum[e] = t;
+                }
+                if (trow == 0) {
+                    const size_t slot = ((size_t)b * ceil_div(HWo, 32) + (m0 >> 5) + mi) * p.cout + n0 + ccol;
+                    *reinterpret_cast<f32x4*>(p.colsum + slot) = csum;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -466,8 +483,9 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
                               const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt,
                               int kgran, const int32_t* n_idx, const int32_t* n_cnt, const float* scale,
                               const float* shift, int shift_classes, const float* post_sub, int relu,
-                              const float* residual, int ldr, float* out, int ldo, void* stream) {
+                              const float* residual, int ldr, float* out, int ldo, float* colsum, void* stream) {
     LDN_REQUIRE(a && w && scale && shift && out, "ldn_conv_image: null pointer");
+    LDN_REQUIRE(!colsum || (!n_idx && (uintptr_t)colsum % 16 == 0), "ldn_conv_image: colsum needs a dense output and 16-byte alignment");
     LDN_REQUIRE(ksize == 1 || ksize == 3, "ldn_conv_image: ksize must be 1 or 3 (got %d)", ksize);
     LDN_REQUIRE(stride >= 1 && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "ldn_conv_image: bad geometry");
     LDN_REQUIRE((Ho - 1) * stride < Hi && (Wo - 1) * stride < Wi, "ldn_conv_image: output grid exceeds input");
@@ -485,7 +503,7 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
     LDN_REQUIRE(!residual || ldr >= cout, "ldn_conv_image: ldr < cout");
     LDN_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "ldn_conv_image: a/w must be 16-byte aligned");
     ImgArgs p{a, lda, B, Hi, Wi, ksize, stride, Ho, Wo, w, cin, cout, k_idx, k_cnt, n_idx, n_cnt,
-              scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, 0, 0, 0};
+              scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, colsum, 0, 0, 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!k_idx) return launch_shape<B_NK>(p, st);                    // w is [cout][taps][cin]
     const int g = n_idx ? kgran : 4;                                 // w is [taps][cin][cout]

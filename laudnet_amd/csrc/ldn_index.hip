@@ -535,12 +535,18 @@ extern "C" int ldn_channel_masker_splits(int HW) {
 extern "C" int ldn_channel_masker(const float* x, int B, int HW, int C, const float* w1, const float* b1,
                                   const float* w2, const float* b2, int hidden, int G, int gran, const float* mask_in,
                                   float* mask, float* logits, int32_t* ch_idx, int32_t* ch_cnt, float* work,
-                                  void* stream) {
+                                  const float* gap_partial, int gap_splits, void* stream) {
     LDN_REQUIRE(mask && ch_idx && ch_cnt, "ldn_channel_masker: null output pointer");
     LDN_REQUIRE(B > 0 && G > 0 && gran > 0, "ldn_channel_masker: bad shape");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int splits = ldn_channel_masker_splits(HW);
-    if (!mask_in) {
+    int splits = ldn_channel_masker_splits(HW);
+    if (!mask_in && gap_partial) {
+        // the producer of x (ldn_conv_image with colsum) already left per-subtile channel sums: no pass over x
+        LDN_REQUIRE(w1 && b1 && gap_splits > 0 && HW > 0 && C > 0, "ldn_channel_masker: bad fused-GAP arguments");
+        LDN_REQUIRE(hidden == 0 || (w2 && b2), "ldn_channel_masker: two-layer masker needs w2/b2");
+        splits = gap_splits;
+        work = const_cast<float*>(gap_partial);
+    } else if (!mask_in) {
         LDN_REQUIRE(x && w1 && b1 && work, "ldn_channel_masker: null pointer");
         LDN_REQUIRE(hidden == 0 || (w2 && b2), "ldn_channel_masker: two-layer masker needs w2/b2");
         LDN_REQUIRE(HW > 0 && C > 0 && C % 4 == 0, "ldn_channel_masker: C must be a positive multiple of 4");

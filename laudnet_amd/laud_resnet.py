@@ -155,12 +155,18 @@ class Masker_channel_MLP(_PrepCache):
                     self._prep = (f(self.conv.weight), f(self.conv.bias), None, None)
         return self._prep
 
-    def lists(self, x, gran, mask_in=None, want_logits=False):
-        """-> (mask [B,G], ch_idx [B,G*gran], ch_cnt [B], logits)"""
+    accepts_fused_gap = True
+
+    def lists(self, x, gran, mask_in=None, want_logits=False, gap=None):
+        """-> (mask [B,G], ch_idx [B,G*gran], ch_cnt [B], logits).  `gap` = [B, splits, C] channel sums of x left by
+        the producing conv's epilogue (ldn_conv_image colsum): the masker then needs no pass over x."""
         if mask_in is not None:
             return ops.channel_masker(None, None, None, None, None, self.channel_dyn_group, gran,
                                       mask_in=mask_in.float().contiguous())
         w1, b1, w2, b2 = self._weights()
+        if gap is not None:
+            return ops.channel_masker(None, w1, b1, w2, b2, self.channel_dyn_group, gran, want_logits=want_logits,
+                                      gap_partial=gap, hw=x.shape[2] * x.shape[3])
         return ops.channel_masker(ops.as_nhwc(x), w1, b1, w2, b2, self.channel_dyn_group, gran, want_logits=want_logits)
 
     def forward(self, x, temperature):
@@ -318,12 +324,15 @@ class Bottleneck(_PrepCache):
         return self._prep
 
     # ---- execution ----------------------------------------------------------------------------
-    def _run_channel(self, x, p):
+    def _run_channel(self, x, p, gap_in=None, want_gap=False):
         B, Cin, Hi, Wi = x.shape
         W, gran = self.width, self.channel_dyn_granularity
         Ho, Wo = (Hi - 1) // self.stride + 1, (Wi - 1) // self.stride + 1
         xn = ops.as_nhwc(x)
-        mask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
+        if gap_in is not None and getattr(self.masker_channel, "accepts_fused_gap", False):
+            mask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask, gap=gap_in)
+        else:
+            mask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
         dev = x.device
         h1 = torch.empty(B, Hi, Wi, W, device=dev, dtype=torch.float32)
         ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1)
@@ -338,9 +347,11 @@ class Bottleneck(_PrepCache):
         else:
             identity = xn
             out = xn if self.inplace_residual else torch.empty_like(xn)
+        gap_out = torch.empty(B, (Ho * Wo + 31) // 32, cout, device=dev, dtype=torch.float32) if want_gap else None
         ops.conv_image(h2, p["w3"], p["s3"], p["t3c"], out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1,
-                       residual=identity)
+                       residual=identity, colsum=gap_out)
         self.last_channel_mask = mask       # kept for parity tooling (bench/tests feed it to the oracle)
+        self.last_gap = gap_out
         return ops.from_nhwc(out), mask
 
     def _run_spatial(self, x, p):
@@ -389,8 +400,9 @@ class Bottleneck(_PrepCache):
             cache[key] = ((b * Hi + y) * Wi + xx).reshape(-1).to(torch.int32).contiguous()
         return cache[key]
 
-    def run_dynamic(self, x):
-        """Execute the block on the HIP path.  Returns (out, stats[4] = {s3, s2, s1, channel sparsity} as a device
+    def run_dynamic(self, x, gap_in=None, want_gap=False):
+        """Execute the block on the HIP path.  gap_in / want_gap: fused global-average-pool hand-off between
+        consecutive channel-mode blocks (the conv3 epilogue leaves the channel sums the next masker needs).  Returns (out, stats[4] = {s3, s2, s1, channel sparsity} as a device
         tensor).  The FLOPs bookkeeping is separate (flops_terms) so a whole network can do it once, vectorised."""
         _eval_only(self, x)
         if self.dyn_mode == "both":
@@ -398,7 +410,7 @@ class Bottleneck(_PrepCache):
                            "(SURVEY 8f-2); use 'channel', 'spatial' or 'layer'")
         p = self._prep if self._prep is not None else self._prepare(x.device)
         if self.dyn_mode == "channel":
-            out, cmask = self._run_channel(x, p)
+            out, cmask = self._run_channel(x, p, gap_in, want_gap)
             stats = torch.ones(4, device=x.device)
             stats[3] = cmask.mean()
         else:
@@ -541,13 +553,18 @@ class ResNet(nn.Module):
         # dynamic blocks: each returns its 4 sparsities as a device vector; the FLOPs bookkeeping of
         # laud_resnet.py:112-147,329-347 is done ONCE below on [n_blocks] vectors (no per-block scalar kernels)
         stats, terms, sizes = [], [], []
-        for i in range(4):
-            layer = getattr(self, f"layer{i + 1}")
-            sizes.append(len(layer))
-            for blk in layer:
-                terms.append(blk.flops_terms(x.shape))
-                x, st = blk.run_dynamic(x)
-                stats.append(st)
+        blocks = [blk for i in range(4) for blk in getattr(self, f"layer{i + 1}")]
+        sizes = [len(getattr(self, f"layer{i + 1}")) for i in range(4)]
+        gap = None
+        for j, blk in enumerate(blocks):
+            terms.append(blk.flops_terms(x.shape))
+            nxt = blocks[j + 1] if j + 1 < len(blocks) else None
+            # a channel-mode block leaves the GAP partials of its output for the next block's MLP masker
+            want_gap = (nxt is not None and blk.dyn_mode == "channel" and nxt.dyn_mode == "channel"
+                        and getattr(nxt.masker_channel, "accepts_fused_gap", False) and nxt.forced_channel_mask is None)
+            x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap)
+            gap = getattr(blk, "last_gap", None) if want_gap else None
+            stats.append(st)
         st = torch.stack(stats)                                    # [n_blocks, 4] = s3, s2, s1, cs
         key = (str(x.device), tuple(terms))
         if getattr(self, "_terms_key", None) != key:

@@ -143,16 +143,26 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
 
 
 # ---------------------------------------------------------------------------------------- a2
-def channel_masker(x_nhwc, w1, b1, w2, b2, groups, gran, mask_in=None, want_logits=False):
+def channel_masker(x_nhwc, w1, b1, w2, b2, groups, gran, mask_in=None, want_logits=False, gap_partial=None, hw=None):
     """Masker_channel_MLP eval forward + active channel lists (see ldn_channel_masker).
     Returns (mask [B,G], ch_idx [B,G*gran] int32, ch_cnt [B] int32, logits [B,2G] or None)."""
     lib = L.load()
-    dev = x_nhwc.device if x_nhwc is not None else mask_in.device
-    L.require_device(x_nhwc, mask_in)
+    src = x_nhwc if x_nhwc is not None else (mask_in if mask_in is not None else gap_partial)
+    dev = src.device
+    L.require_device(x_nhwc, mask_in, gap_partial)
+    if gap_partial is not None:
+        x_nhwc = None
+    gap_splits = 0
     if mask_in is not None:
         B = mask_in.shape[0]
         HW = C = hidden = 0
         work = None
+    elif gap_partial is not None:   # fused GAP: [B, splits, C] channel sums left by the previous conv's epilogue
+        B, gap_splits, C = gap_partial.shape
+        HW = hw
+        hidden = 0 if w2 is None else w1.shape[0]
+        work = None
+        _f32c(gap_partial, "gap_partial")
     else:
         B, H, W, C = x_nhwc.shape
         HW = H * W
@@ -166,14 +176,14 @@ def channel_masker(x_nhwc, w1, b1, w2, b2, groups, gran, mask_in=None, want_logi
     logits = torch.empty(B, 2 * groups, device=dev, dtype=torch.float32) if (want_logits and mask_in is None) else None
     L.check(lib.ldn_channel_masker(L.ptr(x_nhwc), B, HW, C, L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), hidden, groups,
                                    gran, L.ptr(_f32c(mask_in, "mask_in") if mask_in is not None else None), L.ptr(mask),
-                                   L.ptr(logits), L.ptr(idx), L.ptr(cnt), L.ptr(work), L.stream_ptr()),
-            "ldn_channel_masker")
+                                   L.ptr(logits), L.ptr(idx), L.ptr(cnt), L.ptr(work), L.ptr(gap_partial), gap_splits,
+                                   L.stream_ptr()), "ldn_channel_masker")
     return mask, idx, cnt, logits
 
 
 # ---------------------------------------------------------------------------------------- a7 image
 def conv_image(a_nhwc, w, scale, shift, out_nhwc, *, ksize=1, stride=1, k_idx=None, k_cnt=None, kgran=1, n_idx=None,
-               n_cnt=None, post_sub=None, relu=1, residual=None):
+               n_cnt=None, post_sub=None, relu=1, residual=None, colsum=None):
     """Per-image channel-subset convolution (see ldn_conv_image).
     a_nhwc [B,Hi,Wi,lda]; w [cout,ksize*ksize,cin] without k_idx, [ksize*ksize,cin,cout] (k-major) with k_idx;
     shift [cout] or [16,cout]; out_nhwc [B,Ho,Wo,ldo]."""
@@ -193,5 +203,5 @@ def conv_image(a_nhwc, w, scale, shift, out_nhwc, *, ksize=1, stride=1, k_idx=No
                                L.ptr(_i32c(n_idx, "n_idx")), L.ptr(_i32c(n_cnt, "n_cnt")),
                                L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), classes, L.ptr(post_sub),
                                relu, L.ptr(residual), residual.shape[-1] if residual is not None else 0,
-                               L.ptr(_f32c(out_nhwc, "out")), ldo, L.stream_ptr()), "ldn_conv_image")
+                               L.ptr(_f32c(out_nhwc, "out")), ldo, L.ptr(colsum), L.stream_ptr()), "ldn_conv_image")
     return out_nhwc

@@ -111,3 +111,24 @@ def test_full_model_injected(name):
     assert_tuple_close(got[:1], fx["injected_run"][:1], atol=TOL, rtol=1e-5, what=name + " logits")
     assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what=name + " stats")
     assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what=name + " flops")
+
+
+def test_fused_gap_handoff_matches_unfused():
+    """Channel-mode network with masker-produced masks: the GAP partials left by conv3's epilogue (ldn_conv_image colsum)
+    must lead the next block's masker to the same decisions as its own pass over x."""
+    from laudnet_amd.laud_resnet import Masker_channel_MLP
+    fx = FULL["r101_channel2222"]
+    model, x = _hip_model(fx)
+    with torch.no_grad():
+        fused = model(x, 1.0)
+        masks_fused = [b.last_channel_mask.clone() for _, b in full_model_blocks(model)]
+        Masker_channel_MLP.accepts_fused_gap = False
+        try:
+            plain = model(x, 1.0)
+        finally:
+            Masker_channel_MLP.accepts_fused_gap = True
+        masks_plain = [b.last_channel_mask for _, b in full_model_blocks(model)]
+    same = all(torch.equal(a, b) for a, b in zip(masks_fused, masks_plain))
+    assert same, "fused-GAP masks differ from the stand-alone masker's (only a numerical near-tie could explain it)"
+    assert_tuple_close(fused[:1], plain[:1], atol=TOL, rtol=1e-5, what="fused vs unfused logits")
+    assert_tuple_close(fused, fx["masker_run"], atol=TOL, rtol=1e-4, what="vs reference fixture")

@@ -202,13 +202,19 @@ def test_conv_image_dense(ops, B, H, cin, cout, ksize, stride):
     Ho = (H - 1) // stride + 1
     out = torch.empty(B, Ho, Ho, cout, device=DEV)
     resid = seeded_randn((B, Ho, Ho, cout), 24)
+    colsum = torch.full((B, (Ho * Ho + 31) // 32, cout), float("nan"), device=DEV)
     ops.conv_image(x.permute(0, 2, 3, 1).contiguous().to(DEV),
                    w.permute(0, 2, 3, 1).reshape(cout, ksize * ksize, cin).contiguous().to(DEV), sc.to(DEV), sh.to(DEV),
-                   out, ksize=ksize, stride=stride, relu=1, residual=resid.to(DEV))
+                   out, ksize=ksize, stride=stride, relu=1, residual=resid.to(DEV), colsum=colsum)
     want = F.conv2d(x.double(), w.double(), stride=stride, padding=ksize // 2)
     want = want * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
     want = torch.relu(want.permute(0, 2, 3, 1) + resid.double()).float()
     assert torch.allclose(out.cpu(), want, atol=1e-4, rtol=1e-4)
+    # fused GAP partials: sums over each run of 32 pixels (row-major), every slot written exactly once
+    flat = out.cpu().reshape(B, Ho * Ho, cout).double()
+    pad = (-flat.shape[1]) % 32
+    flat = torch.cat([flat, flat.new_zeros(B, pad, cout)], dim=1).reshape(B, -1, 32, cout).sum(dim=2)
+    assert torch.allclose(colsum.cpu().double(), flat, atol=1e-3, rtol=1e-5)
 
 
 @pytest.mark.parametrize("B,H,cin,W,gran,stride", [(3, 14, 64, 16, 1, 1), (3, 14, 32, 16, 2, 2), (4, 7, 128, 64, 4, 1),

@@ -102,8 +102,9 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_sc = smem + 2 * BUF;                          // [BNX] BN scale of the column's channel
     float* s_ps = s_sc + BNX;                              // [BNX] post-ReLU constant of the column's channel
-    int* s_pix = reinterpret_cast<int*>(s_ps + BNX);       // [BM] (oy<<16|ox) or -1
-    int* s_cls = s_pix + BM;                               // [BM] border class * cout
+    float* s_sh = s_ps + BNX;                              // [shift_classes][BNX] folded BN shift of the column's channel
+    int* s_pix = reinterpret_cast<int*>(s_sh + p.shift_classes * BNX);   // [BM] (oy<<16|ox) or -1
+    int* s_cls = s_pix + BM;                               // [BM] border class * BNX
     int* s_nch = s_cls + BM;                               // [BNX] channel of column, -1 zero pad, -2 skip
     int* s_kidx = s_nch + BNX;                             // [cin] (only with k_idx)
 
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
             if (p.shift_classes > 1) {
                 const int top = oy * p.stride - pad < 0, bot = oy * p.stride + pad >= p.Hi;
                 const int lef = ox * p.stride - pad < 0, rig = ox * p.stride + pad >= p.Wi;
-                cls = ((top | (bot << 1)) * 4 + (lef | (rig << 1))) * p.cout;
+                cls = ((top | (bot << 1)) * 4 + (lef | (rig << 1))) * BNX;
             }
         }
         s_pix[i] = pix;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
         s_nch[i] = chn;
         s_sc[i] = chn >= 0 ? p.scale[chn] : 0.f;
         s_ps[i] = (chn >= 0 && p.post_sub) ? p.post_sub[chn] : 0.f;
+        for (int c = 0; c < p.shift_classes; ++c) s_sh[c * BNX + i] = chn >= 0 ? p.shift[c * p.cout + chn] : 0.f;
     }
     if (p.k_idx)
         for (int i = tid; i < Kb; i += 512) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
@@ -173,6 +175,21 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
         long aoff[MS];   // element offset of this thread's A rows for the current tap, -1 = zero row
         long boff[NS];   // B_NK: element offset of w[ch_n][tap][0], -1 = zero row
         int cur_tap = 0;
+        int kr[NS], cn0[NS], cn2[NS];   // k-major: this thread's k row / first and third column channel per slot
+        if (KN) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int sid = (wave + 4 * u) * 64 + lane;
+                kr[u] = sid / BSL;
+                const int j = (sid - kr[u] * BSL) * 4;
+                const bool in = j < nsub * 32;
+                cn0[u] = in ? s_nch[j] : -1;
+                cn2[u] = in ? s_nch[j + 2] : -1;
+            }
+        }
+        // the producers share each SIMD with an MFMA wave that is older (wins issue arbitration): raise their priority
+        // so address generation and load issue are never starved (an MFMA needs one issue slot per 64 cycles)
+        __builtin_amdgcn_s_setprio(2);
         f32x4 rb[NS];    // VGPR-staged weight slots (only when !BGLDS)
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         const int Kb4 = p.k_idx ? round_up(Kb, 4) : p.cin;
@@ -222,34 +239,31 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
                                base + (BM + (wave + 4 * u) * 8) * BK);
             } else {
                 // k-major: the B tile is [32 k rows][BNX columns]; wave instruction (wave + 4u) covers 64 consecutive
-                // 16-byte slots; slot sid -> (k row sid / BSL, column group sid % BSL)
+                // 16-byte slots.  Slot -> (k row kr[u], columns) is fixed for the whole block (cn*[u] hoisted); per chunk
+                // only the weight ROW changes.  Invalid lanes read the zero line instead of branching.
+                int kch[NS];
 #pragma unroll
                 for (int u = 0; u < NS; ++u) {
-                    const int sid = (wave + 4 * u) * 64 + lane;
-                    const int r = sid / BSL, j = (sid - r * BSL) * 4;     // k row, first packed column
-                    const int kpos = c0 + r;
-                    const bool kok = kpos < Kb && j < nsub * 32;
-                    const float* wr = g_zero16;
-                    if (kok) wr = p.w + ((long)cur_tap * p.cin + (p.k_idx ? s_kidx[kpos] : kpos)) * p.cout;
-                    if (BMODE == B_KN4) {
-                        const int chn = kok ? s_nch[j] : -1;
-                        glds16(chn >= 0 ? wr + chn : g_zero16, base + BM * BK + (wave + 4 * u) * 256);
-                    } else {
-                        f32x4 v = zero4;
-                        if (kok) {
-                            if (BMODE == B_KN2) {
-                                const int c0n = s_nch[j], c2n = s_nch[j + 2];
-                                if (c0n >= 0) { const float2 lo = *reinterpret_cast<const float2*>(wr + c0n); v[0] = lo.x; v[1] = lo.y; }
-                                if (c2n >= 0) { const float2 hi = *reinterpret_cast<const float2*>(wr + c2n); v[2] = hi.x; v[3] = hi.y; }
-                            } else {
+                    const int kpos = min(c0 + kr[u], Kb - 1);
+                    kch[u] = p.k_idx ? s_kidx[kpos] : kpos;
+                }
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const int cn = s_nch[j + e];
-                                    if (cn >= 0) v[e] = wr[cn];
-                                }
-                            }
+                for (int u = 0; u < NS; ++u) {
+                    const bool kok = c0 + kr[u] < Kb;
+                    const float* wr = p.w + ((long)cur_tap * p.cin + kch[u]) * p.cout;
+                    if (BMODE == B_KN4) {
+                        glds16((kok && cn0[u] >= 0) ? wr + cn0[u] : g_zero16, base + BM * BK + (wave + 4 * u) * 256);
+                    } else if (BMODE == B_KN2) {
+                        const float2 lo = *reinterpret_cast<const float2*>((kok && cn0[u] >= 0) ? wr + cn0[u] : g_zero16);
+                        const float2 hi = *reinterpret_cast<const float2*>((kok && cn2[u] >= 0) ? wr + cn2[u] : g_zero16);
+                        rb[u][0] = lo.x; rb[u][1] = lo.y; rb[u][2] = hi.x; rb[u][3] = hi.y;
+                    } else {
+                        const int j = (((wave + 4 * u) * 64 + lane) % BSL) * 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int cn = j < nsub * 32 ? s_nch[j + e] : -1;
+                            rb[u][e] = *((kok && cn >= 0) ? wr + cn : g_zero16);
                         }
-                        rb[u] = v;
                     }
                 }
             }
@@ -271,16 +285,33 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
             advance();
             for (int ch = 0; ch < nch; ++ch) {
                 const int buf = ch & 1;
+                LDN_TRACE_T(tr_a)
                 if (!BGLDS) bstore(buf);
+#ifdef LDN_TRACE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+                LDN_TRACE_T(tr_b)
+                LDN_TRACE_ADD(tr_mma, tr_a, tr_b)     // producer: waiting for its loads (+ ds_write)
                 block_sync();                 // barrier(ch): chunk ch is in LDS; consumers are done with chunk ch-1
+                LDN_TRACE_T(tr_a)
+                LDN_TRACE_ADD(tr_bar, tr_b, tr_a)     // producer: waiting at the barrier for the consumers
 #if !(LDN_ABLATE & 2)
                 if (ch + 1 < nch) { issue(c0, buf ^ 1); advance(); }
 #else
                 if (ch + 1 < nch) { advance(); }
 #endif
+                LDN_TRACE_T(tr_b)
+                LDN_TRACE_ADD(tr_iss, tr_a, tr_b)     // producer: address generation + load issue
             }
             block_sync();                     // matches the consumers' final barrier
         }
+#ifdef LDN_TRACE
+        if (tid == 256 && g_trace) {
+            unsigned long long* r = g_trace + ((size_t)blockIdx.x + gridDim.x) * 6;
+            r[0] = tr_t0; r[1] = __builtin_amdgcn_s_memtime(); r[2] = 0; r[3] = 1;
+            r[4] = ntiles | (tr_bar << 32); r[5] = (tr_mma << 32) | (tr_iss & 0xffffffffull);
+        }
+#endif
         return;
     }
 
@@ -374,7 +405,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = chn >= 0 ? acc[s][r] * sc + p.shift[s_cls[mi * 32 + row] + chn] : 0.f;
+            const float v = chn >= 0 ? acc[s][r] * sc + s_sh[s_cls[mi * 32 + row] + col] : 0.f;
             scratch[row * 32 + l31] = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -432,7 +463,7 @@ template <int MS, int NS, int BMODE, bool KSKIP>
 static int launch_k(const ImgArgs& p, hipStream_t st) {
     // blocks of <= 64 KiB LDS run two per CU (memory-bound early stages need the extra waves in flight)
     constexpr int MINW = (MS + NS) <= 8 ? 4 : 2;
-    const size_t lds = (size_t)2 * (MS + NS) * 32 * BK * sizeof(float) + (size_t)(2 * NS * 32) * sizeof(float) +
+    const size_t lds = (size_t)2 * (MS + NS) * 32 * BK * sizeof(float) + (size_t)((2 + p.shift_classes) * NS * 32) * sizeof(float) +
                        (size_t)(2 * MS * 32 + NS * 32 + (p.k_idx ? p.cin : 0)) * sizeof(int);
     LDN_REQUIRE(lds <= 160 * 1024, "k_conv_image: %zu B of LDS exceed 160 KiB (cin too large for k_idx)", lds);
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_conv_image<MS, NS, BMODE, KSKIP, MINW>), lds),

@@ -40,7 +40,7 @@ fns = {
 }
 fn = fns[kind]
 lib = _lib.load()
-nblk = 1 << 16
+nblk = 1 << 17
 trace = torch.zeros(nblk * 6, dtype=torch.int64, device=dev)
 lib.ldn_debug_set_trace.argtypes = [ctypes.c_void_p]
 for _ in range(3):
@@ -53,6 +53,11 @@ torch.cuda.synchronize()
 print("launch us", 1e3 * e0.elapsed_time(e1))
 t = trace.cpu().numpy().reshape(-1, 6)
 t = t[t[:, 0] != 0]
+prod = t[t[:, 2] == 0]
+t = t[t[:, 2] != 0]
+if len(prod):
+    pn = prod[:, 4] & 0xffffffff; big = pn == pn.max()
+    print('PRODUCER wave (largest blocks): dur', (prod[big, 1] - prod[big, 0]).mean(), ' wait-own-loads', ((prod[big, 5] >> 32) & 0xffffffff).mean(), ' wait-barrier', (prod[big, 4] >> 32).mean(), ' issue', (prod[big, 5] & 0xffffffff).mean())
 t0, t1, hw, xcc, nt_bar, mma_iss = [t[:, i] for i in range(6)]
 ntiles = nt_bar & 0xffffffff; t_bar = nt_bar >> 32; t_mma = (mma_iss >> 32) & 0xffffffff; t_iss = mma_iss & 0xffffffff; tm = t1
 base = t0.min()

@@ -126,6 +126,22 @@ int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, in
                    int shift_classes, const float* post_sub, int relu, const float* residual, int ldr,
                    float* out, int ldo, float* colsum, void* stream);
 
+/* ---- a7 (spatial / layer / both): the same kernel over PACKED PIXEL LISTS ---------------------
+ * Image b owns the packed rows [row_prefix[b], row_prefix[b+1]) (B == 1, row_prefix == NULL: rows [0, *m_count),
+ * m_count == NULL -> m_cap).  For packed row R:
+ *   A row of tap t  = a_map ? a_map[R*taps + t] : R        (-1 = zero row; a_map required for taps == 9)
+ *   destination row = out_map ? out_map[R] : R             (scatter into the NHWC residual stream)
+ *   border class    = from pix_map[R] (flat output pixel b*Ho*Wo + oy*Wo + ox) when shift_classes == 16
+ * Channel subsets (k_idx/n_idx, per image) and all epilogue terms are as in ldn_conv_image; relu == 2 applies
+ * ReLU only where relu_if_neg[R] < 0.  ldn_conv_rows is the B == 1, no-channel-list special case.
+ * dyn_mode 'both' (laud_resnet.py:101-103) = packed rows from ldn_mask_to_index + lists from ldn_channel_masker. */
+int ldn_conv_packed(const float* a, int lda, int B, const int32_t* row_prefix, const int32_t* m_count, int m_cap,
+                    const int32_t* a_map, int taps, const int32_t* out_map, const int32_t* pix_map, int Hi, int Wi,
+                    int Ho, int Wo, int stride, const float* w, int cin, int cout, const int32_t* k_idx,
+                    const int32_t* k_cnt, int kgran, const int32_t* n_idx, const int32_t* n_cnt, const float* scale,
+                    const float* shift, int shift_classes, const float* post_sub, int relu,
+                    const int32_t* relu_if_neg, const float* residual, int ldr, float* out, int ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,8 @@ SIGNATURES = {
     "ldn_conv_rows": ([_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P], _I),
     "ldn_channel_masker_splits": ([_I], _I),
     "ldn_channel_masker": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P], _I),
+    "ldn_conv_packed": ([_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P,
+                         _I, _P, _I, _P, _P, _I, _P, _I, _P], _I),
     "ldn_conv_image": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I,
                         _P, _I, _P, _I, _P, _P], _I),
 }

@@ -47,6 +47,16 @@ struct ImgArgs {
     const float* residual; int ldr;
     float* out; int ldo;
     float* colsum;   // optional [B][ceil(HWo/32)][cout]: per 32-pixel subtile column sums of the output (fused GAP)
+    // ---- packed pixel-list mode (spatial / layer / both): image b owns packed rows [row_prefix[b], row_prefix[b+1])
+    //      (or, with B == 1 and row_prefix == NULL, rows [0, *m_count)); see ldn_conv_packed in include/ldn_hip.h
+    int packed;                      // 0 = dense image mode (all of the above), 1 = packed rows
+    const int32_t* row_prefix;       // [B+1] or NULL
+    const int32_t* m_count;          // device row count for the single-image form, or NULL (= m_cap)
+    int m_cap;                       // worst-case rows per image (grid sizing)
+    const int32_t* a_map;            // [rows][taps] A row of each tap (-1 = zero), NULL = identity (taps == 1)
+    const int32_t* out_map;          // [rows] destination row in out/residual, NULL = identity
+    const int32_t* pix_map;          // [rows] flat output pixel (b*Ho*Wo + oy*Wo + ox) for the border classes, or NULL
+    const int32_t* relu_if_neg;      // relu == 2: ReLU only where relu_if_neg[row] < 0
     int ntn;    // N blocks per image
     int bn;     // columns per N block (multiple of 32, <= NS*32)
     int bm;     // pixels per M block (multiple of 32, <= MS*32; balanced over the image)
@@ -107,6 +117,8 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
     int* s_cls = s_pix + BM;                               // [BM] border class * BNX
     int* s_nch = s_cls + BM;                               // [BNX] channel of column, -1 zero pad, -2 skip
     int* s_kidx = s_nch + BNX;                             // [cin] (only with k_idx)
+    int* s_orow = s_kidx + (p.k_idx ? p.cin : 0);          // packed mode: [BM] destination row (-1 invalid)
+    int* s_arow = s_orow + BM;                             // packed mode: [BM][taps] A row per tap (-1 zero)
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
@@ -115,14 +127,25 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
     const int b = bid % p.B;
     const int t = bid / p.B;
     const int nt = t % p.ntn, mt = t / p.ntn;
-    const int HWo = p.Ho * p.Wo;
+    // rows of this image: dense mode = its Ho*Wo output pixels; packed mode = its slice of the packed row lists
+    int rbase, HWo;
+    if (!p.packed) {
+        HWo = p.Ho * p.Wo;
+        rbase = b * HWo;
+    } else if (p.row_prefix) {
+        rbase = p.row_prefix[b];
+        HWo = p.row_prefix[b + 1] - rbase;
+    } else {
+        rbase = 0;
+        HWo = p.m_count ? min(p.m_count[0], p.m_cap) : p.m_cap;
+    }
     const int m0 = mt * p.bm, n0 = nt * p.bn;
     const int Kb = p.k_idx ? p.k_cnt[b] : p.cin;
     const int Nb = p.n_idx ? p.n_cnt[b] : p.cout;
     const int Nb4 = min(round_up(Nb, 4), p.cout);
     if (n0 >= Nb4 || m0 >= HWo) return;
-    const int T = p.ksize * p.ksize;
-    const int pad = p.ksize >> 1;
+    const int T = p.packed ? p.ksize : p.ksize * p.ksize;   // packed mode: ksize carries the tap count (1 or 9)
+    const int pad = p.packed ? (T == 9 ? 1 : 0) : p.ksize >> 1;
     const int msub = ceil_div(min(HWo - m0, p.bm), 32);        // valid m-subtiles (1..MS)
     const int nsub = ceil_div(min(Nb4 - n0, p.bn), 32);        // valid n-subtiles (1..NS)
     const int ntiles = msub * nsub;
@@ -132,9 +155,15 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
 
     for (int i = tid; i < BM; i += 512) {
         const int m = m0 + i;
-        int pix = -1, cls = 0;
-        if (m < HWo) {
-            const int oy = m / p.Wo, ox = m - oy * p.Wo;
+        int pix = -1, cls = 0, oy = 0, ox = 0;
+        const bool valid = m < HWo && i < p.bm;
+        if (valid) {
+            if (!p.packed) {
+                oy = m / p.Wo; ox = m - oy * p.Wo;
+            } else if (p.pix_map) {
+                const int q = p.pix_map[rbase + m] % (p.Ho * p.Wo);
+                oy = q / p.Wo; ox = q - oy * p.Wo;
+            }
             pix = (oy << 16) | ox;
             if (p.shift_classes > 1) {
                 const int top = oy * p.stride - pad < 0, bot = oy * p.stride + pad >= p.Hi;
@@ -144,7 +173,20 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
         }
         s_pix[i] = pix;
         s_cls[i] = cls;
+        if (p.packed) {
+            int orow = -1;
+            if (valid) {
+                orow = p.out_map ? p.out_map[rbase + m] : rbase + m;
+                if (p.relu == 2 && p.relu_if_neg[rbase + m] < 0) orow |= 0x40000000;   // bit 30: apply ReLU to this row
+            }
+            s_orow[i] = orow;
+        }
     }
+    if (p.packed)
+        for (int i = tid; i < BM * T; i += 512) {
+            const int r = i / T, m = m0 + r;
+            s_arow[i] = (m < HWo && r < p.bm) ? (p.a_map ? p.a_map[(size_t)(rbase + m) * T + (i - r * T)] : rbase + m) : -1;
+        }
     for (int i = tid; i < BNX; i += 512) {
         const int j = n0 + i;
         const bool in_block = i < p.bn;
@@ -195,16 +237,23 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
         const int Kb4 = p.k_idx ? round_up(Kb, 4) : p.cin;
 
         auto set_tap = [&](int tap) {
-            const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+            const int ksz = p.packed ? 3 : p.ksize;
+            const int ky = tap / ksz, kx = tap - ky * ksz;
 #pragma unroll
             for (int u = 0; u < MS; ++u) {
                 long off = -1;
                 if (u < msub) {
-                    const int pix = s_pix[(wave + 4 * u) * 8 + rg];
-                    if (pix >= 0) {
-                        const int iy = (pix >> 16) * p.stride + ky - pad, ix = (pix & 0xffff) * p.stride + kx - pad;
-                        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-                            off = ((long)(b * p.Hi + iy) * p.Wi + ix) * p.lda;
+                    const int row = (wave + 4 * u) * 8 + rg;
+                    if (p.packed) {
+                        const int ar = s_arow[row * T + tap];
+                        if (ar >= 0) off = (long)ar * p.lda;
+                    } else {
+                        const int pix = s_pix[row];
+                        if (pix >= 0) {
+                            const int iy = (pix >> 16) * p.stride + ky - pad, ix = (pix & 0xffff) * p.stride + kx - pad;
+                            if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+                                off = ((long)(b * p.Hi + iy) * p.Wi + ix) * p.lda;
+                        }
                     }
                 }
                 aoff[u] = off;
@@ -419,9 +468,15 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
                 const int row = mi * 32 + trow + 8 * it;
                 if (s_pix[row] < 0) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (trow + 8 * it) * 32 + tc4);
-                const size_t orow = (size_t)b * HWo + m0 + row;
+                size_t orow = (size_t)rbase + m0 + row;
+                bool do_relu = p.relu == 1;
+                if (p.packed) {
+                    const int o = s_orow[row];
+                    do_relu = do_relu || (o & 0x40000000);
+                    orow = (size_t)(o & 0x3fffffff);
+                }
                 if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + orow * p.ldr + n0 + ccol);
-                if (p.relu) {
+                if (do_relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
@@ -439,7 +494,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
                     csum[e] = t;
                 }
                 if (trow == 0) {
-                    const size_t slot = ((size_t)b * ceil_div(HWo, 32) + (m0 >> 5) + mi) * p.cout + n0 + ccol;
+                    const size_t slot = ((size_t)b * ceil_div(HWo, 32) + (m0 >> 5) + mi) * p.cout + n0 + ccol;   // dense mode only
                     *reinterpret_cast<f32x4*>(p.colsum + slot) = csum;
                 }
             }
@@ -464,12 +519,12 @@ static int launch_k(const ImgArgs& p, hipStream_t st) {
     // blocks of <= 64 KiB LDS run two per CU (memory-bound early stages need the extra waves in flight)
     constexpr int MINW = (MS + NS) <= 8 ? 4 : 2;
     const size_t lds = (size_t)2 * (MS + NS) * 32 * BK * sizeof(float) + (size_t)((2 + p.shift_classes) * NS * 32) * sizeof(float) +
-                       (size_t)(2 * MS * 32 + NS * 32 + (p.k_idx ? p.cin : 0)) * sizeof(int);
+                       (size_t)(2 * MS * 32 + NS * 32 + (p.k_idx ? p.cin : 0) + (p.packed ? MS * 32 * (1 + p.ksize) : 0)) * sizeof(int);
     LDN_REQUIRE(lds <= 160 * 1024, "k_conv_image: %zu B of LDS exceed 160 KiB (cin too large for k_idx)", lds);
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_conv_image<MS, NS, BMODE, KSKIP, MINW>), lds),
                 "k_conv_image: cannot reserve %zu B of LDS", lds);
     ImgArgs q = p;
-    const int msubs = ceil_div(p.Ho * p.Wo, 32);
+    const int msubs = ceil_div(p.packed ? p.m_cap : p.Ho * p.Wo, 32);
     const int mtn = ceil_div(msubs, MS);              // M blocks per image, then balance their sizes
     q.bm = ceil_div(msubs, mtn) * 32;
     const unsigned grid = (unsigned)p.B * mtn * p.ntn;
@@ -482,7 +537,7 @@ template <int BMODE>
 static int launch_shape(const ImgArgs& a, hipStream_t st) {
     ImgArgs p = a;
     const int nsubs = ceil_div(a.cout, 32);
-    const int hw = a.Ho * a.Wo;
+    const int hw = a.packed ? a.m_cap : a.Ho * a.Wo;
     // tile shape: as many output pixels as the LDS budget allows for the layer's width, so that every byte pulled
     // into the CU is reused by as many MFMAs as possible (whole 14x14 / 7x7 images at stages 3 / 4)
     int per;                                   // n-subtiles per N block
@@ -497,6 +552,14 @@ static int launch_shape(const ImgArgs& a, hipStream_t st) {
     if (per <= 4) return launch_k<4, 4, BMODE, true>(p, st);
     if (per <= 6) return launch_k<8, 6, BMODE, false>(p, st);
     return launch_k<4, 10, BMODE, false>(p, st);
+}
+
+static int dispatch_mode(const ImgArgs& p, int kgran, hipStream_t st) {
+    if (!p.k_idx) return launch_shape<B_NK>(p, st);                  // w is [cout][taps][cin]
+    const int g = p.n_idx ? kgran : 4;                               // w is [taps][cin][cout]
+    if (g % 4 == 0) return launch_shape<B_KN4>(p, st);
+    if (g % 2 == 0) return launch_shape<B_KN2>(p, st);
+    return launch_shape<B_KN1>(p, st);
 }
 
 }  // namespace ldn
@@ -534,11 +597,48 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
     LDN_REQUIRE(!residual || ldr >= cout, "ldn_conv_image: ldr < cout");
     LDN_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "ldn_conv_image: a/w must be 16-byte aligned");
     ImgArgs p{a, lda, B, Hi, Wi, ksize, stride, Ho, Wo, w, cin, cout, k_idx, k_cnt, n_idx, n_cnt,
-              scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, colsum, 0, 0, 0};
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!k_idx) return launch_shape<B_NK>(p, st);                    // w is [cout][taps][cin]
-    const int g = n_idx ? kgran : 4;                                 // w is [taps][cin][cout]
-    if (g % 4 == 0) return launch_shape<B_KN4>(p, st);
-    if (g % 2 == 0) return launch_shape<B_KN2>(p, st);
-    return launch_shape<B_KN1>(p, st);
+              scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, colsum,
+              0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    return dispatch_mode(p, kgran, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ldn_conv_packed(const float* a, int lda, int B, const int32_t* row_prefix, const int32_t* m_count,
+                               int m_cap, const int32_t* a_map, int taps, const int32_t* out_map,
+                               const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride, const float* w,
+                               int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt, int kgran,
+                               const int32_t* n_idx, const int32_t* n_cnt, const float* scale, const float* shift,
+                               int shift_classes, const float* post_sub, int relu, const int32_t* relu_if_neg,
+                               const float* residual, int ldr, float* out, int ldo, void* stream) {
+    LDN_REQUIRE(a && w && scale && shift && out, "ldn_conv_packed: null pointer");
+    LDN_REQUIRE(taps == 1 || taps == 9, "ldn_conv_packed: taps must be 1 or 9 (got %d)", taps);
+    LDN_REQUIRE(a_map || taps == 1, "ldn_conv_packed: a_map required when taps > 1");
+    LDN_REQUIRE(B >= 1 && (row_prefix || B == 1), "ldn_conv_packed: B > 1 needs row_prefix");
+    LDN_REQUIRE(cin > 0 && cout > 0 && cin % 4 == 0, "ldn_conv_packed: cin must be a positive multiple of 4 (got %d)", cin);
+    LDN_REQUIRE(lda % 4 == 0 && lda >= (k_idx ? 4 : cin), "ldn_conv_packed: lda must be a multiple of 4 and >= cin");
+    LDN_REQUIRE((k_idx == nullptr) == (k_cnt == nullptr) && (n_idx == nullptr) == (n_cnt == nullptr),
+                "ldn_conv_packed: index list and count must be given together");
+    LDN_REQUIRE((!k_idx && !n_idx) || row_prefix, "ldn_conv_packed: per-image channel lists need per-image row ranges");
+    LDN_REQUIRE(shift_classes == 1 || (shift_classes == 16 && pix_map && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0 && stride >= 1),
+                "ldn_conv_packed: shift_classes 16 needs pix_map and the layer geometry");
+    LDN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || relu_if_neg), "ldn_conv_packed: bad relu mode");
+    LDN_REQUIRE(ldo >= cout && ldo % 4 == 0 && cout % 4 == 0, "ldn_conv_packed: cout and ldo must be multiples of 4, ldo >= cout");
+    LDN_REQUIRE(!(n_idx && residual), "ldn_conv_packed: residual with an output-channel subset is not supported");
+    LDN_REQUIRE((uintptr_t)out % 16 == 0 && (!residual || ((uintptr_t)residual % 16 == 0 && ldr % 4 == 0 && ldr >= cout)),
+                "ldn_conv_packed: out/residual must be 16-byte aligned with strides that are multiples of 4");
+    LDN_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "ldn_conv_packed: a/w must be 16-byte aligned");
+    if (m_cap <= 0) return LDN_OK;
+    ImgArgs p{a, lda, B, Hi > 0 ? Hi : 1, Wi > 0 ? Wi : 1, taps, stride >= 1 ? stride : 1, Ho > 0 ? Ho : 1, Wo > 0 ? Wo : 1,
+              w, cin, cout, k_idx, k_cnt, n_idx, n_cnt, scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo,
+              nullptr, 1, row_prefix, m_count, m_cap, a_map, out_map, pix_map, relu_if_neg, 0, 0, 0};
+    return dispatch_mode(p, kgran, static_cast<hipStream_t>(stream));
+}
+
+// the shared-weight packed-row convolution of the spatial / layer path: one "image" holding every active row
+extern "C" int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count,
+                             int m_cap, const float* w, int cin, int cout, const float* scale, const float* shift,
+                             int relu, const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual,
+                             int ldr, float* out, int ldo, void* stream) {
+    return ldn_conv_packed(a, lda, 1, nullptr, m_count, m_cap, a_rows, taps, out_rows, nullptr, 0, 0, 0, 0, 1, w, cin, cout,
+                           nullptr, nullptr, 1, nullptr, nullptr, scale, shift, 1, nullptr, relu, relu_if_neg, residual, ldr,
+                           out, ldo, stream);
 }

@@ -390,6 +390,49 @@ class Bottleneck(_PrepCache):
         self.last_spatial_mask = patch
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), patch, ix
 
+    def _run_both(self, x, p):
+        """dyn_mode 'both' (laud_resnet.py:101-103): packed pixel lists (spatial mask) x per-image channel lists."""
+        B, Cin, Hi, Wi = x.shape
+        W, gran = self.width, self.channel_dyn_granularity
+        Ho = Wo = self.output_size
+        if Hi != Ho * self.stride or Wi != Wo * self.stride:
+            raise LdnError(f"Bottleneck: input {Hi}x{Wi} does not match output_size {Ho} * stride {self.stride}")
+        ms = self.masker_spatial
+        if ms.mask_channel_group != 1:
+            raise LdnError("HIP path: spatial_mask_channel_group > 1 is not built (all shipped configs use 1)")
+        xn = ops.as_nhwc(x)
+        dev = x.device
+        cmask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
+        if self.forced_spatial_mask is not None:
+            patch = self.forced_spatial_mask.to(device=dev, dtype=torch.float32).contiguous()
+        else:
+            patch = ms(x, 1.0)[0]
+        ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, self.stride)
+        x2d = xn.reshape(B * Hi * Wi, Cin)
+        geom = (Hi, Wi, Ho, Wo, self.stride)
+        h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
+        ops.conv_packed(x2d, p["w1"], p["s1"], p["t1"], h1, B=B, row_prefix=ix.pre1, m_cap=Hi * Wi, a_map=ix.idx1, taps=1,
+                        n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1)
+        h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
+        ops.conv_packed(h1, p["w2"], p["s2"], p["t2_tab"], h2, B=B, row_prefix=ix.pre3, m_cap=Ho * Wo, a_map=ix.nbr, taps=9,
+                        pix_map=ix.idx3, geom=geom, k_idx=idx, k_cnt=cnt, kgran=gran, n_idx=idx, n_cnt=cnt,
+                        post_sub=p["c2"], relu=1)
+        cout = p["w3"].shape[2]
+        if self.downsample is not None:
+            out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
+            ops.conv_rows(x2d, p["wd"], p["sd"], p["td"], out2d,
+                          a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev), taps=1, m_cap=ix.cap3, relu=2,
+                          relu_if_neg=ix.pos3)
+            resid = out2d
+        elif self.inplace_residual:
+            resid = out2d = x2d
+        else:
+            resid, out2d = x2d, torch.relu(x2d)
+        ops.conv_packed(h2, p["w3"], p["s3"], p["t3c"], out2d, B=B, row_prefix=ix.pre3, m_cap=Ho * Wo, taps=1,
+                        out_map=ix.idx3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual2d=resid)
+        self.last_channel_mask, self.last_spatial_mask = cmask, patch
+        return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), cmask, ix
+
     def _ds_rows(self, B, Hi, Wi, Ho, Wo, s, dev):
         key = (B, Hi, Wi, s, str(dev))
         cache = self.__dict__.setdefault("_ds_cache", {})
@@ -405,11 +448,11 @@ class Bottleneck(_PrepCache):
         consecutive channel-mode blocks (the conv3 epilogue leaves the channel sums the next masker needs).  Returns (out, stats[4] = {s3, s2, s1, channel sparsity} as a device
         tensor).  The FLOPs bookkeeping is separate (flops_terms) so a whole network can do it once, vectorised."""
         _eval_only(self, x)
-        if self.dyn_mode == "both":
-            raise LdnError("HIP path: dyn_mode='both' (channel AND spatial in one block) is not built yet "
-                           "(SURVEY 8f-2); use 'channel', 'spatial' or 'layer'")
         p = self._prep if self._prep is not None else self._prepare(x.device)
-        if self.dyn_mode == "channel":
+        if self.dyn_mode == "both":
+            out, cmask, ix = self._run_both(x, p)
+            stats = torch.cat((ix.stats, cmask.mean().reshape(1)))
+        elif self.dyn_mode == "channel":
             out, cmask = self._run_channel(x, p, gap_in, want_gap)
             stats = torch.ones(4, device=x.device)
             stats[3] = cmask.mean()

@@ -205,3 +205,31 @@ def conv_image(a_nhwc, w, scale, shift, out_nhwc, *, ksize=1, stride=1, k_idx=No
                                relu, L.ptr(residual), residual.shape[-1] if residual is not None else 0,
                                L.ptr(_f32c(out_nhwc, "out")), ldo, L.ptr(colsum), L.stream_ptr()), "ldn_conv_image")
     return out_nhwc
+
+
+# ---------------------------------------------------------------------------------------- a7 packed (+ channel lists)
+def conv_packed(a2d, w, scale, shift, out2d, *, B=1, row_prefix=None, m_count=None, m_cap=None, a_map=None, taps=1,
+                out_map=None, pix_map=None, geom=None, k_idx=None, k_cnt=None, kgran=1, n_idx=None, n_cnt=None,
+                post_sub=None, relu=1, relu_if_neg=None, residual2d=None):
+    """Convolution over packed pixel lists with optional per-image channel subsets (see ldn_conv_packed).
+    geom = (Hi, Wi, Ho, Wo, stride) is only needed with a 16-class shift table."""
+    L.require_device(a2d, w, out2d)
+    lib = L.load()
+    if k_idx is None:
+        cout, t, cin = w.shape
+    else:
+        t, cin, cout = w.shape
+    if t != taps:
+        raise L.LdnError(f"conv_packed: weight has {t} taps, expected {taps}")
+    classes = 1 if shift.dim() == 1 else shift.shape[0]
+    hi, wi, ho, wo, stride = geom if geom is not None else (0, 0, 0, 0, 1)
+    L.check(lib.ldn_conv_packed(L.ptr(_f32c(a2d, "a")), a2d.stride(0), B, L.ptr(_i32c(row_prefix, "row_prefix")),
+                                L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(_i32c(a_map, "a_map")), taps,
+                                L.ptr(_i32c(out_map, "out_map")), L.ptr(_i32c(pix_map, "pix_map")), hi, wi, ho, wo, stride,
+                                L.ptr(_f32c(w, "w")), cin, cout, L.ptr(_i32c(k_idx, "k_idx")), L.ptr(_i32c(k_cnt, "k_cnt")),
+                                kgran, L.ptr(_i32c(n_idx, "n_idx")), L.ptr(_i32c(n_cnt, "n_cnt")),
+                                L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), classes, L.ptr(post_sub), relu,
+                                L.ptr(_i32c(relu_if_neg, "relu_if_neg")), L.ptr(residual2d),
+                                residual2d.stride(0) if residual2d is not None else 0, L.ptr(_f32c(out2d, "out")),
+                                out2d.stride(0), L.stream_ptr()), "ldn_conv_packed")
+    return out2d

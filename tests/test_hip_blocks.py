@@ -14,8 +14,7 @@ TOL = 1e-3  # north_star: outputs within 1e-3 fp32 of the reference PyTorch mask
 
 BLOCKS = {**load_golden("blocks_s1.pt"), **load_golden("blocks_s2.pt")}
 FULL = load_golden("full_tiny.pt")
-BUILT = sorted(n for n in BLOCKS if BLOCKS[n]["kw"]["dyn_mode"] != "both"
-               and BLOCKS[n]["kw"]["spatial_mask_channel_group"] == 1)
+BUILT = sorted(n for n in BLOCKS if BLOCKS[n]["kw"]["spatial_mask_channel_group"] == 1)
 
 
 def _hip_block(fx):
@@ -78,7 +77,7 @@ def test_training_and_cpu_raise():
         blk.eval().cpu()(start_state(block_input(fx)), 1.0)
 
 
-FULL_BUILT = sorted(n for n in FULL if "both" not in FULL[n]["kw"]["dyn_mode"])
+FULL_BUILT = sorted(FULL)
 
 
 def _hip_model(fx):
@@ -132,3 +131,30 @@ def test_fused_gap_handoff_matches_unfused():
     assert same, "fused-GAP masks differ from the stand-alone masker's (only a numerical near-tie could explain it)"
     assert_tuple_close(fused[:1], plain[:1], atol=TOL, rtol=1e-5, what="fused vs unfused logits")
     assert_tuple_close(fused, fx["masker_run"], atol=TOL, rtol=1e-4, what="vs reference fixture")
+
+
+@pytest.mark.parametrize("mode,stride", [("channel", 1), ("both", 2)])
+def test_conv_linear_masker_block_vs_oracle(mode, stride):
+    """channel_masker='conv_linear' (the Bottleneck ctor default, models/utils.py:133-169) against the oracle block with
+    the same state_dict; masks must agree (the fixture has no near-tie) and outputs within TOL."""
+    import torch.nn as nn
+    from laudnet_amd.laud_resnet import Bottleneck
+    from oracle import torch_ref as TR
+    inpl, planes, hout = (64, 16, 14) if stride == 1 else (32, 16, 14)
+    kw = dict(inplanes=inpl, planes=planes, stride=stride, channel_dyn_granularity=2, output_size=hout,
+              mask_spatial_granularity=2, dyn_mode=mode, channel_masker="conv_linear", reduction=4)
+    mk_down = lambda: (nn.Sequential(nn.Conv2d(inpl, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+                       if stride != 1 or inpl != planes * 4 else None)
+    ref = TR.BottleneckRef(downsample=mk_down(), **kw).eval()
+    sd = fill_state_dict(ref.state_dict(), 77)
+    ref.load_state_dict(sd)
+    hip = Bottleneck(downsample=mk_down(), **kw).eval()
+    hip.load_state_dict(sd)
+    hip = hip.to(DEV)
+    x = torch.relu(seeded_randn((3, inpl, hout * stride, hout * stride), 78))
+    with torch.no_grad():
+        want = ref(start_state(x), 1.0)
+        got = hip(start_state(x.to(DEV)), 1.0)
+    assert_tuple_close(got[1:6], want[1:6], atol=1e-6, what="stats (identical masks)")
+    assert_tuple_close(got[:1], want[:1], atol=TOL, what="out")
+    assert_tuple_close(got[6:], want[6:], atol=0.0, rtol=1e-5, what="flops")

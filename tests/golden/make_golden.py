@@ -274,6 +274,120 @@ def make_full(R, name, seed=7, batch=2, width_mult=0.125, input_size=224):
     return fx
 
 
+# ----------------------------------------------------------------------------- RegNet (needs a torchvision stub)
+def load_reference_regnet():
+    """laud_regnet.py imports 4 symbols from torchvision 0.14 (laud_regnet.py:14-16); torchvision is not installed, so a
+    stub exposing exactly those is injected (SURVEY 8c shim 2).  The two containers are restated from torchvision 0.14.1."""
+    import torch.nn as nn
+
+    class ConvNormActivation(nn.Sequential):
+        def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=None, groups=1,
+                     norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU, dilation=1, inplace=True, bias=None):
+            if padding is None:
+                padding = (kernel_size - 1) // 2 * dilation
+            if bias is None:
+                bias = norm_layer is None
+            layers = [nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation=dilation, groups=groups,
+                                bias=bias)]
+            if norm_layer is not None:
+                layers.append(norm_layer(out_channels))
+            if activation_layer is not None:
+                layers.append(activation_layer(inplace=inplace))
+            super().__init__(*layers)
+            self.out_channels = out_channels
+
+    class SqueezeExcitation(nn.Module):
+        def __init__(self, input_channels, squeeze_channels, activation=nn.ReLU, scale_activation=nn.Sigmoid):
+            super().__init__()
+            self.avgpool = nn.AdaptiveAvgPool2d(1)
+            self.fc1 = nn.Conv2d(input_channels, squeeze_channels, 1)
+            self.fc2 = nn.Conv2d(squeeze_channels, input_channels, 1)
+            self.activation = activation()
+            self.scale_activation = scale_activation()
+
+        def forward(self, x):
+            s = self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x)))))
+            return s * x
+
+    def _make_divisible(v, divisor, min_value=None):
+        if min_value is None:
+            min_value = divisor
+        new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+        if new_v < 0.9 * v:
+            new_v += divisor
+        return new_v
+
+    tv = types.ModuleType("torchvision")
+    tv.__path__ = []
+    iru = types.ModuleType("torchvision._internally_replaced_utils")
+    iru.load_state_dict_from_url = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("offline"))
+    ops_pkg = types.ModuleType("torchvision.ops")
+    ops_pkg.__path__ = []
+    misc = types.ModuleType("torchvision.ops.misc")
+    misc.ConvNormActivation, misc.SqueezeExcitation = ConvNormActivation, SqueezeExcitation
+    models_pkg = types.ModuleType("torchvision.models")
+    models_pkg.__path__ = []
+    mu = types.ModuleType("torchvision.models._utils")
+    mu._make_divisible = _make_divisible
+    for name, mod in (("torchvision", tv), ("torchvision._internally_replaced_utils", iru), ("torchvision.ops", ops_pkg),
+                      ("torchvision.ops.misc", misc), ("torchvision.models", models_pkg),
+                      ("torchvision.models._utils", mu)):
+        sys.modules[name] = mod
+    spec = importlib.util.spec_from_file_location("models.laud_regnet", os.path.join(REF_ROOT, "models", "laud_regnet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["models.laud_regnet"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+REGNET_TINY = dict(depths=[1, 1, 2, 1], widths=[16, 32, 48, 64], group_widths=[8, 8, 8, 8],
+                   bottleneck_multipliers=[1.0, 1.0, 1.0, 1.0], strides=[2, 2, 2, 2], se_ratio=0.25)
+REGNET_CASES = {
+    "layerskip": dict(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[16, 8, 4, 2]),
+    "spatial_g2": dict(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[2, 2, 2, 1]),
+    "channel_g2": dict(dyn_mode=["channel"] * 4, channel_dyn_granularity=[2, 2, 2, 2], channel_masker=["MLP"] * 4,
+                       channel_masker_layers=[2, 2, 2, 2]),
+    "both": dict(dyn_mode=["both"] * 4, mask_spatial_granularity=[4, 2, 2, 1], channel_dyn_granularity=[2, 2, 2, 2],
+                 channel_masker=["MLP"] * 4, channel_masker_layers=[1, 1, 1, 1]),
+}
+
+
+def make_regnet(G):
+    out = {"params": {}, "tiny_params": dict(REGNET_TINY), "cases": {}}
+    for name, kw in (("lad_regnet_y_400mf", dict(depth=16, w_0=48, w_a=27.89, w_m=2.09, group_width=8)),
+                     ("lad_regnet_y_800mf", dict(depth=14, w_0=56, w_a=38.84, w_m=2.4, group_width=16)),
+                     ("lad_regnet_y_1_6gf", dict(depth=27, w_0=48, w_a=20.71, w_m=2.65, group_width=24)),
+                     ("lad_regnet_y_3_2gf", dict(depth=21, w_0=80, w_a=42.63, w_m=2.66, group_width=24)),
+                     ("lad_regnet_y_8gf", dict(depth=17, w_0=192, w_a=76.82, w_m=2.19, group_width=56)),
+                     ("lad_regnet_y_16gf", dict(depth=18, w_0=200, w_a=106.23, w_m=2.48, group_width=112))):
+        bp = G.BlockParams.from_init_params(se_ratio=0.25, **kw)
+        out["params"][name] = dict(depths=bp.depths, widths=bp.widths, group_widths=bp.group_widths,
+                                   bottleneck_multipliers=bp.bottleneck_multipliers, strides=bp.strides)
+    seed, batch, size = 9, 2, 64
+    for cname, kw in REGNET_CASES.items():
+        bp = G.BlockParams(**REGNET_TINY)
+        model = quiet(G.LAD_RegNet, bp, num_classes=10, stem_width=8, input_size=size, **kw).eval()
+        model.load_state_dict(fill_state_dict(model.state_dict(), seed))
+        x = seeded_randn((batch, 3, size, size), seed + 100)
+        fx = dict(kw=dict(kw, num_classes=10, stem_width=8, input_size=size), seed=seed, x_seed=seed + 100, batch=batch,
+                  keys=list(model.state_dict().keys()), n_params=sum(p.numel() for p in model.parameters()))
+        with torch.no_grad():
+            fx["masker_run"] = to_cpu(model(x, 1.0))
+            blocks = [(n, m.f) for n, m in model.named_modules() if isinstance(m, G.ResBottleneckBlock)]
+            masks = injected_masks_for(blocks, batch, seed=2000 + seed)
+            for bname, f in blocks:
+                if "spatial" in masks[bname]:
+                    if cname == "layerskip":   # one bit per image
+                        masks[bname]["spatial"] = masks[bname]["spatial"][:, :, :1, :1].contiguous()
+                    inject(f.masker_spatial, masks[bname]["spatial"])
+                if "channel" in masks[bname]:
+                    inject(f.masker_channel, masks[bname]["channel"])
+            fx["mask_seed"] = 2000 + seed
+            fx["injected_run"] = to_cpu(model(x, 1.0))
+        out["cases"][cname] = fx
+    return out
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -288,7 +402,8 @@ def main():
         torch.save(blocks, os.path.join(HERE, f"blocks_s{stride}.pt"))
     full = {name: make_full(R, name) for name in FULL_CASES}
     torch.save(full, os.path.join(HERE, "full_tiny.pt"))
-    for f in ("l1_ops.pt", "blocks_s1.pt", "blocks_s2.pt", "full_tiny.pt"):
+    torch.save(make_regnet(load_reference_regnet()), os.path.join(HERE, "regnet_tiny.pt"))
+    for f in ("l1_ops.pt", "blocks_s1.pt", "blocks_s2.pt", "full_tiny.pt", "regnet_tiny.pt"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

@@ -168,3 +168,49 @@ def test_full_models_injected(name):
     with torch.no_grad():
         got = model(x, 1.0)
     assert_tuple_close(got, fx["injected_run"], atol=2e-4, rtol=1e-5, what=name)
+
+
+# ------------------------------------------------------------------ LAD-RegNet (torchvision containers restated)
+REGNET = load_golden("regnet_tiny.pt")
+
+
+def test_regnet_block_params_match_reference():
+    from oracle import regnet_ref as RR
+    for name, want in REGNET["params"].items():
+        got = RR.regnet_block_params(**RR.REGNET_Y[name])
+        assert got == want, name
+    p800 = RR.regnet_block_params(**RR.REGNET_Y["lad_regnet_y_800mf"])
+    assert p800["widths"] == [64, 144, 320, 784] and p800["depths"] == [1, 3, 8, 2]
+
+
+def _build_regnet(fx):
+    from oracle import regnet_ref as RR
+    model = RR.RegNetRef(REGNET["tiny_params"] | {}, se_ratio=REGNET["tiny_params"]["se_ratio"], **fx["kw"]).eval()
+    assert list(model.state_dict().keys()) == fx["keys"], "state_dict keys must equal the reference's"
+    assert sum(p.numel() for p in model.parameters()) == fx["n_params"]
+    model.load_state_dict(fill_state_dict(model.state_dict(), fx["seed"]))
+    size = fx["kw"]["input_size"]
+    return model, seeded_randn((fx["batch"], 3, size, size), fx["x_seed"])
+
+
+@pytest.mark.parametrize("name", sorted(REGNET["cases"]))
+def test_regnet_masker_run(name):
+    fx = REGNET["cases"][name]
+    model, x = _build_regnet(fx)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got, fx["masker_run"], atol=2e-5, rtol=1e-5, what=name)
+
+
+@pytest.mark.parametrize("name", sorted(REGNET["cases"]))
+def test_regnet_injected_run(name):
+    fx = REGNET["cases"][name]
+    model, x = _build_regnet(fx)
+    blocks = [(n, b.f) for n, b in model.blocks()]
+    masks = injected_masks_for(blocks, fx["batch"], fx["mask_seed"])
+    for bname, f in blocks:
+        f.forced_spatial_mask = masks[bname].get("spatial")
+        f.forced_channel_mask = masks[bname].get("channel")
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got, fx["injected_run"], atol=2e-5, rtol=1e-5, what=name)

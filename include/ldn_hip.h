@@ -142,6 +142,18 @@ int ldn_conv_packed(const float* a, int lda, int B, const int32_t* row_prefix, c
                     const float* shift, int shift_classes, const float* post_sub, int relu,
                     const int32_t* relu_if_neg, const float* residual, int ldr, float* out, int ldo, void* stream);
 
+/* ---- a9: LAD-RegNet BottleneckTransform (laud_regnet.py:157-217), layer-skip execution ------------------------
+ * b: grouped 3x3 conv (+BN+ReLU) over packed rows: out[r,c] = act(scale[c]*sum_{t<9} sum_{i<gw}
+ *    a[nbr[r*9+t], (c/gw)*gw + i] * w[c,t,i] + shift[c]); nbr as produced by ldn_mask_to_index; w is [C][9][gw]. */
+int ldn_grouped_conv3x3_rows(const float* a, int lda, const int32_t* nbr, const int32_t* m_count, int m_cap,
+                             const float* w, int C, int group_width, const float* scale, const float* shift, int relu,
+                             float* out, int ldo, void* stream);
+/* se: torchvision SqueezeExcitation (laud_regnet.py:119-123,194) applied IN PLACE to the packed rows of every kept
+ *    image: gate[b,:] = sigmoid(W2 relu(W1 mean_rows(a_b) + b1) + b2), a[r,:] *= gate[image(r),:].
+ *    w1 [S][C], w2 [C][S].  work: B*(ldn_channel_masker_splits(max_rows_per_image)+1)*C floats. */
+int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B, int C, int S, const float* w1, const float* b1,
+                  const float* w2, const float* b2, int max_rows_per_image, float* work, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

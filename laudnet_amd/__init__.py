@@ -8,4 +8,7 @@ from ._lib import LdnError, load as load_library  # noqa: F401
 from .laud_resnet import (Bottleneck, ExpandMask, Masker_channel_conv_linear, Masker_channel_MLP,  # noqa: F401
                           Masker_spatial, ResNet, uni_resnet50, uni_resnet101)
 
+from .laud_regnet import (LAD_RegNet, BlockParams, lad_regnet_y_400mf, lad_regnet_y_800mf,  # noqa: F401
+                          lad_regnet_y_1_6gf, lad_regnet_y_3_2gf, lad_regnet_y_8gf, lad_regnet_y_16gf)
+
 __version__ = "0.1.0"

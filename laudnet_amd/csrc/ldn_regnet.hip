@@ -1,0 +1,162 @@
+// LAD-RegNet-specific kernels of the hot path (gfx950): grouped 3x3 convolution over packed pixel lists and the
+// squeeze-excitation of a packed (layer-skip) batch.  All are HBM-bound VALU kernels: a RegNet-Y grouped conv has
+// 9*gw MACs per output element (gw = 8..24), far below the fp32 ridge, so no MFMA here.
+#include "ldn_common.h"
+
+namespace ldn {
+
+// out[r, c] = act(scale[c] * sum_{t<9} sum_{i<gw} a[nbr[r,t], g*gw + i] * w[c, t, i] + shift[c]),  g = c / gw
+// one thread per (row, 4 consecutive output channels); the 4 channels share the group's activation loads.
+template <int GW4>   // gw / 4 (2, 4 or 6): compile-time inner extent; 0 = run-time loop
+__global__ __launch_bounds__(256) void k_grouped3x3_rows(const float* __restrict__ a, int lda,
+                                                          const int32_t* __restrict__ nbr,
+                                                          const int32_t* __restrict__ m_count, int m_cap,
+                                                          const float* __restrict__ w, int C, int gw,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          int relu, float* __restrict__ out, int ldo) {
+    const int M = m_count ? min(m_count[0], m_cap) : m_cap;
+    const int C4 = C >> 2;
+    const long total = (long)M * C4;
+    const int g4 = GW4 ? GW4 : (gw >> 2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / C4), c = (int)(i - (long)r * C4) * 4;
+        const int g0 = (c / gw) * gw;   // first input channel of this output channel's group (c..c+3 share it: gw % 4 == 0)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ar = nbr[(size_t)r * 9 + t];
+            if (ar < 0) continue;
+            const float* ap = a + (size_t)ar * lda + g0;
+            const float* wp = w + ((size_t)c * 9 + t) * gw;
+            const int qn = GW4 ? GW4 : g4;
+#pragma unroll
+            for (int q = 0; q < qn; ++q) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ap + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)e * 9 * gw + q * 4);
+                    acc[e] += av[0] * wv[0] + av[1] * wv[1] + av[2] * wv[2] + av[3] * wv[3];
+                }
+            }
+        }
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 v = acc * sc + sh;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)r * ldo + c) = v;
+    }
+}
+
+// per-image channel sums over the image's packed rows [prefix[b], prefix[b+1]); grid (splits, B), deterministic
+__global__ __launch_bounds__(256) void k_rows_gap(const float* __restrict__ a, int lda, const int32_t* __restrict__ prefix,
+                                                   int C, int splits, float* __restrict__ partial) {
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int r0 = prefix[b], n = prefix[b + 1] - r0;
+    const int per = ceil_div(max(n, 1), splits);
+    const int lo = r0 + s * per, hi = min(r0 + n, lo + per);
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int r = lo; r < hi; ++r) acc += *reinterpret_cast<const f32x4*>(a + (size_t)r * lda + c);
+        *reinterpret_cast<f32x4*>(partial + ((size_t)b * splits + s) * C + c) = acc;
+    }
+}
+
+// squeeze-excitation head per image: mean -> fc1 + ReLU -> fc2 -> sigmoid  (torchvision SqueezeExcitation)
+__global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ partial, const int32_t* __restrict__ prefix,
+                                                  int C, int S, int splits, const float* __restrict__ w1,
+                                                  const float* __restrict__ b1, const float* __restrict__ w2,
+                                                  const float* __restrict__ b2, float* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(16))) float s_f[];
+    float* s_mean = s_f;        // [C]
+    float* s_hid = s_f + C;     // [S]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = prefix[b + 1] - prefix[b];
+    if (n == 0) return;         // skipped image: its gate is never read
+    const float inv = 1.f / (float)n;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
+        s_mean[c] = s * inv;
+    }
+    __syncthreads();
+    for (int o = wave; o < S; o += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += w1[(size_t)o * C + c] * s_mean[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) s_hid[o] = fmaxf(acc + b1[o], 0.f);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc = b2[c];
+        for (int j = 0; j < S; ++j) acc += w2[(size_t)c * S + j] * s_hid[j];
+        gate[(size_t)b * C + c] = 1.f / (1.f + __expf(-acc));
+    }
+}
+
+// a[r, :] *= gate[image(r), :] for the packed rows of every image; grid (chunks, B)
+__global__ __launch_bounds__(256) void k_rows_scale(float* __restrict__ a, int lda, const int32_t* __restrict__ prefix,
+                                                     int C, const float* __restrict__ gate) {
+    const int b = blockIdx.y;
+    const int r0 = prefix[b], n = prefix[b + 1] - r0;
+    const int C4 = C >> 2;
+    const long total = (long)n * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / C4), c = (int)(i - (long)r * C4) * 4;
+        f32x4* p = reinterpret_cast<f32x4*>(a + (size_t)(r0 + r) * lda + c);
+        *p = *p * *reinterpret_cast<const f32x4*>(gate + (size_t)b * C + c);
+    }
+}
+
+}  // namespace ldn
+
+using namespace ldn;
+
+extern "C" int ldn_grouped_conv3x3_rows(const float* a, int lda, const int32_t* nbr, const int32_t* m_count, int m_cap,
+                                        const float* w, int C, int group_width, const float* scale, const float* shift,
+                                        int relu, float* out, int ldo, void* stream) {
+    LDN_REQUIRE(a && nbr && w && scale && shift && out, "ldn_grouped_conv3x3_rows: null pointer");
+    LDN_REQUIRE(C > 0 && group_width > 0 && C % group_width == 0 && group_width % 4 == 0,
+                "ldn_grouped_conv3x3_rows: channels must be a multiple of the group width, group width a multiple of 4");
+    LDN_REQUIRE(lda % 4 == 0 && ldo % 4 == 0 && lda >= C && ldo >= C, "ldn_grouped_conv3x3_rows: strides must be multiples of 4");
+    if (m_cap <= 0) return LDN_OK;
+    long blocks = ((long)m_cap * (C / 4) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define LDN_LAUNCH_G(G4)                                                                                              \
+    hipLaunchKernelGGL(k_grouped3x3_rows<G4>, dim3((unsigned)blocks), dim3(256), 0, st, a, lda, nbr, m_count, m_cap, w, C, \
+                       group_width, scale, shift, relu, out, ldo)
+    switch (group_width) {
+        case 8: LDN_LAUNCH_G(2); break;
+        case 16: LDN_LAUNCH_G(4); break;
+        case 24: LDN_LAUNCH_G(6); break;
+        default: LDN_LAUNCH_G(0); break;
+    }
+#undef LDN_LAUNCH_G
+    LDN_CHECK_LAUNCH("k_grouped3x3_rows");
+    return LDN_OK;
+}
+
+extern "C" int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B, int C, int S, const float* w1,
+                             const float* b1, const float* w2, const float* b2, int max_rows_per_image, float* work,
+                             void* stream) {
+    LDN_REQUIRE(a && row_prefix && w1 && b1 && w2 && b2 && work, "ldn_se_packed: null pointer");
+    LDN_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && S > 0 && lda % 4 == 0, "ldn_se_packed: bad shape");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int splits = ldn_channel_masker_splits(max_rows_per_image);
+    float* partial = work;                           // [B][splits][C]
+    float* gate = work + (size_t)B * splits * C;     // [B][C]
+    hipLaunchKernelGGL(k_rows_gap, dim3(splits, B), dim3(256), 0, st, a, lda, row_prefix, C, splits, partial);
+    LDN_CHECK_LAUNCH("k_rows_gap");
+    hipLaunchKernelGGL(k_se_head, dim3(B), dim3(256), (size_t)(C + S) * sizeof(float), st, partial, row_prefix, C, S, splits,
+                       w1, b1, w2, b2, gate);
+    LDN_CHECK_LAUNCH("k_se_head");
+    int chunks = (max_rows_per_image * (C / 4) + 255) / 256;
+    if (chunks > 64) chunks = 64;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(k_rows_scale, dim3(chunks, B), dim3(256), 0, st, a, lda, row_prefix, C, gate);
+    LDN_CHECK_LAUNCH("k_rows_scale");
+    return LDN_OK;
+}

@@ -233,3 +233,32 @@ def conv_packed(a2d, w, scale, shift, out2d, *, B=1, row_prefix=None, m_count=No
                                 residual2d.stride(0) if residual2d is not None else 0, L.ptr(_f32c(out2d, "out")),
                                 out2d.stride(0), L.stream_ptr()), "ldn_conv_packed")
     return out2d
+
+
+# ---------------------------------------------------------------------------------------- a9 (LAD-RegNet, layer skip)
+def grouped_conv3x3_rows(a2d, nbr, w, group_width, scale, shift, out2d, *, m_count=None, m_cap=None, relu=1):
+    """Grouped 3x3 conv + BN (+ReLU) over packed rows (see ldn_grouped_conv3x3_rows).  w [C,9,gw]."""
+    L.require_device(a2d, nbr, w, out2d)
+    lib = L.load()
+    C = w.shape[0]
+    m_cap = out2d.shape[0] if m_cap is None else m_cap
+    L.check(lib.ldn_grouped_conv3x3_rows(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(nbr, "nbr")),
+                                         L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(_f32c(w, "w")), C, group_width,
+                                         L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,
+                                         L.ptr(_f32c(out2d, "out")), out2d.stride(0), L.stream_ptr()),
+            "ldn_grouped_conv3x3_rows")
+    return out2d
+
+
+def se_packed(a2d, row_prefix, w1, b1, w2, b2, max_rows_per_image):
+    """In-place squeeze-excitation over the packed rows of every kept image (see ldn_se_packed)."""
+    L.require_device(a2d, row_prefix)
+    lib = L.load()
+    B = row_prefix.numel() - 1
+    S, C = w1.shape
+    splits = lib.ldn_channel_masker_splits(max_rows_per_image)
+    work = torch.empty(B * (splits + 1) * C, device=a2d.device, dtype=torch.float32)
+    L.check(lib.ldn_se_packed(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(row_prefix, "row_prefix")), B, C, S,
+                              L.ptr(_f32c(w1, "w1")), L.ptr(_f32c(b1, "b1")), L.ptr(_f32c(w2, "w2")), L.ptr(_f32c(b2, "b2")),
+                              max_rows_per_image, L.ptr(work), L.stream_ptr()), "ldn_se_packed")
+    return a2d

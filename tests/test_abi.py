@@ -70,3 +70,17 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_regnet_state_dict_surface_matches_reference():
+    import laudnet_amd
+    fxs = load_golden("regnet_tiny.pt")
+    bp = laudnet_amd.BlockParams(**fxs["tiny_params"])
+    for name, fx in fxs["cases"].items():
+        model = laudnet_amd.LAD_RegNet(bp, **fx["kw"])
+        assert list(model.state_dict().keys()) == fx["keys"], name
+        assert sum(p.numel() for p in model.parameters()) == fx["n_params"]
+    for name, want in fxs["params"].items():
+        import laudnet_amd.laud_regnet as R
+        got = R.BlockParams.from_init_params(se_ratio=0.25, **R._Y[name.replace("lad_regnet_y_", "")])
+        assert (got.depths, got.widths, got.group_widths) == (want["depths"], want["widths"], want["group_widths"]), name

@@ -158,3 +158,46 @@ def test_conv_linear_masker_block_vs_oracle(mode, stride):
     assert_tuple_close(got[1:6], want[1:6], atol=1e-6, what="stats (identical masks)")
     assert_tuple_close(got[:1], want[:1], atol=TOL, what="out")
     assert_tuple_close(got[6:], want[6:], atol=0.0, rtol=1e-5, what="flops")
+
+
+# ------------------------------------------------------------------ LAD-RegNet, layer skip (BASELINE config 4)
+REGNET = load_golden("regnet_tiny.pt")
+
+
+def _hip_regnet(fx):
+    import laudnet_amd
+    model = laudnet_amd.LAD_RegNet(laudnet_amd.BlockParams(**REGNET["tiny_params"]), **fx["kw"]).eval()
+    assert list(model.state_dict().keys()) == fx["keys"]
+    model.load_state_dict(fill_state_dict(model.state_dict(), fx["seed"]))
+    size = fx["kw"]["input_size"]
+    return model.to(DEV), seeded_randn((fx["batch"], 3, size, size), fx["x_seed"]).to(DEV)
+
+
+def test_regnet_layerskip_injected():
+    from fill import seeded_bernoulli
+    fx = REGNET["cases"]["layerskip"]
+    model, x = _hip_regnet(fx)
+    for i, blk in enumerate(model.blocks()):
+        blk.f.forced_spatial_mask = seeded_bernoulli((fx["batch"], 1, 1, 1), 0.5, fx["mask_seed"] + 2 * i)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=TOL, rtol=1e-5, what="regnet logits")
+    assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what="regnet stats")
+    assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what="regnet flops")
+
+
+def test_regnet_layerskip_own_maskers():
+    fx = REGNET["cases"]["layerskip"]
+    model, x = _hip_regnet(fx)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got[1:6], fx["masker_run"][1:6], atol=1e-6, what="regnet stats (same skip decisions)")
+    assert_tuple_close(got[:1], fx["masker_run"][:1], atol=TOL, rtol=1e-5, what="regnet logits")
+
+
+def test_regnet_other_modes_raise():
+    from laudnet_amd import LdnError
+    fx = REGNET["cases"]["channel_g2"]
+    model, x = _hip_regnet(fx)
+    with pytest.raises(LdnError):
+        model(x, 1.0)

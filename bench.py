@@ -45,13 +45,21 @@ WORKLOADS = {
                     kw=dict(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[4, 4, 2, 1]), p_channel=None, p_spatial=0.5),
     "layer": dict(name="LAUD-ResNet101 layer-skip target-0.5 @224",
                   kw=dict(dyn_mode=["layer"] * 4), p_channel=None, p_spatial=0.5),
+    # BASELINE config 4: the reference rejects dyn_mode='layer' for RegNet; layer skip = spatial with one patch per image
+    "regnet": dict(name="LAUD-RegNetY-800MF layer-skip target-0.5 @224", arch="lad_regnet_y_800mf",
+                   kw=dict(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[56, 28, 14, 7]), p_channel=None, p_spatial=0.5),
 }
 
 
 def blocks_of(model):
-    for s in (1, 2, 3, 4):
-        for blk in getattr(model, f"layer{s}"):
-            yield blk
+    """(module holding the maskers / forced masks, callable block) pairs in execution order"""
+    if hasattr(model, "trunk_output"):          # LAD-RegNet: maskers live in block.f
+        for blk in model.blocks():
+            yield blk.f, blk
+    else:
+        for s in (1, 2, 3, 4):
+            for blk in getattr(model, f"layer{s}"):
+                yield blk, blk
 
 
 def calibrate_maskers(model, x, p_channel, p_spatial):
@@ -60,9 +68,9 @@ def calibrate_maskers(model, x, p_channel, p_spatial):
     import torch.nn.functional as F
     with torch.no_grad():
         h = x.contiguous(memory_format=torch.channels_last)
-        h = model.maxpool(model.relu(model.bn1(model.conv1(h))))
+        h = model.stem(h) if hasattr(model, "stem") else model.maxpool(model.relu(model.bn1(model.conv1(h))))
         state = (h, None, None, None, None, None, torch.tensor(0.0, device=x.device))
-        for blk in blocks_of(model):
+        for blk, runner in blocks_of(model):
             if blk.masker_channel is not None and p_channel is not None:
                 mk = blk.masker_channel
                 G = mk.channel_dyn_group
@@ -80,7 +88,7 @@ def calibrate_maskers(model, x, p_channel, p_spatial):
                 shift = -torch.quantile(diff.cpu(), 1.0 - p_spatial).item()
                 ms.conv.bias.data[:g] += shift
                 ms._drop_cache()
-            state = blk(state, 1.0)
+            state = runner(state, 1.0)
 
 
 class KernelTimer:
@@ -147,7 +155,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     kw = dict(wl["kw"], num_classes=1000, input_size=224)
-    model = laudnet_amd.uni_resnet101(**kw).eval()
+    model = getattr(laudnet_amd, wl.get("arch", "uni_resnet101"))(**kw).eval()
     sd = fill_state_dict(model.state_dict(), 1)
     for k in sd:   # damp the residual branches (as zero_init_residual would) so 33 seeded-random blocks keep O(1) activations
         if k.endswith("bn3.weight"):
@@ -196,7 +204,7 @@ def main():
     flops_perc = out[5].float().mean().item()
     flops_per_img = out[6].item()
     result = {
-        "metric": "images/sec, LAUD-ResNet101 @224 bs256 (dynamic-inference hot path)",
+        "metric": "images/sec, " + wl["name"].split(" ")[0] + " @224 bs256 (dynamic-inference hot path)",
         "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded randn images, seeded random weights, randomised BN stats)",
@@ -221,13 +229,17 @@ def main():
 
     if rank == 0 and world == 1:
         from oracle import torch_ref as TR
-        ref = TR.resnet101_ref(**kw).eval()
+        if "arch" in wl:
+            from oracle import regnet_ref as RR
+            ref = RR.regnet_y_ref(wl["arch"], **kw).eval()
+        else:
+            ref = TR.resnet101_ref(**kw).eval()
         ref.load_state_dict(calibrated_sd)
         if not args.no_dense:
             try:
                 refg = ref.to(dev).to(memory_format=torch.channels_last)
                 # parity on identical inputs AND masks: replay the masks the HIP maskers produced in the last step
-                for hb, rb in zip(blocks_of(model), (b for _, b in refg.blocks())):
+                for (hb, _), rb in zip(blocks_of(model), ((b.f if hasattr(b, "f") else b) for _, b in refg.blocks())):
                     cm, sm = getattr(hb, "last_channel_mask", None), getattr(hb, "last_spatial_mask", None)
                     rb.forced_channel_mask = None if cm is None else cm.clone()
                     rb.forced_spatial_mask = None if sm is None else sm.clone()
@@ -253,7 +265,7 @@ def main():
         if not args.no_cpu:
             cores = min(os.cpu_count() or 1, 32)   # torch CPU convs stop scaling (and thrash) far below 256 threads
             torch.set_num_threads(cores)
-            for rb in (b for _, b in ref.blocks()):
+            for rb in ((b.f if hasattr(b, "f") else b) for _, b in ref.blocks()):
                 rb.forced_channel_mask = rb.forced_spatial_mask = None
             xc = x[: args.cpu_batch].cpu().contiguous()
             ref = ref.cpu()

@@ -49,6 +49,52 @@ __global__ __launch_bounds__(256) void k_grouped3x3_rows(const float* __restrict
     }
 }
 
+// v2: one block = one channel group x a run of packed rows; the group's [gw][9][gw] weights sit in LDS (all lanes of a
+// channel quad read the same address: broadcast), each thread produces 4 output channels of one row.
+template <int GW>
+__global__ __launch_bounds__(256) void k_grouped3x3_lds(const float* __restrict__ a, int lda,
+                                                         const int32_t* __restrict__ nbr,
+                                                         const int32_t* __restrict__ m_count, int m_cap,
+                                                         const float* __restrict__ w, int C,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int relu, float* __restrict__ out, int ldo) {
+    constexpr int QUADS = GW / 4, ROWS = 256 / QUADS;
+    __shared__ __attribute__((aligned(16))) float s_w[GW * 9 * GW];
+    const int g = blockIdx.y, tid = threadIdx.x;
+    const int M = m_count ? min(m_count[0], m_cap) : m_cap;
+    for (int i = tid * 4; i < GW * 9 * GW; i += 1024)
+        *reinterpret_cast<f32x4*>(s_w + i) = *reinterpret_cast<const f32x4*>(w + (size_t)g * GW * 9 * GW + i);
+    __syncthreads();
+    const int q = tid % QUADS, rl = tid / QUADS;
+    if (rl >= ROWS) return;
+    const int c = g * GW + q * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    for (int row = blockIdx.x * ROWS + rl; row < M; row += gridDim.x * ROWS) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ar = nbr[(size_t)row * 9 + t];
+            if (ar < 0) continue;
+            const float* ap = a + (size_t)ar * lda + g * GW;
+#pragma unroll
+            for (int qi = 0; qi < QUADS; ++qi) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ap + qi * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(s_w + ((q * 4 + e) * 9 + t) * GW + qi * 4);
+                    acc[e] += av[0] * wv[0] + av[1] * wv[1] + av[2] * wv[2] + av[3] * wv[3];
+                }
+            }
+        }
+        f32x4 v = acc * sc + sh;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)row * ldo + c) = v;
+    }
+}
+
 // per-image channel sums over the image's packed rows [prefix[b], prefix[b+1]); grid (splits, B), deterministic
 __global__ __launch_bounds__(256) void k_rows_gap(const float* __restrict__ a, int lda, const int32_t* __restrict__ prefix,
                                                    int C, int splits, float* __restrict__ partial) {
@@ -128,12 +174,22 @@ extern "C" int ldn_grouped_conv3x3_rows(const float* a, int lda, const int32_t* 
 #define LDN_LAUNCH_G(G4)                                                                                              \
     hipLaunchKernelGGL(k_grouped3x3_rows<G4>, dim3((unsigned)blocks), dim3(256), 0, st, a, lda, nbr, m_count, m_cap, w, C, \
                        group_width, scale, shift, relu, out, ldo)
+#define LDN_LAUNCH_L(GW)                                                                                              \
+    {                                                                                                                 \
+        constexpr int rows_per_block = 256 / (GW / 4);                                                               \
+        long bx = (m_cap + rows_per_block - 1) / rows_per_block;                                                      \
+        const long cap = (256L * 16) / (C / GW) + 1;                                                                  \
+        if (bx > cap) bx = cap;                                                                                       \
+        hipLaunchKernelGGL(k_grouped3x3_lds<GW>, dim3((unsigned)bx, C / GW), dim3(256), 0, st, a, lda, nbr, m_count,   \
+                           m_cap, w, C, scale, shift, relu, out, ldo);                                                \
+    }
     switch (group_width) {
-        case 8: LDN_LAUNCH_G(2); break;
-        case 16: LDN_LAUNCH_G(4); break;
-        case 24: LDN_LAUNCH_G(6); break;
+        case 8: LDN_LAUNCH_L(8); break;
+        case 16: LDN_LAUNCH_L(16); break;
+        case 24: LDN_LAUNCH_L(24); break;
         default: LDN_LAUNCH_G(0); break;
     }
+#undef LDN_LAUNCH_L
 #undef LDN_LAUNCH_G
     LDN_CHECK_LAUNCH("k_grouped3x3_rows");
     return LDN_OK;

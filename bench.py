@@ -280,6 +280,17 @@ def main():
             result["cpu_baseline"] = {"value": args.cpu_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
                                       "sample": f"{reps} forward passes of batch {args.cpu_batch} (same model/weights/inputs), "
                                                 f"oracle dense emulation in torch fp32 on {cores} threads"}
+    # second half of the BASELINE metric: the reference's analytic predictor with MI355X parameters (tools/predict_speedup.py,
+    # generated in the build container by importing the reference's DyNetSimulator; committed under profiles/)
+    pj = os.path.join(ROOT, "profiles", "predicted_speedup_mi355x.json")
+    if os.path.exists(pj):
+        key = {"channel": "channel-2222", "spatial": "spatial S=4-4-2-1", "layer": "ResNet101 layer skip", "regnet": "RegNetY-800MF"}[args.workload]
+        rows = [r for r in json.load(open(pj))["rows"] if key in r["workload"] and r["mem_bandwidth"].startswith("8.0")]
+        if rows:
+            result["predicted_speedup"] = {"value": rows[0]["predicted_speedup"], "source": "reference DyNetSimulator, MI355X parameters "
+                                           "(256 CUs x 128 fp32 lanes, 2.4 GHz, 8 TB/s), bs256; uncalibrated NVIDIA-fitted knobs"}
+            if "realised_speedup_vs_dense_emulation" in result:
+                result["realised_over_predicted"] = result["realised_speedup_vs_dense_emulation"] / rows[0]["predicted_speedup"]
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

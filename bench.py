@@ -35,6 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense bf16 matrix peak
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -139,6 +140,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (same kernels, no launch gaps)")
+    ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
+                    help="arithmetic of the MFMA convolutions (include/ldn_hip.h: ldn_set_math_mode); fp32 storage either way")
     args = ap.parse_args()
 
     import laudnet_amd
@@ -152,6 +155,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     laudnet_amd.load_library()   # fail loudly if the HIP extension is missing
+    ops.set_math_mode(args.math)
 
     wl = WORKLOADS[args.workload]
     kw = dict(wl["kw"], num_classes=1000, input_size=224)
@@ -207,7 +211,8 @@ def main():
         "metric": "images/sec, " + wl["name"].split(" ")[0] + " @224 bs256 (dynamic-inference hot path)",
         "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded randn images, seeded random weights, randomised BN stats)",
+        "dtype": "f32" if args.math == "fp32" else "bf16x3 (fp32 tensors; each fp32 product = 3 bf16 MFMA products of hi/lo splits, fp32 accumulate)",
+        "data": "synthetic (seeded randn images, seeded random weights, randomised BN stats)",
         "config": {"workload": wl["name"] + f" bs{args.batch}/GPU, masks produced by the maskers in the timed region",
                    "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                    "parallelism": f"dp{world} (batch shards, all-gather logits + all-reduce stats over RCCL)",
@@ -222,11 +227,32 @@ def main():
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if args.workload == "channel" and args.batch == 256 and os.path.exists(tj):
             traffic = json.load(open(tj))["traffic_bytes_per_launch"]
-        result["roofline"] = {"kernel": "k_conv_image (3x3 per-image channel-subset conv, fp32 MFMA)", "bound": "mfma",
-                              "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": n,
-                              "avg_launch_us": 1e3 * ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9}
+        if args.math == "fp32":
+            kernel, peak, extra = "k_conv_image (3x3 per-image channel-subset conv, fp32 MFMA)", F32_MFMA_PEAK_TFLOPS, {}
+        else:   # three bf16 MFMAs are executed per algorithmic product: the matrix pipe sees 3x the algorithmic FLOPs
+            kernel, peak = "k_conv_bf3 (3x3 per-image channel-subset conv, bf16x3 split-precision MFMA)", BF16_MFMA_PEAK_TFLOPS
+            extra = {"executed_mfma_tflops": 3 * achieved, "frac_executed": 3 * achieved / peak,
+                     "frac_of_fp32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS}
+        result["roofline"] = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                              "frac": achieved / peak, "traffic": traffic, "launches": n,
+                              "avg_launch_us": 1e3 * ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9, **extra}
 
+    if rank == 0 and world == 1 and args.math != "fp32":
+        # the same workload with fp32 operands on v_mfma_f32_32x32x2_f32 (reported beside the headline, not as `value`)
+        ops.set_math_mode("fp32")
+        for _ in range(2):
+            out32 = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out32 = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        same = all(torch.equal(a, b) for a, b in zip(out[1:5], out32[1:5]))
+        result["fp32_mfma_mode"] = {"value": args.batch / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt,
+                                    "max_abs_logit_diff_vs_headline_mode": (out[0] - out32[0]).abs().max().item(),
+                                    "same_masker_decisions": bool(same)}
+        ops.set_math_mode(args.math)
     if rank == 0 and world == 1:
         from oracle import torch_ref as TR
         if "arch" in wl:

@@ -33,6 +33,16 @@ const char* ldn_last_error(void);
 int ldn_version(void);
 /* number of compute units of the current device (used by callers to size persistent grids) */
 int ldn_device_cus(int* cus);
+/* Arithmetic of the MFMA convolutions (ldn_conv_image / ldn_conv_packed / ldn_conv_rows), process-wide:
+ *   0 = fp32 operands on v_mfma_f32_32x32x2_f32 (fp32 multiply, fp32 accumulate);
+ *   1 = "bf16x3" split precision: each fp32 operand x is split in registers into bf16 hi + bf16 lo
+ *       (round-to-nearest-even both), the product is hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_bf16 with
+ *       fp32 accumulation; per-product relative error <= ~2^-16 (measured: 5e-6 relative on a K=2304 conv),
+ *       inside the north star's 1e-3 fp32 parity tolerance.  Storage stays fp32 everywhere.
+ * The initial value is taken from the environment variable LDN_MATH_MODE (default 0).  The reference has no
+ * counterpart (cuDNN chooses its own algorithms, TF32 included, behind torch.backends.cudnn.allow_tf32). */
+int ldn_set_math_mode(int mode);
+int ldn_get_math_mode(void);
 
 /* ---- a1: Masker_spatial.forward, eval branch (models/utils.py:47-65) ------------------------
  * x [B,Hi,Wi,C] NHWC -> adaptive average pool to SxS (only if S < Hi, utils.py:48; bins

@@ -18,6 +18,8 @@ SIGNATURES = {
     "ldn_last_error": ([], C.c_char_p),
     "ldn_version": ([], _I),
     "ldn_device_cus": ([C.POINTER(_I)], _I),
+    "ldn_set_math_mode": ([_I], _I),
+    "ldn_get_math_mode": ([], _I),
     "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P], _I),
     "ldn_mask_to_index": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "ldn_gather_rows": ([_P, _I, _P, _P, _I, _I, _P, _I, _P], _I),

@@ -31,7 +31,7 @@
 #include "ldn_common.h"
 
 #ifndef LDN_ABLATE
-#define LDN_ABLATE 0   // tuning only: 1 = no MFMA, 2 = no loads in the K loop (results are wrong)
+#define LDN_ABLATE 0   // tuning only: 1 = no MFMA, 2 = no A loads in the K loop, 4 = no weight loads, 8 = no weight split/store (results are wrong)
 #endif
 
 namespace ldn {
@@ -87,29 +87,19 @@ __device__ __forceinline__ void block_sync() {
     asm volatile("" ::: "memory");
 }
 
-// MS x NS = m-subtiles x n-subtiles of 32 per block (two LDS buffers of (MS+NS)*4 KiB).
-// BMODE= weight layout / staging path:
-//        B_NK  : w[cout][taps][cin] ("n-major"), no K gather.  Tile rows = output channels (gathered through
-//                n_idx for free: a row is a pointer), 128 contiguous bytes of K per row            -> LDS-DMA
-//        B_KN4 : w[taps][cin][cout] ("k-major"), used whenever the INPUT channels are gathered (k_idx): tile
-//                rows = the chunk's 32 packed k positions (row gather, free), columns = output channels,
-//                contiguous or gathered in aligned runs of >= 4                                    -> LDS-DMA
-//        B_KN2 / B_KN1 : same layout, output channels gathered in aligned pairs / singly           -> VGPRs
-//        (k-major keeps every weight fetch inside one or a few 128-byte lines of a single row; the n-major
-//         layout with a K gather touched ~2.6x more lines than it used)
-// KSKIP= skip the empty 8-wide k groups of a partial chunk (pays when the per-tap K is short).
-enum { B_NK = 0, B_KN4 = 1, B_KN2 = 2, B_KN1 = 3 };
+// per-block geometry and the LDS tables behind the two staging buffers (built by tile_setup)
+struct Tile {
+    float *s_sc, *s_ps, *s_sh;
+    int *s_pix, *s_cls, *s_nch, *s_kidx, *s_orow, *s_arow;
+    int b, rbase, HWo, m0, n0, Kb, Nb, T, pad, msub, nsub;
+};
 
-template <int MS, int NS, int BMODE, bool KSKIP, int MINW>
-__global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
-    static_assert(MS >= 4 && MS + NS <= 18, "LDS budget");
-    constexpr int ACC = (MS * NS + 3) / 4;                 // 32x32 accumulators per consumer wave
+// Decode blockIdx into (image, M block, N block), fill the LDS tables and synchronise the block.  Returns false
+// (for the whole block) when the block has no work.
+template <int MS, int NS>
+__device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& o) {
     constexpr int BM = MS * 32, BNX = NS * 32;
-    constexpr int BUF = (BM + BNX) * BK;                   // floats per LDS buffer
-    constexpr bool BGLDS = BMODE == B_NK || BMODE == B_KN4;
-    constexpr bool KN = BMODE != B_NK;
-    constexpr int BSL = BNX / 4;                           // 16-byte slots per k-major B row
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BUF = (BM + BNX) * BK;
     float* s_sc = smem + 2 * BUF;                          // [BNX] BN scale of the column's channel
     float* s_ps = s_sc + BNX;                              // [BNX] post-ReLU constant of the column's channel
     float* s_sh = s_ps + BNX;                              // [shift_classes][BNX] folded BN shift of the column's channel
@@ -143,15 +133,11 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
     const int Kb = p.k_idx ? p.k_cnt[b] : p.cin;
     const int Nb = p.n_idx ? p.n_cnt[b] : p.cout;
     const int Nb4 = min(round_up(Nb, 4), p.cout);
-    if (n0 >= Nb4 || m0 >= HWo) return;
+    if (n0 >= Nb4 || m0 >= HWo) return false;
     const int T = p.packed ? p.ksize : p.ksize * p.ksize;   // packed mode: ksize carries the tap count (1 or 9)
     const int pad = p.packed ? (T == 9 ? 1 : 0) : p.ksize >> 1;
     const int msub = ceil_div(min(HWo - m0, p.bm), 32);        // valid m-subtiles (1..MS)
     const int nsub = ceil_div(min(Nb4 - n0, p.bn), 32);        // valid n-subtiles (1..NS)
-    const int ntiles = msub * nsub;
-#ifdef LDN_TRACE
-    unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime(), tr_t0 = __builtin_amdgcn_s_memtime(), tr_bar = 0, tr_mma = 0, tr_iss = 0, tr_a = 0, tr_b = 0;
-#endif
 
     for (int i = tid; i < BM; i += 512) {
         const int m = m0 + i;
@@ -200,6 +186,130 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
     if (p.k_idx)
         for (int i = tid; i < Kb; i += 512) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
     __syncthreads();
+    o.s_sc = s_sc; o.s_ps = s_ps; o.s_sh = s_sh; o.s_pix = s_pix; o.s_cls = s_cls; o.s_nch = s_nch; o.s_kidx = s_kidx;
+    o.s_orow = s_orow; o.s_arow = s_arow;
+    o.b = b; o.rbase = rbase; o.HWo = HWo; o.m0 = m0; o.n0 = n0; o.Kb = Kb; o.Nb = Nb; o.T = T; o.pad = pad;
+    o.msub = msub; o.nsub = nsub;
+    return true;
+}
+
+// Residual operand of tile (mi, nj) in the layout tile_store consumes (4 x 16 bytes per lane).  Issued one tile ahead of
+// the store so that the global-load latency is hidden behind the previous tile's transpose and stores (the loads cannot
+// be hoisted by the compiler: residual may alias out in the in-place form).
+__device__ __forceinline__ void tile_resid(const ImgArgs& p, const Tile& t, int mi, int nj, int lane, f32x4* res) {
+    const int trow = lane >> 3, ccol = nj * 32 + (lane & 7) * 4;
+    const bool col_ok = t.s_nch[ccol] != -2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = mi * 32 + trow + 8 * it;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (col_ok && t.s_pix[row] >= 0) {
+            const size_t orow = p.packed ? (size_t)(t.s_orow[row] & 0x3fffffff) : (size_t)t.rbase + t.m0 + row;
+            v = *reinterpret_cast<const f32x4*>(p.residual + orow * p.ldr + t.n0 + ccol);
+        }
+        res[it] = v;
+    }
+}
+
+// Epilogue of one 32x32 accumulator tile (mi, nj) held by one wave: transpose through the wave's 4 KiB LDS scratch, then
+// folded-BN affine / residual / ReLU / post_sub on 4 consecutive channels per lane and 16-byte stores along the channel
+// axis; optional fused global-average-pool partials (colsum).
+__device__ __forceinline__ void tile_store(const ImgArgs& p, const Tile& t, float* scratch, const f32x16& acc, int mi,
+                                           int nj, int lane, const f32x4* res) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+    // phase 1: raw accumulators -> scratch (MFMA layout: lane = column, register r = row (r&3) + 8 (r>>2) + 4 h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // phase 2: lane = (row trow + 8 it, 4 consecutive columns): affine with the row's border class, residual, ReLU, store.
+    // Columns without a channel have scale = shift = 0 in the tables and exact-zero accumulators (their weight rows
+    // are staged as zeros), so they come out as 0.
+    const int ccol = nj * 32 + tc4;
+    if (t.s_nch[ccol] != -2) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(t.s_sc + ccol);
+        const f32x4 ps = *reinterpret_cast<const f32x4*>(t.s_ps + ccol);
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = mi * 32 + trow + 8 * it;
+            if (t.s_pix[row] < 0) continue;
+            const int cls = p.shift_classes > 1 ? t.s_cls[row] : 0;
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(t.s_sh + cls + ccol);
+            f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (trow + 8 * it) * 32 + tc4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+            size_t orow = (size_t)t.rbase + t.m0 + row;
+            bool do_relu = p.relu == 1;
+            if (p.packed) {
+                const int o = t.s_orow[row];
+                do_relu = do_relu || (o & 0x40000000);
+                orow = (size_t)(o & 0x3fffffff);
+            }
+            if (p.residual) v += res[it];
+            if (do_relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            v -= ps;
+            *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + t.n0 + ccol) = v;
+            csum += v;
+        }
+        if (p.colsum) {   // fused global-average-pool partials for the NEXT block's channel masker
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = csum[e];
+                x += __shfl_xor(x, 8, 64);
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+                csum[e] = x;
+            }
+            if (trow == 0) {
+                const size_t slot = ((size_t)t.b * ceil_div(t.HWo, 32) + (t.m0 >> 5) + mi) * p.cout + t.n0 + ccol;   // dense mode only
+                *reinterpret_cast<f32x4*>(p.colsum + slot) = csum;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// MS x NS = m-subtiles x n-subtiles of 32 per block (two LDS buffers of (MS+NS)*4 KiB).
+// BMODE= weight layout / staging path:
+//        B_NK  : w[cout][taps][cin] ("n-major"), no K gather.  Tile rows = output channels (gathered through
+//                n_idx for free: a row is a pointer), 128 contiguous bytes of K per row            -> LDS-DMA
+//        B_KN4 : w[taps][cin][cout] ("k-major"), used whenever the INPUT channels are gathered (k_idx): tile
+//                rows = the chunk's 32 packed k positions (row gather, free), columns = output channels,
+//                contiguous or gathered in aligned runs of >= 4                                    -> LDS-DMA
+//        B_KN2 / B_KN1 : same layout, output channels gathered in aligned pairs / singly           -> VGPRs
+//        (k-major keeps every weight fetch inside one or a few 128-byte lines of a single row; the n-major
+//         layout with a K gather touched ~2.6x more lines than it used)
+// KSKIP= skip the empty 8-wide k groups of a partial chunk (pays when the per-tap K is short).
+enum { B_NK = 0, B_KN4 = 1, B_KN2 = 2, B_KN1 = 3 };
+
+template <int MS, int NS, int BMODE, bool KSKIP, int MINW>
+__global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
+    static_assert(MS >= 4 && MS + NS <= 18, "LDS budget");
+    constexpr int ACC = (MS * NS + 3) / 4;                 // 32x32 accumulators per consumer wave
+    constexpr int BM = MS * 32, BNX = NS * 32;
+    constexpr int BUF = (BM + BNX) * BK;                   // floats per LDS buffer
+    constexpr bool BGLDS = BMODE == B_NK || BMODE == B_KN4;
+    constexpr bool KN = BMODE != B_NK;
+    constexpr int BSL = BNX / 4;                           // 16-byte slots per k-major B row
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    Tile t;
+    if (!tile_setup<MS, NS>(p, smem, t)) return;
+    float *const s_sc = t.s_sc, *const s_ps = t.s_ps, *const s_sh = t.s_sh;
+    int *const s_pix = t.s_pix, *const s_cls = t.s_cls, *const s_nch = t.s_nch, *const s_kidx = t.s_kidx;
+    int *const s_orow = t.s_orow, *const s_arow = t.s_arow;
+    const int tid = threadIdx.x;
+    const int b = t.b, rbase = t.rbase, HWo = t.HWo, m0 = t.m0, n0 = t.n0, Kb = t.Kb, T = t.T, pad = t.pad;
+    const int msub = t.msub, nsub = t.nsub, ntiles = msub * nsub;
+    (void)s_sc; (void)s_ps; (void)s_sh; (void)s_cls; (void)s_orow; (void)rbase; (void)HWo; (void)m0; (void)n0;
+#ifdef LDN_TRACE
+    unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime(), tr_t0 = __builtin_amdgcn_s_memtime(), tr_bar = 0, tr_mma = 0, tr_iss = 0, tr_a = 0, tr_b = 0;
+#endif
 
     const int lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -356,7 +466,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
         }
 #ifdef LDN_TRACE
         if (tid == 256 && g_trace) {
-            unsigned long long* r = g_trace + ((size_t)blockIdx.x + gridDim.x) * 6;
+            unsigned long long* r = g_trace + ((size_t)blockIdx.x + gridDim.x) * 8;
             r[0] = tr_t0; r[1] = __builtin_amdgcn_s_memtime(); r[2] = 0; r[3] = 1;
             r[4] = ntiles | (tr_bar << 32); r[5] = (tr_mma << 32) | (tr_iss & 0xffffffffull);
         }
@@ -442,69 +552,18 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
 
     // ---- epilogue
     float* scratch = smem + wave * (32 * 32);
-    const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+    f32x4 res[4];
 #pragma unroll
     for (int s = 0; s < ACC; ++s) {
         const int tt = wave + 4 * s;
         if (tt >= ntiles) continue;
         const int nj = tt / msub, mi = tt - nj * msub;
-        const int col = nj * 32 + l31;
-        const int chn = s_nch[col];
-        const float sc = s_sc[col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = chn >= 0 ? acc[s][r] * sc + s_sh[s_cls[mi * 32 + row] + col] : 0.f;
-            scratch[row * 32 + l31] = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int ccol = nj * 32 + tc4;
-        if (s_nch[ccol] != -2) {
-            const f32x4 ps = *reinterpret_cast<const f32x4*>(s_ps + ccol);
-            f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = mi * 32 + trow + 8 * it;
-                if (s_pix[row] < 0) continue;
-                f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (trow + 8 * it) * 32 + tc4);
-                size_t orow = (size_t)rbase + m0 + row;
-                bool do_relu = p.relu == 1;
-                if (p.packed) {
-                    const int o = s_orow[row];
-                    do_relu = do_relu || (o & 0x40000000);
-                    orow = (size_t)(o & 0x3fffffff);
-                }
-                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + orow * p.ldr + n0 + ccol);
-                if (do_relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                v -= ps;
-                *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + n0 + ccol) = v;
-                csum += v;
-            }
-            if (p.colsum) {   // fused global-average-pool partials for the NEXT block's channel masker
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = csum[e];
-                    t += __shfl_xor(t, 8, 64);
-                    t += __shfl_xor(t, 16, 64);
-                    t += __shfl_xor(t, 32, 64);
-                    csum[e] = t;
-                }
-                if (trow == 0) {
-                    const size_t slot = ((size_t)b * ceil_div(HWo, 32) + (m0 >> 5) + mi) * p.cout + n0 + ccol;   // dense mode only
-                    *reinterpret_cast<f32x4*>(p.colsum + slot) = csum;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (p.residual) tile_resid(p, t, mi, nj, lane, res);   // in flight during the tile's LDS transpose
+        tile_store(p, t, scratch, acc[s], mi, nj, lane, res);
     }
 #ifdef LDN_TRACE
     if (tid == 0 && g_trace) {
-        unsigned long long* r = g_trace + (size_t)blockIdx.x * 6;
+        unsigned long long* r = g_trace + (size_t)blockIdx.x * 8;
         r[0] = tr_t0; r[1] = __builtin_amdgcn_s_memtime();
         r[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
         r[3] = __builtin_amdgcn_s_memrealtime() - tr_r0;                        // 100 MHz ticks
@@ -513,13 +572,393 @@ __global__ __launch_bounds__(512, MINW) void k_conv_image(const ImgArgs p) {
 #endif
 }
 
+// ================================================================================================ bf16x3 kernel
+// Split-precision variant (math mode 1).  Same block structure, A staging, tables and epilogue as k_conv_image, but
+//   * every fp32 operand x is used as bf16 hi + bf16 lo (both round-to-nearest-even, x = hi + lo + O(2^-17 |x|)) and a
+//     product is formed as lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (8 passes each) with fp32 accumulation:
+//     5.3x less matrix-pipe time per K than v_mfma_f32_32x32x2_f32;
+//   * the WEIGHT tile goes through the producers' VGPRs: they split it once per chunk and write it to LDS as rows of
+//     output channels whose 128 bytes hold four k-octets as [8 hi bf16 | 8 lo bf16] (k-major weights are transposed in
+//     registers on the way), so a B fragment is two ds_read_b128 and no VALU in the consumers, for all four BMODEs;
+//   * the ACTIVATION tile still lands as raw fp32 through LDS-DMA; each consumer wave owns whole m-subtiles (wave grid
+//     WM x 4/WM over the block's subtiles), splits its A fragments once per K16 step and reuses them against every
+//     n-subtile it owns -- register blocking that keeps both the VALU work and the LDS reads per MFMA low.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? x0[e] : x1[e - 4];
+        const __bf16 hb = (__bf16)v;
+        hi[e] = hb;
+        lo[e] = (__bf16)(v - (float)hb);
+    }
+}
+
+template <int MS, int NS, int WM, int BMODE, bool KSKIP, int MINW>
+__global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
+    static_assert(MS >= 1 && MS + NS <= 18 && NS % 2 == 0 && (WM == 1 || WM == 2 || WM == 4), "tile shape");
+    constexpr int WN = 4 / WM;                             // consumer wave grid WM (m) x WN (n)
+    constexpr int AM = (MS + WM - 1) / WM, CN = (NS + WN - 1) / WN;   // subtiles per wave in m / n
+    constexpr int BM = MS * 32, BNX = NS * 32;
+    constexpr int BUF = (BM + BNX) * BK;
+    constexpr bool KN = BMODE != B_NK;
+    constexpr int BSL = BNX / 4;                           // column quads of the weight tile
+    constexpr int NBT = KN ? (BSL * 4 + 255) / 256 : NS / 2;   // weight tasks per producer lane and chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    Tile t;
+#ifdef LDN_TRACE
+    unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime(), tr_t0 = __builtin_amdgcn_s_memtime(), tr_bar = 0, tr_mma = 0, tr_iss = 0, tr_a = 0, tr_b = 0, tr_pro = 0, tr_epi = 0;
+#endif
+    if (!tile_setup<MS, NS>(p, smem, t)) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Kb = t.Kb, T = t.T, msub = t.msub, nsub = t.nsub;
+    const int cpt = ceil_div(Kb, BK);
+    const int nch = T * cpt;
+
+    if (wave8 >= 4) {
+        // ================================================================ producers (waves 4..7)
+        const int wave = wave8 - 4;
+        // ---- A: LDS-DMA of raw fp32 rows, exactly as in k_conv_image
+        const int rg = lane >> 3, pslot = lane & 7;
+        const int qt = pslot ^ (((rg >> 1) + 4 * (wave & 1)) & 7);
+        const int kq = qt * 4;
+        long aoff[MS];
+        const int Kb4 = p.k_idx ? round_up(Kb, 4) : p.cin;
+        __builtin_amdgcn_s_setprio(2);
+        auto set_tap = [&](int tap) {
+            const int ksz = p.packed ? 3 : p.ksize;
+            const int ky = tap / ksz, kx = tap - ky * ksz;
+#pragma unroll
+            for (int u = 0; u < MS; ++u) {
+                long off = -1;
+                if (u < msub) {
+                    const int row = (wave + 4 * u) * 8 + rg;
+                    if (p.packed) {
+                        const int ar = t.s_arow[row * T + tap];
+                        if (ar >= 0) off = (long)ar * p.lda;
+                    } else {
+                        const int pix = t.s_pix[row];
+                        if (pix >= 0) {
+                            const int iy = (pix >> 16) * p.stride + ky - t.pad, ix = (pix & 0xffff) * p.stride + kx - t.pad;
+                            if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+                                off = ((long)(t.b * p.Hi + iy) * p.Wi + ix) * p.lda;
+                        }
+                    }
+                }
+                aoff[u] = off;
+            }
+        };
+        auto issue_a = [&](int c0, int buf) {
+            const int c = c0 + kq;
+            float* base = smem + buf * BUF;
+#pragma unroll
+            for (int u = 0; u < MS; ++u)
+                if (u < msub)
+                    glds16((aoff[u] >= 0 && c < Kb4) ? p.a + aoff[u] + c : g_zero16, base + (wave + 4 * u) * 8 * BK);
+        };
+
+        // ---- B: global -> VGPR -> split -> LDS rows [n][4 octets x (8 hi | 8 lo)], slots XOR-swizzled like the A rows
+        f32x4 rb[NBT][KN ? 8 : 2];
+        // n-major weights: wave-task (wave + 4u) covers 16 rows x 4 octets; this lane = row rl, octet oct.  Eight
+        // consecutive lanes write eight rows with distinct swizzles (conflict-free ds_write_b128).
+        const int rl = ((lane & 7) << 1) | (lane >> 5), oct_nk = (lane >> 3) & 3;
+        long bbase[NBT];            // B_NK: element offset of w[chn][0][0] for this lane's row, -1 = no row
+        int cq[NBT], oct_kn[NBT];   // k-major: column quad / octet of task u
+        int cn[NBT][BMODE == B_KN1 ? 4 : (BMODE == B_KN2 ? 2 : 1)];
+#pragma unroll
+        for (int u = 0; u < NBT; ++u) {
+            if (!KN) {
+                const int row = (wave + 4 * u) * 16 + rl;
+                const int chn = row < nsub * 32 ? t.s_nch[row] : -1;
+                bbase[u] = chn >= 0 ? (long)chn * T * p.cin : -1;
+            } else {
+                const int q = wave * 64 + lane + 256 * u;
+                oct_kn[u] = q / BSL;
+                cq[u] = q - oct_kn[u] * BSL;
+                const bool in = oct_kn[u] < 4 && cq[u] * 4 < nsub * 32;
+                if (!in) oct_kn[u] = -1;
+                if (BMODE == B_KN4) cn[u][0] = in ? t.s_nch[cq[u] * 4] : -1;
+                if (BMODE == B_KN2) { cn[u][0] = in ? t.s_nch[cq[u] * 4] : -1; cn[u][1] = in ? t.s_nch[cq[u] * 4 + 2] : -1; }
+                if (BMODE == B_KN1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cn[u][e] = in ? t.s_nch[cq[u] * 4 + e] : -1;
+                }
+            }
+        }
+        auto load_b = [&](int tap, int c0) {
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) {
+                if (!KN) {
+                    const int c = c0 + oct_nk * 8;
+                    const float* src = p.w + bbase[u] + (long)tap * p.cin + c;
+                    rb[u][0] = *reinterpret_cast<const f32x4*>((bbase[u] >= 0 && c < p.cin) ? src : g_zero16);
+                    rb[u][1] = *reinterpret_cast<const f32x4*>((bbase[u] >= 0 && c + 4 < p.cin) ? src + 4 : g_zero16);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int kpos = c0 + oct_kn[u] * 8 + j;
+                        const bool kok = oct_kn[u] >= 0 && kpos < Kb;
+                        const int kc = min(max(kpos, 0), Kb - 1);
+                        const int kch = p.k_idx ? t.s_kidx[kc] : kc;
+                        const float* wr = p.w + ((long)tap * p.cin + kch) * p.cout;
+                        if (BMODE == B_KN4) {
+                            rb[u][j] = *reinterpret_cast<const f32x4*>((kok && cn[u][0] >= 0) ? wr + cn[u][0] : g_zero16);
+                        } else if (BMODE == B_KN2) {
+                            const float2 lo = *reinterpret_cast<const float2*>((kok && cn[u][0] >= 0) ? wr + cn[u][0] : g_zero16);
+                            const float2 hi = *reinterpret_cast<const float2*>((kok && cn[u][1] >= 0) ? wr + cn[u][1] : g_zero16);
+                            rb[u][j][0] = lo.x; rb[u][j][1] = lo.y; rb[u][j][2] = hi.x; rb[u][j][3] = hi.y;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rb[u][j][e] = *((kok && cn[u][e] >= 0) ? wr + cn[u][e] : g_zero16);
+                        }
+                    }
+                }
+            }
+        };
+        auto store_b = [&](int buf) {
+            float* bt = smem + buf * BUF + BM * BK;
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) {
+                if (!KN) {
+                    const int row = (wave + 4 * u) * 16 + rl;
+                    if (row < nsub * 32) {
+                        bf16x8 hi, lo;
+                        split_bf16(rb[u][0], rb[u][1], hi, lo);
+                        const int sw = lane & 7;                                    // (row >> 1) & 7
+                        *reinterpret_cast<bf16x8*>(bt + row * BK + ((2 * oct_nk) ^ sw) * 4) = hi;
+                        *reinterpret_cast<bf16x8*>(bt + row * BK + ((2 * oct_nk + 1) ^ sw) * 4) = lo;
+                    }
+                } else if (oct_kn[u] >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {      // column e of the quad: its 8 k values sit in rb[u][0..7][e]
+                        const f32x4 x0 = {rb[u][0][e], rb[u][1][e], rb[u][2][e], rb[u][3][e]};
+                        const f32x4 x1 = {rb[u][4][e], rb[u][5][e], rb[u][6][e], rb[u][7][e]};
+                        bf16x8 hi, lo;
+                        split_bf16(x0, x1, hi, lo);
+                        const int row = cq[u] * 4 + e, sw = (row >> 1) & 7;
+                        *reinterpret_cast<bf16x8*>(bt + row * BK + ((2 * oct_kn[u]) ^ sw) * 4) = hi;
+                        *reinterpret_cast<bf16x8*>(bt + row * BK + ((2 * oct_kn[u] + 1) ^ sw) * 4) = lo;
+                    }
+                }
+            }
+        };
+
+        if (nch > 0) {
+            // two cursors: A is DMA'd one chunk ahead of the consumers, B is loaded into VGPRs two chunks ahead
+            int tap_a = 0, c0_a = 0, tap_b = 0, c0_b = 0;
+            auto adv_a = [&]() { c0_a += BK; if (c0_a >= Kb) { c0_a = 0; ++tap_a; if (tap_a < T) set_tap(tap_a); } };
+            auto adv_b = [&]() { c0_b += BK; if (c0_b >= Kb) { c0_b = 0; ++tap_b; } };
+            set_tap(0);
+            load_b(0, 0);
+            adv_b();
+            issue_a(0, 0);
+            adv_a();
+            store_b(0);
+            if (nch > 1) { load_b(tap_b, c0_b); adv_b(); }
+            for (int ch = 0; ch < nch; ++ch) {
+                const int buf = ch & 1;
+                LDN_TRACE_T(tr_a)
+#ifdef LDN_TRACE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+                LDN_TRACE_T(tr_b)
+                LDN_TRACE_ADD(tr_mma, tr_a, tr_b)     // producer: waiting for its own loads
+                block_sync();                 // barrier(ch): chunk ch is in LDS, B(ch+1) is in VGPRs, buffer buf^1 is free
+                LDN_TRACE_T(tr_a)
+                LDN_TRACE_ADD(tr_bar, tr_b, tr_a)     // producer: waiting at the barrier for the consumers
+                if (ch + 1 < nch) {
+#if !(LDN_ABLATE & 2)
+                    issue_a(c0_a, buf ^ 1);
+#endif
+                    adv_a();
+#if !(LDN_ABLATE & 8)
+                    store_b(buf ^ 1);
+#endif
+#if !(LDN_ABLATE & 4)
+                    if (ch + 2 < nch) { load_b(tap_b, c0_b); adv_b(); }
+#endif
+                }
+                LDN_TRACE_T(tr_b)
+                LDN_TRACE_ADD(tr_iss, tr_a, tr_b)     // producer: DMA issue + weight split/store + weight load issue
+            }
+            block_sync();
+        }
+#ifdef LDN_TRACE
+        if (tid == 256 && g_trace) {
+            unsigned long long* r = g_trace + ((size_t)blockIdx.x + gridDim.x) * 8;
+            r[0] = tr_t0; r[1] = __builtin_amdgcn_s_memtime(); r[2] = 0; r[3] = 1;
+            r[4] = (msub * nsub) | (tr_bar << 32); r[5] = (tr_mma << 32) | (tr_iss & 0xffffffffull);
+        }
+#endif
+        return;
+    }
+
+    // ==================================================================== consumers (waves 0..3)
+    const int wave = wave8;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int swl = (l31 >> 1) & 7;
+    const int wm = wave % WM, wn = wave / WM;
+    const int my_am = msub > wm ? (msub - wm + WM - 1) / WM : 0;    // m-subtiles wm, wm + WM, ...
+    const int my_cn = nsub > wn ? (nsub - wn + WN - 1) / WN : 0;    // n-subtiles wn, wn + WN, ...
+    f32x16 acc[AM][CN];
+#pragma unroll
+    for (int a = 0; a < AM; ++a)
+#pragma unroll
+        for (int c = 0; c < CN; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    const int a_row = (wm * 32 + l31) * BK, b_row = (BM + wn * 32 + l31) * BK;
+    int sl[BK / 16][2];                        // swizzled float offsets of this lane's two slots in K16 step ks
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+        sl[ks][0] = ((4 * ks + 2 * h) ^ swl) * 4;
+        sl[ks][1] = ((4 * ks + 2 * h + 1) ^ swl) * 4;
+    }
+
+    if (nch > 0) {
+        int cin_chunk = 0;
+        for (int ch = 0; ch < nch; ++ch) {
+            const int buf = ch & 1;
+            const int kgroups = ceil_div(min(Kb - cin_chunk * BK, BK), 8);   // octets of this chunk that hold data
+            if (++cin_chunk == cpt) cin_chunk = 0;
+            LDN_TRACE_T(tr_a)
+            block_sync();                      // barrier(ch)
+            LDN_TRACE_T(tr_b)
+            LDN_TRACE_ADD(tr_bar, tr_a, tr_b)
+#ifdef LDN_TRACE
+            if (ch == 0) tr_pro = tr_b - tr_t0;
+#endif
+            const float* tb = smem + buf * BUF;
+            // lane's octet of K16 step ks: raw A floats [8 oct, 8 oct + 8) = slots 2 oct, 2 oct + 1; the B row holds the
+            // octet's hi half in slot 2 oct and its lo half in slot 2 oct + 1.  All AM m-subtiles are computed (rows of
+            // subtiles beyond msub hold stale data; their accumulators are never stored); n-subtiles beyond my_cn are
+            // skipped by a wave-uniform branch, and the B fragment of subtile c + 1 is requested before the MFMAs of c.
+            f32x4 ar[AM][2];
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int a = 0; a < AM; ++a) {
+                ar[a][0] = *reinterpret_cast<const f32x4*>(tb + a_row + a * (WM * 32 * BK) + sl[0][0]);
+                ar[a][1] = *reinterpret_cast<const f32x4*>(tb + a_row + a * (WM * 32 * BK) + sl[0][1]);
+            }
+            bh = *reinterpret_cast<const bf16x8*>(tb + b_row + sl[0][0]);
+            bl = *reinterpret_cast<const bf16x8*>(tb + b_row + sl[0][1]);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if (KSKIP && 2 * ks >= kgroups) break;
+                bf16x8 ah[AM], al[AM];
+#pragma unroll
+                for (int a = 0; a < AM; ++a) split_bf16(ar[a][0], ar[a][1], ah[a], al[a]);
+                if (ks + 1 < BK / 16) {
+#pragma unroll
+                    for (int a = 0; a < AM; ++a) {
+                        ar[a][0] = *reinterpret_cast<const f32x4*>(tb + a_row + a * (WM * 32 * BK) + sl[ks + 1][0]);
+                        ar[a][1] = *reinterpret_cast<const f32x4*>(tb + a_row + a * (WM * 32 * BK) + sl[ks + 1][1]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CN; ++c) {
+                    if (c < my_cn) {
+                        const bf16x8 ch_ = bh, cl_ = bl;
+                        if (c + 1 < CN) {       // rows beyond nsub * 32 exist in LDS (stale): harmless to read
+                            bh = *reinterpret_cast<const bf16x8*>(tb + b_row + (c + 1) * (WN * 32 * BK) + sl[ks][0]);
+                            bl = *reinterpret_cast<const bf16x8*>(tb + b_row + (c + 1) * (WN * 32 * BK) + sl[ks][1]);
+                        }
+#pragma unroll
+                        for (int a = 0; a < AM; ++a) {
+#if LDN_ABLATE & 1
+                            asm volatile("" ::"v"(al[a]), "v"(ah[a]), "v"(ch_), "v"(cl_));
+                            continue;
+#endif
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], ch_, acc[a][c], 0, 0, 0);
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], cl_, acc[a][c], 0, 0, 0);
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], ch_, acc[a][c], 0, 0, 0);
+                        }
+                    }
+                }
+                if (ks + 1 < BK / 16) {
+                    bh = *reinterpret_cast<const bf16x8*>(tb + b_row + sl[ks + 1][0]);
+                    bl = *reinterpret_cast<const bf16x8*>(tb + b_row + sl[ks + 1][1]);
+                }
+            }
+            LDN_TRACE_T(tr_a)
+            LDN_TRACE_ADD(tr_mma, tr_b, tr_a)
+        }
+        block_sync();   // every consumer is done with both buffers before buffer 0 becomes the epilogue scratch
+    }
+    LDN_TRACE_T(tr_epi)
+
+    float* scratch = smem + wave * (32 * 32);
+    f32x4 res[2][4];
+    if (p.residual && my_am > 0 && my_cn > 0) tile_resid(p, t, wm, wn, lane, res[0]);
+#pragma unroll
+    for (int i = 0; i < AM * CN; ++i) {
+        const int a = i / CN, c = i % CN;               // compile-time after unrolling
+        const int a2 = (i + 1) / CN, c2 = (i + 1) % CN;
+        if (p.residual && i + 1 < AM * CN && a2 < my_am && c2 < my_cn)
+            tile_resid(p, t, wm + WM * a2, wn + WN * c2, lane, res[(i + 1) & 1]);
+        if (a < my_am && c < my_cn) tile_store(p, t, scratch, acc[a][c], wm + WM * a, wn + WN * c, lane, res[i & 1]);
+    }
+#ifdef LDN_TRACE
+    if (tid == 0 && g_trace) {
+        unsigned long long* r = g_trace + (size_t)blockIdx.x * 8;
+        r[0] = tr_t0; r[1] = __builtin_amdgcn_s_memtime();
+        r[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        r[3] = __builtin_amdgcn_s_memrealtime() - tr_r0;                        // 100 MHz ticks
+        r[4] = (msub * nsub) | (tr_bar << 32); r[5] = (tr_mma << 32) | (tr_iss & 0xffffffffull);
+        r[6] = tr_pro; r[7] = r[1] - tr_epi;
+    }
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------- host
+static int g_math_mode = -1;   // 0 = fp32 MFMA, 1 = bf16x3 split precision (initial value from env LDN_MATH_MODE)
+static int math_mode() {
+    if (g_math_mode < 0) {
+        const char* e = getenv("LDN_MATH_MODE");
+        g_math_mode = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_math_mode;
+}
+
+static size_t tile_lds_bytes(const ImgArgs& p, int MS, int NS) {
+    return (size_t)2 * (MS + NS) * 32 * BK * sizeof(float) + (size_t)((2 + p.shift_classes) * NS * 32) * sizeof(float) +
+           (size_t)(2 * MS * 32 + NS * 32 + (p.k_idx ? p.cin : 0) + (p.packed ? MS * 32 * (1 + p.ksize) : 0)) * sizeof(int);
+}
+
+template <int MS, int NS, int WM, int BMODE, bool KSKIP>
+static int launch_bf3(const ImgArgs& p, hipStream_t st) {
+    constexpr int MINW = (MS + NS) <= 8 ? 4 : 2;
+    const size_t lds = tile_lds_bytes(p, MS, NS);
+    LDN_REQUIRE(lds <= 160 * 1024, "k_conv_bf3: %zu B of LDS exceed 160 KiB (cin too large for k_idx)", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_conv_bf3<MS, NS, WM, BMODE, KSKIP, MINW>), lds),
+                "k_conv_bf3: cannot reserve %zu B of LDS", lds);
+    ImgArgs q = p;
+    const int msubs = ceil_div(p.packed ? p.m_cap : p.Ho * p.Wo, 32);
+    const int mtn = ceil_div(msubs, MS);
+    q.bm = ceil_div(msubs, mtn) * 32;
+    const unsigned grid = (unsigned)p.B * mtn * p.ntn;
+    hipLaunchKernelGGL((k_conv_bf3<MS, NS, WM, BMODE, KSKIP, MINW>), dim3(grid), dim3(512), lds, st, q);
+    LDN_CHECK_LAUNCH("k_conv_bf3");
+    return LDN_OK;
+}
+
 template <int MS, int NS, int BMODE, bool KSKIP>
 static int launch_k(const ImgArgs& p, hipStream_t st) {
+    if (math_mode() == 1) {
+        // consumer wave grid WM x 4/WM: every wave owns whole m-subtiles (A fragments are split once and reused);
+        // 4 x 1 for the tall 8 x 6 tile, 2 x 2 otherwise; 7x7 images (<= 2 m-subtiles) get a 2-subtile-high tile
+        const int msubs = ceil_div(p.packed ? p.m_cap : p.Ho * p.Wo, 32);
+        if constexpr (MS == 4 && NS == 10) {
+            if (msubs <= 2) return launch_bf3<2, 10, 2, BMODE, KSKIP>(p, st);
+        }
+        return launch_bf3<MS, NS, (MS >= 8 ? 4 : 2), BMODE, KSKIP>(p, st);
+    }
     // blocks of <= 64 KiB LDS run two per CU (memory-bound early stages need the extra waves in flight)
     constexpr int MINW = (MS + NS) <= 8 ? 4 : 2;
-    const size_t lds = (size_t)2 * (MS + NS) * 32 * BK * sizeof(float) + (size_t)((2 + p.shift_classes) * NS * 32) * sizeof(float) +
-                       (size_t)(2 * MS * 32 + NS * 32 + (p.k_idx ? p.cin : 0) + (p.packed ? MS * 32 * (1 + p.ksize) : 0)) * sizeof(int);
+    const size_t lds = tile_lds_bytes(p, MS, NS);
     LDN_REQUIRE(lds <= 160 * 1024, "k_conv_image: %zu B of LDS exceed 160 KiB (cin too large for k_idx)", lds);
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_conv_image<MS, NS, BMODE, KSKIP, MINW>), lds),
                 "k_conv_image: cannot reserve %zu B of LDS", lds);
@@ -565,6 +1004,14 @@ static int dispatch_mode(const ImgArgs& p, int kgran, hipStream_t st) {
 }  // namespace ldn
 
 using namespace ldn;
+
+extern "C" int ldn_set_math_mode(int mode) {
+    LDN_REQUIRE(mode == 0 || mode == 1, "ldn_set_math_mode: mode must be 0 (fp32) or 1 (bf16x3), got %d", mode);
+    g_math_mode = mode;
+    return LDN_OK;
+}
+
+extern "C" int ldn_get_math_mode(void) { return math_mode(); }
 
 #ifdef LDN_TRACE
 extern "C" int ldn_debug_set_trace(void* buf) {

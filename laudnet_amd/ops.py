@@ -21,6 +21,21 @@ def _i32c(t, what):
     return t
 
 
+MATH_MODES = {"fp32": 0, "bf16x3": 1}
+
+
+def set_math_mode(mode):
+    """Arithmetic of the MFMA convolutions: "fp32" or "bf16x3" (see ldn_set_math_mode in include/ldn_hip.h)."""
+    if mode not in MATH_MODES:
+        raise L.LdnError(f"set_math_mode: unknown mode {mode!r} (expected one of {sorted(MATH_MODES)})")
+    L.check(L.load().ldn_set_math_mode(MATH_MODES[mode]), "ldn_set_math_mode")
+
+
+def get_math_mode():
+    m = L.load().ldn_get_math_mode()
+    return next(k for k, v in MATH_MODES.items() if v == m)
+
+
 def as_nhwc(x):
     """[B,C,H,W] logical tensor -> contiguous [B,H,W,C] view (copying into channels_last if needed)."""
     if x.dim() != 4:

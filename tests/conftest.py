@@ -13,6 +13,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_generate_tests(metafunc):
+    # GPU parity tests run once per arithmetic mode of the MFMA convolutions (include/ldn_hip.h: ldn_set_math_mode)
+    if "math_mode" in metafunc.fixturenames:
+        metafunc.parametrize("math_mode", ["fp32", "bf16x3"])
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

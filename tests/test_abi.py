@@ -41,6 +41,22 @@ def test_argument_validation_without_gpu():
     assert lib.ldn_channel_masker_splits(3136) >= 1
 
 
+def test_math_mode_switch_without_gpu():
+    from laudnet_amd import _lib, ops
+    lib = _lib.load()
+    before = ops.get_math_mode()
+    try:
+        ops.set_math_mode("bf16x3")
+        assert ops.get_math_mode() == "bf16x3" and lib.ldn_get_math_mode() == 1
+        ops.set_math_mode("fp32")
+        assert lib.ldn_get_math_mode() == 0
+        assert lib.ldn_set_math_mode(7) == -1 and b"mode" in lib.ldn_last_error()
+        with pytest.raises(_lib.LdnError):
+            ops.set_math_mode("tf32")
+    finally:
+        ops.set_math_mode(before)
+
+
 @pytest.mark.parametrize("name", ["r50_spatial_g1", "r101_channel2222", "r101_spatial4421", "r101_layer", "r50_mixed"])
 def test_state_dict_surface_matches_reference(name):
     import laudnet_amd

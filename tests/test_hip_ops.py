@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _set_math_mode(math_mode):
+    from laudnet_amd import ops as _ops
+    _ops.set_math_mode(math_mode)
+    yield
+    _ops.set_math_mode("fp32")
+
+
 @pytest.fixture(scope="module")
 def ops():
     from laudnet_amd import ops as _ops, load_library

@@ -41,7 +41,7 @@ fns = {
 fn = fns[kind]
 lib = _lib.load()
 nblk = 1 << 17
-trace = torch.zeros(nblk * 6, dtype=torch.int64, device=dev)
+trace = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
 lib.ldn_debug_set_trace.argtypes = [ctypes.c_void_p]
 for _ in range(3):
     fn()
@@ -51,14 +51,14 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); fn(); e1.record()
 torch.cuda.synchronize()
 print("launch us", 1e3 * e0.elapsed_time(e1))
-t = trace.cpu().numpy().reshape(-1, 6)
+t = trace.cpu().numpy().reshape(-1, 8)
 t = t[t[:, 0] != 0]
 prod = t[t[:, 2] == 0]
 t = t[t[:, 2] != 0]
 if len(prod):
     pn = prod[:, 4] & 0xffffffff; big = pn == pn.max()
     print('PRODUCER wave (largest blocks): dur', (prod[big, 1] - prod[big, 0]).mean(), ' wait-own-loads', ((prod[big, 5] >> 32) & 0xffffffff).mean(), ' wait-barrier', (prod[big, 4] >> 32).mean(), ' issue', (prod[big, 5] & 0xffffffff).mean())
-t0, t1, hw, xcc, nt_bar, mma_iss = [t[:, i] for i in range(6)]
+t0, t1, hw, xcc, nt_bar, mma_iss, t_pro, t_epi = [t[:, i] for i in range(8)]
 ntiles = nt_bar & 0xffffffff; t_bar = nt_bar >> 32; t_mma = (mma_iss >> 32) & 0xffffffff; t_iss = mma_iss & 0xffffffff; tm = t1
 base = t0.min()
 print("blocks traced", len(t), " memtime span", (t1.max() - base), "ticks")
@@ -66,7 +66,7 @@ dur = t1 - t0
 print("ticks/us estimate:", (t1.max() - base) / (1e3 * e0.elapsed_time(e1)))
 for nt_ in sorted(set(ntiles.tolist())):
     m = ntiles == nt_
-    print(f" ntiles={nt_:3d}: n={m.sum():5d}  dur mean {dur[m].mean():9.0f} min {dur[m].min():8d} max {dur[m].max():8d}  start mean {(t0[m]-base).mean():9.0f} max {(t0[m]-base).max():9d}  wave0: barrier-wait {t_bar[m].mean():9.0f} issue {t_iss[m].mean():8.0f} mma {t_mma[m].mean():9.0f}")
+    print(f" ntiles={nt_:3d}: n={m.sum():5d}  dur mean {dur[m].mean():9.0f} min {dur[m].min():8d} max {dur[m].max():8d}  start mean {(t0[m]-base).mean():9.0f} max {(t0[m]-base).max():9d}  wave0: barrier-wait {t_bar[m].mean():9.0f} issue {t_iss[m].mean():8.0f} mma {t_mma[m].mean():9.0f} prologue {t_pro[m].mean():8.0f} epilogue {t_epi[m].mean():8.0f}")
 cu = ((xcc & 0xf) << 16) | (hw & 0xff00) | ((hw >> 13) & 7) << 4 | ((hw >> 12) & 1)
 cu_key = (xcc & 0xf) * 10000 + ((hw >> 13) & 7) * 1000 + ((hw >> 12) & 1) * 100 + ((hw >> 8) & 0xf)
 uk = np.unique(cu_key)

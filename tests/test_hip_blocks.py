@@ -11,9 +11,15 @@ from helpers import (assert_tuple_close, block_input, full_model_blocks, injecte
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = 1e-3  # north_star: outputs within 1e-3 fp32 of the reference PyTorch masked-conv path
-# relative slack on the O(1e3) logits of the seeded-random full nets: fp32 round-off, and the 2^-16 per-product error of
-# the bf16x3 split-precision mode accumulated over ~100 layers (measured 2e-5)
-LOGIT_RTOL = {"fp32": 1e-5, "bf16x3": 1e-4}
+# slack on the O(1e3) logits of the seeded-random full nets.  fp32: round-off relative to each logit.  bf16x3: the 2^-17
+# operand split error of ~100 chained layers is proportional to the SCALE of the logit vector, not to each logit
+# (measured 5.5e-6 of max|logit|), so the bound is 1e-3 + 1e-5 * max|logit| on every element.
+LOGIT_RTOL = {"fp32": 1e-5, "bf16x3": 0.0}
+LOGIT_SCALE_TOL = {"fp32": 0.0, "bf16x3": 1e-5}
+
+
+def logit_atol(math_mode, want):
+    return TOL + LOGIT_SCALE_TOL[math_mode] * float(torch.as_tensor(want[0]).abs().max())
 
 
 @pytest.fixture(autouse=True)
@@ -119,7 +125,8 @@ def test_full_model_injected(name, math_mode):
         got = model(x, 1.0)
     torch.cuda.synchronize()
     # seeded-random 50/101-layer nets let logits grow to O(1e3): 1e-3 absolute plus fp32 round-off relative
-    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=TOL, rtol=LOGIT_RTOL[math_mode], what=name + " logits")
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=logit_atol(math_mode, fx["injected_run"]), rtol=LOGIT_RTOL[math_mode],
+                       what=name + " logits")
     assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what=name + " stats")
     assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what=name + " flops")
 
@@ -193,7 +200,8 @@ def test_regnet_layerskip_injected(math_mode):
         blk.f.forced_spatial_mask = seeded_bernoulli((fx["batch"], 1, 1, 1), 0.5, fx["mask_seed"] + 2 * i)
     with torch.no_grad():
         got = model(x, 1.0)
-    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=TOL, rtol=LOGIT_RTOL[math_mode], what="regnet logits")
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=logit_atol(math_mode, fx["injected_run"]), rtol=LOGIT_RTOL[math_mode],
+                       what="regnet logits")
     assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what="regnet stats")
     assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what="regnet flops")
 
@@ -204,7 +212,8 @@ def test_regnet_layerskip_own_maskers(math_mode):
     with torch.no_grad():
         got = model(x, 1.0)
     assert_tuple_close(got[1:6], fx["masker_run"][1:6], atol=1e-6, what="regnet stats (same skip decisions)")
-    assert_tuple_close(got[:1], fx["masker_run"][:1], atol=TOL, rtol=LOGIT_RTOL[math_mode], what="regnet logits")
+    assert_tuple_close(got[:1], fx["masker_run"][:1], atol=logit_atol(math_mode, fx["masker_run"]), rtol=LOGIT_RTOL[math_mode],
+                       what="regnet logits")
 
 
 def test_regnet_other_modes_raise():

@@ -239,6 +239,10 @@ def main():
 
     if rank == 0 and world == 1 and args.math != "fp32":
         # the same workload with fp32 operands on v_mfma_f32_32x32x2_f32 (reported beside the headline, not as `value`)
+        def grab_masks():
+            return [m for hb, _ in blocks_of(model) for m in (getattr(hb, "last_channel_mask", None), getattr(hb, "last_spatial_mask", None))
+                    if m is not None]
+        masks_head = grab_masks()
         ops.set_math_mode("fp32")
         for _ in range(2):
             out32 = step()
@@ -248,11 +252,17 @@ def main():
             out32 = step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
-        same = torch.equal(torch.as_tensor(out[5]), torch.as_tensor(out32[5]))   # per-block FLOPs ratios <=> identical masks
+        masks32 = grab_masks()
+        total = sum(m.numel() for m in masks_head)
+        flips = sum(int((a != b).sum().item()) for a, b in zip(masks_head, masks32))
+        # masker decisions are thresholds: a 1e-6 perturbation flips the few that sit on a tie, after which the two runs
+        # follow different masks -- the arithmetic parity figure is dense_emulation_gpu.max_abs_logit_diff_vs_hip_same_masks
         result["fp32_mfma_mode"] = {"value": args.batch / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt,
-                                    "max_abs_logit_diff_vs_headline_mode": (out[0] - out32[0]).abs().max().item(),
-                                    "same_masker_decisions": bool(same)}
+                                    "masker_decisions_differing_from_headline_mode": flips, "masker_decisions_total": total,
+                                    "max_abs_logit_diff_vs_headline_mode_own_masks": (out[0] - out32[0]).abs().max().item()}
         ops.set_math_mode(args.math)
+        out = step()   # leave the modules' last_*_mask in the headline mode for the same-mask parity leg below
+        torch.cuda.synchronize()
     if rank == 0 and world == 1:
         from oracle import torch_ref as TR
         if "arch" in wl:

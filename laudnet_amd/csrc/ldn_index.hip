@@ -358,10 +358,13 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
         }
         __syncthreads();
         if (hidden > 0) {
-            for (int o = tid; o < G2; o += 256) {
-                float a = b2[o];
-                for (int j = 0; j < hidden; ++j) a += w2[(size_t)o * hidden + j] * s_hid[j];
-                s_log[o] = a;
+            // one wave per output, lanes along the hidden axis: w2 rows are read as contiguous 4 * hidden bytes
+            // (a thread-per-output loop touches 64 cache lines per load instruction and dominated this kernel)
+            for (int o = wave; o < G2; o += 4) {
+                float a = 0.f;
+                for (int j = lane; j < hidden; j += 64) a += w2[(size_t)o * hidden + j] * s_hid[j];
+                a = wave_sum(a);
+                if (lane == 0) s_log[o] = a + b2[o];
             }
             __syncthreads();
         }

@@ -352,6 +352,7 @@ class Bottleneck(_PrepCache):
                        residual=identity, colsum=gap_out)
         self.last_channel_mask = mask       # kept for parity tooling (bench/tests feed it to the oracle)
         self.last_gap = gap_out
+        self.last_channel_cnt = cnt         # [B] active channels per image: mean(mask) = cnt.sum() / (B * width)
         return ops.from_nhwc(out), mask
 
     def _run_spatial(self, x, p):
@@ -443,7 +444,7 @@ class Bottleneck(_PrepCache):
             cache[key] = ((b * Hi + y) * Wi + xx).reshape(-1).to(torch.int32).contiguous()
         return cache[key]
 
-    def run_dynamic(self, x, gap_in=None, want_gap=False):
+    def run_dynamic(self, x, gap_in=None, want_gap=False, defer_stats=False):
         """Execute the block on the HIP path.  gap_in / want_gap: fused global-average-pool hand-off between
         consecutive channel-mode blocks (the conv3 epilogue leaves the channel sums the next masker needs).  Returns (out, stats[4] = {s3, s2, s1, channel sparsity} as a device
         tensor).  The FLOPs bookkeeping is separate (flops_terms) so a whole network can do it once, vectorised."""
@@ -454,6 +455,8 @@ class Bottleneck(_PrepCache):
             stats = torch.cat((ix.stats, cmask.mean().reshape(1)))
         elif self.dyn_mode == "channel":
             out, cmask = self._run_channel(x, p, gap_in, want_gap)
+            if defer_stats:   # a whole network turns the per-image channel counts of all its blocks into sparsities at once
+                return out, (self.last_channel_cnt, float(x.shape[0] * self.width))
             stats = torch.ones(4, device=x.device)
             stats[3] = cmask.mean()
         else:
@@ -605,10 +608,10 @@ class ResNet(nn.Module):
             # a channel-mode block leaves the GAP partials of its output for the next block's MLP masker
             want_gap = (nxt is not None and blk.dyn_mode == "channel" and nxt.dyn_mode == "channel"
                         and getattr(nxt.masker_channel, "accepts_fused_gap", False) and nxt.forced_channel_mask is None)
-            x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap)
+            x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap, defer_stats=True)
             gap = getattr(blk, "last_gap", None) if want_gap else None
             stats.append(st)
-        st = torch.stack(stats)                                    # [n_blocks, 4] = s3, s2, s1, cs
+        st = self._stack_stats(stats, x.device)                    # [n_blocks, 4] = s3, s2, s1, cs
         key = (str(x.device), tuple(terms))
         if getattr(self, "_terms_key", None) != key:
             self._terms_key = key
@@ -630,6 +633,32 @@ class ResNet(nn.Module):
         flops = flops + c_in * x.shape[1]
         split = lambda v: list(torch.split(v, sizes))
         return x, split(s3), split(s2), split(s1), split(cs), perc, flops
+
+    def _stack_stats(self, stats, dev):
+        """Per-block stats -> [n_blocks, 4].  Channel-mode blocks hand over (per-image channel counts, B * width):
+        their sparsity row is (1, 1, 1, cnt.sum() / (B * width)), formed for all such blocks with three small kernels
+        instead of a mean + fill + copy per block."""
+        deferred = [j for j, st in enumerate(stats) if isinstance(st, tuple)]
+        if not deferred:
+            return torch.stack(stats)
+        cs = torch.stack([stats[j][0] for j in deferred]).sum(dim=1).to(torch.float32)
+        dkey = (str(dev), tuple(stats[j][1] for j in deferred))
+        if getattr(self, "_denoms_key", None) != dkey:
+            self._denoms_key = dkey
+            self._denoms = torch.tensor(dkey[1], dtype=torch.float32, device=dev)
+        cs = cs / self._denoms
+        rows = torch.ones(len(deferred), 4, device=dev)
+        rows[:, 3] = cs
+        if len(deferred) == len(stats):
+            return rows
+        out, k = [], 0
+        for j, st in enumerate(stats):
+            if isinstance(st, tuple):
+                out.append(rows[k])
+                k += 1
+            else:
+                out.append(st)
+        return torch.stack(out)
 
     def get_optim_policies(self):
         backbone_params, masker_params = [], []

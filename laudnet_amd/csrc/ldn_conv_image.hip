@@ -275,6 +275,108 @@ __device__ __forceinline__ void tile_store(const ImgArgs& p, const Tile& t, floa
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- epilogue of k_conv_bf3 (the fp32 kernel keeps tile_resid / tile_store above)
+// Per-lane description of the 4 output rows (trow + 8 it of m-subtile mi) a lane stores in the epilogue; read from the
+// block tables once per m-subtile instead of once per tile (the table reads are dependent LDS round trips).
+struct RowInfo {
+    long orow[4];   // destination row in out / residual, -1 = no row
+    int cls[4];     // border class * BNX (offset into the shift table)
+    bool relu[4];
+};
+
+__device__ __forceinline__ void tile_rows(const ImgArgs& p, const Tile& t, int mi, int lane, RowInfo& ri) {
+    const int trow = lane >> 3;
+    int pix[4], orw[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = mi * 32 + trow + 8 * it;
+        pix[it] = t.s_pix[row];
+        ri.cls[it] = p.shift_classes > 1 ? t.s_cls[row] : 0;
+        orw[it] = p.packed ? t.s_orow[row] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = mi * 32 + trow + 8 * it;
+        ri.relu[it] = p.relu == 1 || (p.packed && (orw[it] & 0x40000000));
+        ri.orow[it] = pix[it] < 0 ? -1 : (p.packed ? (long)(orw[it] & 0x3fffffff) : (long)t.rbase + t.m0 + row);
+    }
+}
+
+// Residual operand of tile (mi, nj), 4 x 16 bytes per lane in the layout tile_store_rows consumes.  On gfx9 loads and
+// stores share vmcnt and may complete out of order with each other, so a load consumed while stores are pending waits
+// for every one of them (one such wait per tile here; requesting several tiles' residuals ahead costs registers the
+// 128-VGPR shapes do not have).
+__device__ __forceinline__ void tile_resid_rows(const ImgArgs& p, const Tile& t, const RowInfo& ri, int nj, int lane, f32x4* res) {
+    const int ccol = nj * 32 + (lane & 7) * 4;
+    const bool col_ok = t.s_nch[ccol] != -2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (col_ok && ri.orow[it] >= 0) v = *reinterpret_cast<const f32x4*>(p.residual + ri.orow[it] * p.ldr + t.n0 + ccol);
+        res[it] = v;
+    }
+}
+
+// Same epilogue as tile_store with the row table hoisted (RowInfo), the LDS reads batched two rows at a time, and
+// compiler barriers instead of fences around the transpose: LDS instructions of one wave execute in order, and a
+// release fence would also wait for every outstanding global store.
+__device__ __forceinline__ void tile_store_rows(const ImgArgs& p, const Tile& t, float* scratch, const f32x16& acc,
+                                                const RowInfo& ri, int mi, int nj, int lane, const f32x4* res) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[r];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int ccol = nj * 32 + tc4;
+    if (t.s_nch[ccol] != -2) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(t.s_sc + ccol);
+        const f32x4 ps = *reinterpret_cast<const f32x4*>(t.s_ps + ccol);
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i2 = 0; i2 < 4; i2 += 2) {
+            f32x4 v[2], sh[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {   // the LDS reads of two rows first: one round trip
+                v[u] = *reinterpret_cast<const f32x4*>(scratch + (trow + 8 * (i2 + u)) * 32 + tc4);
+                sh[u] = *reinterpret_cast<const f32x4*>(t.s_sh + ri.cls[i2 + u] + ccol);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int it = i2 + u;
+                if (ri.orow[it] < 0) continue;
+                f32x4 x = v[u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = x[e] * sc[e] + sh[u][e];
+                if (p.residual) x += res[it];
+                if (ri.relu[it]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+                }
+                x -= ps;
+                *reinterpret_cast<f32x4*>(p.out + ri.orow[it] * p.ldo + t.n0 + ccol) = x;
+                csum += x;
+            }
+        }
+        if (p.colsum) {   // fused global-average-pool partials for the NEXT block's channel masker
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = csum[e];
+                x += __shfl_xor(x, 8, 64);
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+                csum[e] = x;
+            }
+            if (trow == 0) {
+                const size_t slot = ((size_t)t.b * ceil_div(t.HWo, 32) + (t.m0 >> 5) + mi) * p.cout + t.n0 + ccol;   // dense mode only
+                *reinterpret_cast<f32x4*>(p.colsum + slot) = csum;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // MS x NS = m-subtiles x n-subtiles of 32 per block (two LDS buffers of (MS+NS)*4 KiB).
 // BMODE= weight layout / staging path:
 //        B_NK  : w[cout][taps][cin] ("n-major"), no K gather.  Tile rows = output channels (gathered through
@@ -891,15 +993,19 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
     LDN_TRACE_T(tr_epi)
 
     float* scratch = smem + wave * (32 * 32);
-    f32x4 res[2][4];
-    if (p.residual && my_am > 0 && my_cn > 0) tile_resid(p, t, wm, wn, lane, res[0]);
 #pragma unroll
-    for (int i = 0; i < AM * CN; ++i) {
-        const int a = i / CN, c = i % CN;               // compile-time after unrolling
-        const int a2 = (i + 1) / CN, c2 = (i + 1) % CN;
-        if (p.residual && i + 1 < AM * CN && a2 < my_am && c2 < my_cn)
-            tile_resid(p, t, wm + WM * a2, wn + WN * c2, lane, res[(i + 1) & 1]);
-        if (a < my_am && c < my_cn) tile_store(p, t, scratch, acc[a][c], wm + WM * a, wn + WN * c, lane, res[i & 1]);
+    for (int a = 0; a < AM; ++a) {
+        if (a >= my_am) break;
+        const int mi = wm + WM * a;
+        RowInfo ri;                      // the row table of the m-subtile is read once for all its n-subtiles
+        tile_rows(p, t, mi, lane, ri);
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+            if (c >= my_cn) break;
+            f32x4 res[4];
+            if (p.residual) tile_resid_rows(p, t, ri, wn + WN * c, lane, res);   // in flight during the tile's transpose
+            tile_store_rows(p, t, scratch, acc[a][c], ri, mi, wn + WN * c, lane, res);
+        }
     }
 #ifdef LDN_TRACE
     if (tid == 0 && g_trace) {

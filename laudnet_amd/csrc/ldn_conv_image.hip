@@ -707,6 +707,10 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
     constexpr bool KN = BMODE != B_NK;
     constexpr int BSL = BNX / 4;                           // column quads of the weight tile
     constexpr int NBT = KN ? (BSL * 4 + 255) / 256 : NS / 2;   // weight tasks per producer lane and chunk
+    // narrow k-major tiles (<= 128 columns, aligned column pairs): tasks of (column pair, octet) instead of (column
+    // quad, octet) -- 4 * BNX / 2 <= 256 tasks spread over all four producer waves instead of two
+    constexpr bool PAIR = (BMODE == B_KN4 || BMODE == B_KN2) && BNX <= 128;
+    constexpr int NPR = BNX / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Tile t;
 #ifdef LDN_TRACE
@@ -770,8 +774,18 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
         long bbase[NBT];            // B_NK: element offset of w[chn][0][0] for this lane's row, -1 = no row
         int cq[NBT], oct_kn[NBT];   // k-major: column quad / octet of task u
         int cn[NBT][BMODE == B_KN1 ? 4 : (BMODE == B_KN2 ? 2 : 1)];
+        float2 rbp[PAIR ? 8 : 1];   // PAIR: the task's 8 k rows x 2 columns
+        int pr_oct = -1, pr_col = 0, pr_chn = -1;
+        if (PAIR) {
+            const int q = wave * 64 + lane;
+            pr_oct = q / NPR;
+            pr_col = 2 * (q - pr_oct * NPR);
+            if (pr_oct >= 4 || pr_col >= nsub * 32) pr_oct = -1;
+            pr_chn = pr_oct >= 0 ? t.s_nch[pr_col] : -1;
+        }
 #pragma unroll
         for (int u = 0; u < NBT; ++u) {
+            if (PAIR) break;
             if (!KN) {
                 const int row = (wave + 4 * u) * 16 + rl;
                 const int chn = row < nsub * 32 ? t.s_nch[row] : -1;
@@ -791,6 +805,17 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
             }
         }
         auto load_b = [&](int tap, int c0) {
+            if (PAIR) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kpos = c0 + pr_oct * 8 + j;
+                    const bool kok = pr_oct >= 0 && pr_chn >= 0 && kpos < Kb;
+                    const int kc = min(max(kpos, 0), Kb - 1);
+                    const int kch = p.k_idx ? t.s_kidx[kc] : kc;
+                    rbp[j] = *reinterpret_cast<const float2*>(kok ? p.w + ((long)tap * p.cin + kch) * p.cout + pr_chn : g_zero16);
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < NBT; ++u) {
                 if (!KN) {
@@ -822,6 +847,22 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
         };
         auto store_b = [&](int buf) {
             float* bt = smem + buf * BUF + BM * BK;
+            if (PAIR) {
+                if (pr_oct >= 0) {
+                    const float* f = reinterpret_cast<const float*>(rbp);   // f[2 j + e] = row j, column e
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const f32x4 x0 = {f[e], f[2 + e], f[4 + e], f[6 + e]};
+                        const f32x4 x1 = {f[8 + e], f[10 + e], f[12 + e], f[14 + e]};
+                        bf16x8 hi, lo;
+                        split_bf16(x0, x1, hi, lo);
+                        const int row = pr_col + e, sw = (pr_col >> 1) & 7;
+                        *reinterpret_cast<bf16x8*>(bt + row * BK + ((2 * pr_oct) ^ sw) * 4) = hi;
+                        *reinterpret_cast<bf16x8*>(bt + row * BK + ((2 * pr_oct + 1) ^ sw) * 4) = lo;
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < NBT; ++u) {
                 if (!KN) {

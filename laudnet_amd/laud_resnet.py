@@ -591,9 +591,12 @@ class ResNet(nn.Module):
         c_in = x.shape[1]
         # static stem (laud_resnet.py:318-324): plain library ops, channels-last so the blocks see NHWC rows
         x = x.contiguous(memory_format=torch.channels_last)
-        x = self.relu(self.bn1(self.conv1(x)))
+        # eval-mode stem = conv with the BN folded into its weights, then max-pool, then ReLU on the pooled map
+        # (relu(maxpool(y)) == maxpool(relu(y)): both are monotone) -- two full-resolution passes fewer than conv, bn, relu
+        w, b = self._folded_stem()
+        x = F.conv2d(x, w, b, self.conv1.stride, self.conv1.padding)
         flops = c_in * x.shape[1] * x.shape[2] * x.shape[3] * self.conv1.weight.shape[2] * self.conv1.weight.shape[3]
-        x = self.maxpool(x)
+        x = self.maxpool(x).relu_()
         flops += x.shape[1] * x.shape[2] * x.shape[3] * 9
 
         # dynamic blocks: each returns its 4 sparsities as a device vector; the FLOPs bookkeeping of
@@ -633,6 +636,19 @@ class ResNet(nn.Module):
         flops = flops + c_in * x.shape[1]
         split = lambda v: list(torch.split(v, sizes))
         return x, split(s3), split(s2), split(s1), split(cs), perc, flops
+
+    def _folded_stem(self):
+        """conv1 weights scaled by bn1's eval affine (laud_resnet.py:318-320), cached until a parameter or buffer changes."""
+        bn = self.bn1
+        src = (self.conv1.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in src)
+        if getattr(self, "_stem_key", None) != key:
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                w = (self.conv1.weight * scale.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+                self._stem = (w, (bn.bias - bn.running_mean * scale).contiguous())
+            self._stem_key = key
+        return self._stem
 
     def _stack_stats(self, stats, dev):
         """Per-block stats -> [n_blocks, 4].  Channel-mode blocks hand over (per-image channel counts, B * width):

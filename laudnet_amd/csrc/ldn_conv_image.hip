@@ -900,7 +900,14 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
             issue_a(0, 0);
             adv_a();
             store_b(0);
-            if (nch > 1) { load_b(tap_b, c0_b); adv_b(); }
+            if (nch > 1) {   // both buffers are free at the start: chunk 1 is staged behind chunk 0, before barrier(0)
+                load_b(tap_b, c0_b);
+                adv_b();
+                issue_a(c0_a, 1);
+                adv_a();
+                store_b(1);
+                if (nch > 2) { load_b(tap_b, c0_b); adv_b(); }
+            }
             for (int ch = 0; ch < nch; ++ch) {
                 const int buf = ch & 1;
                 LDN_TRACE_T(tr_a)
@@ -912,7 +919,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
                 block_sync();                 // barrier(ch): chunk ch is in LDS, B(ch+1) is in VGPRs, buffer buf^1 is free
                 LDN_TRACE_T(tr_a)
                 LDN_TRACE_ADD(tr_bar, tr_b, tr_a)     // producer: waiting at the barrier for the consumers
-                if (ch + 1 < nch) {
+                if (ch >= 1 && ch + 1 < nch) {
 #if !(LDN_ABLATE & 2)
                     issue_a(c0_a, buf ^ 1);
 #endif
@@ -1130,6 +1137,8 @@ static int launch_shape(const ImgArgs& a, hipStream_t st) {
     if (nsubs <= 4) per = nsubs;               // <= 128 columns: memory-bound layers, two 64 KiB blocks per CU
     else if (hw <= 128) per = min(nsubs, 10);  // 7x7 images: wide N blocks (weights dominate the traffic)
     else if (hw <= 256 && a.n_idx) per = min(nsubs, 6);   // 14x14 images: whole image x <= 192 columns per block
+    // (measured: the wide 1x1 convs without an output list -- conv3, downsample -- are faster as two co-resident
+    //  64 KiB blocks per CU whose phases overlap than as one whole-image block: 208 vs 294 us at stage 3)
     else per = 4;
     p.bn = per * 32;
     p.ntn = ceil_div(a.cout, p.bn);

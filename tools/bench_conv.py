@@ -56,6 +56,15 @@ def main():
             "conv3": (lambda: ops.conv_image(h2, w3, sC, tC, out, k_idx=idx, k_cnt=cnt, kgran=args.gran, relu=1, residual=x),
                       float((2.0 * hw * Cin * cntf).sum()), 8.0 * B * hw * Cin + 4.0 * hw * float(cntf.sum())),
         }
+        # dense counterparts (shared n-major weights, no channel lists): what the same layers cost without skipping
+        wd1 = torch.randn(W, 1, Cin, device=dev) * 0.05
+        wd2 = torch.randn(W, 9, W, device=dev) * 0.05
+        wd3 = torch.randn(Cin, 1, W, device=dev) * 0.05
+        runs.update({
+            "dense1": (lambda: ops.conv_image(x, wd1, sW, tW, h1, relu=1), 2.0 * B * hw * Cin * W, 4.0 * B * hw * (Cin + W)),
+            "dense2": (lambda: ops.conv_image(h1, wd2, sW, tab, h2, ksize=3, stride=1, relu=1), 2.0 * B * hw * 9 * W * W, 8.0 * B * hw * W),
+            "dense3": (lambda: ops.conv_image(h2, wd3, sC, tC, out, relu=1, residual=x), 2.0 * B * hw * Cin * W, 4.0 * B * hw * (2 * Cin + W)),
+        })
         for kind in args.kinds.split(","):
             fn, flops, bytes_ = runs[kind]
             for _ in range(2):

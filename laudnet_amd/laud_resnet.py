@@ -275,6 +275,11 @@ class Bottleneck(_PrepCache):
         self.forced_spatial_mask = None
         self.forced_channel_mask = None
         self.inplace_residual = False   # set by ResNet for its own intermediate tensors
+        # how a channel-mode block is executed: "gather" = per-image channel-subset convs (MACs skipped), "dense" =
+        # shared-weight convs over multi-image row tiles with the mask applied to the conv outputs (no MACs skipped),
+        # "auto" = dense on maps of <= 64 pixels, where streaming a private weight subset per image costs more than the
+        # skipped MACs save (measured) -- the per-stage decision the reference's latency predictor encodes
+        self.channel_exec = "auto"
         self._init_cache()
 
     # ---- folded, device-resident parameters -------------------------------------------------
@@ -324,10 +329,62 @@ class Bottleneck(_PrepCache):
         return self._prep
 
     # ---- execution ----------------------------------------------------------------------------
+    def _dense_ix(self, B, Ho, Wo, dev):
+        """Index lists of an all-active batch (every pixel of every image), cached per shape: the packed-row machinery of the
+        spatial mode then is a dense convolution whose M tiles span images."""
+        key = (B, Ho, Wo, self.stride, str(dev))
+        cache = self.__dict__.setdefault("_dense_ix_cache", {})
+        if key not in cache:
+            if Ho != Wo:
+                raise LdnError("Bottleneck: dense channel execution needs square maps")
+            cache[key] = ops.mask_to_index(torch.ones(B, Ho, Wo, device=dev), Ho, Wo, self.stride)
+        return cache[key]
+
+    def _run_channel_dense(self, x, p):
+        """Channel mode without gathers: conv1/conv2 run over all channels with shared (n-major) weights on row tiles that
+        span images, their outputs u = relu(bn(.)) - c are zeroed on the masked channels of each image (exactly what the
+        gathered form stores / skips), conv3 reads the zero-filled u2.  Same channel algebra, same results."""
+        B, Cin, Hi, Wi = x.shape
+        W, gran = self.width, self.channel_dyn_granularity
+        Ho, Wo = (Hi - 1) // self.stride + 1, (Wi - 1) // self.stride + 1
+        xn = ops.as_nhwc(x)
+        mask, _, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
+        chm = mask.repeat_interleave(gran, dim=1).unsqueeze(1) if gran > 1 else mask.unsqueeze(1)   # [B,1,W]
+        dev = x.device
+        if "w2_nk" not in p:
+            with torch.no_grad():
+                p["w2_nk"] = self.conv2.weight.detach().float().permute(0, 2, 3, 1).reshape(W, 9, W).contiguous().to(dev)
+                p["w3_nk"] = self.conv3.weight.detach().float().reshape(-1, 1, W).contiguous().to(dev)
+        ix = self._dense_ix(B, Ho, Wo, dev)
+        x2d = xn.reshape(B * Hi * Wi, Cin)
+        h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
+        ops.conv_packed(x2d, p["w1"], p["s1"], p["t1"], h1, taps=1, m_cap=ix.cap1, post_sub=p["c1"], relu=1)
+        h1.view(B, -1, W).mul_(chm)
+        h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
+        ops.conv_packed(h1, p["w2_nk"], p["s2"], p["t2_tab"], h2, a_map=ix.nbr, taps=9, m_cap=ix.cap3, pix_map=ix.idx3,
+                        geom=(Hi, Wi, Ho, Wo, self.stride), post_sub=p["c2"], relu=1)
+        h2.view(B, -1, W).mul_(chm)
+        cout = p["w3_nk"].shape[0]
+        if self.downsample is not None:
+            identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
+            ops.conv_image(xn, p["wd"], p["sd"], p["td"], identity, stride=p["ds_stride"], relu=0)
+            out = identity
+        else:
+            identity = xn
+            out = xn if self.inplace_residual else torch.empty_like(xn)
+        ops.conv_packed(h2, p["w3_nk"], p["s3"], p["t3c"], out.view(B * Ho * Wo, cout), taps=1, m_cap=ix.cap3, relu=1,
+                        residual2d=identity.view(B * Ho * Wo, cout))
+        self.last_channel_mask = mask
+        self.last_gap = None
+        self.last_channel_cnt = cnt
+        return ops.from_nhwc(out), mask
+
     def _run_channel(self, x, p, gap_in=None, want_gap=False):
         B, Cin, Hi, Wi = x.shape
         W, gran = self.width, self.channel_dyn_granularity
         Ho, Wo = (Hi - 1) // self.stride + 1, (Wi - 1) // self.stride + 1
+        if self.channel_exec == "dense" or (self.channel_exec == "auto" and Ho * Wo <= 64):
+            return self._run_channel_dense(x, p)
         xn = ops.as_nhwc(x)
         if gap_in is not None and getattr(self.masker_channel, "accepts_fused_gap", False):
             mask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask, gap=gap_in)

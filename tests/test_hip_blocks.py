@@ -54,6 +54,26 @@ def test_block_injected_masks(name):
     assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what=name + " flops")
 
 
+CHANNEL_ONLY = [n for n in BUILT if BLOCKS[n]["kw"]["dyn_mode"] == "channel"]
+
+
+@pytest.mark.parametrize("exec_mode", ["gather", "dense"])
+@pytest.mark.parametrize("name", CHANNEL_ONLY)
+def test_block_channel_exec_modes(name, exec_mode):
+    """Both executions of a channel-mode block (per-image gathered subsets / dense shared-weight convs with the mask
+    applied to the outputs) reproduce the reference's masked block."""
+    fx = BLOCKS[name]
+    blk = _hip_block(fx)
+    blk.channel_exec = exec_mode
+    blk.forced_channel_mask = fx["channel_mask"].to(DEV)
+    with torch.no_grad():
+        got = blk(start_state(block_input(fx).to(DEV)), 1.0)
+    torch.cuda.synchronize()
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=TOL, what=f"{name} {exec_mode} out")
+    assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what=f"{name} {exec_mode} stats")
+    assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what=f"{name} {exec_mode} flops")
+
+
 @pytest.mark.parametrize("name", BUILT)
 def test_block_own_masker(name):
     """Masks produced by the HIP maskers.  A mask bit may legitimately flip at a numerical near-tie, so the
@@ -107,11 +127,16 @@ def _hip_model(fx):
     return model.to(DEV), x.to(DEV)
 
 
+@pytest.mark.parametrize("channel_exec", ["auto", "dense"])
 @pytest.mark.parametrize("name", FULL_BUILT)
-def test_full_model_injected(name, math_mode):
+def test_full_model_injected(name, math_mode, channel_exec):
     fx = FULL[name]
+    if channel_exec != "auto" and "channel" not in fx["kw"]["dyn_mode"]:
+        pytest.skip("no channel-mode blocks")
     model, x = _hip_model(fx)
     blocks = full_model_blocks(model)
+    for _, blk in blocks:
+        blk.channel_exec = channel_exec
     # same recipe as make_golden.injected_masks_for, via the oracle-style attribute names
     from fill import seeded_bernoulli
     for i, (bname, blk) in enumerate(blocks):

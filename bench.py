@@ -93,40 +93,47 @@ def calibrate_maskers(model, x, p_channel, p_spatial):
 
 
 class KernelTimer:
-    """HIP-event timing of selected launches on the launch stream (torch's current stream == the stream the C ABI
-    is given).  Enabled only around the dominant kernel; two event records per launch."""
+    """HIP-event timing of the channel-mode conv launches on the launch stream (torch's current stream == the stream
+    the C ABI is given): two event records per launch.  Launches are classified as
+      "conv2_3x3" : per-image channel-subset 3x3 (input and output lists)          -> MFMA roofline (FLOPs)
+      "conv3_1x1" : 1x1 with gathered input channels, dense wide output + residual -> HBM roofline (bytes)."""
 
     def __init__(self):
         self.records = []
 
-    def wrap(self, fn, select):
+    def wrap(self, fn):
         def timed(*a, **kw):
-            if not select(a, kw):
+            kind = None
+            if kw.get("ksize", 1) == 3 and kw.get("k_cnt") is not None:
+                kind = "conv2_3x3"
+            elif kw.get("ksize", 1) == 1 and kw.get("k_cnt") is not None and kw.get("n_cnt") is None:
+                kind = "conv3_1x1"
+            if kind is None:
                 return fn(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(*a, **kw)
             e1.record()
-            a_t, w = a[0], a[1]
-            self.records.append((e0, e1, kw.get("k_cnt"), kw.get("n_cnt"), tuple(a[4].shape), tuple(w.shape)))
+            self.records.append((kind, e0, e1, kw.get("k_cnt"), kw.get("n_cnt"), tuple(a[4].shape), tuple(a[1].shape),
+                                 kw.get("residual") is not None))
             return out
         return timed
 
     def summary(self):
+        """-> {kind: (launches, total ms, algorithmic FLOPs, algorithmic bytes)}.  Bytes: activations read once
+        (4 * Ho*Wo * sum_b K_b), the weight matrix once, residual read and output written once."""
         torch.cuda.synchronize()
-        tot_ms, tot_flops, n = 0.0, 0.0, 0
-        for e0, e1, kc, nc, oshape, wshape in self.records:
+        agg = {}
+        for kind, e0, e1, kc, nc, oshape, wshape, has_res in self.records:
             B, Ho, Wo, _ = oshape
-            if kc is not None:      # k-major weights [taps][cin][cout] whenever the input channels are gathered
-                taps, cin, cout = wshape
-            else:
-                cout, taps, cin = wshape
-            kb = kc.double() if kc is not None else torch.full((B,), float(cin), dtype=torch.float64)
-            nb = nc.double() if nc is not None else torch.full((B,), float(cout), dtype=torch.float64)
-            tot_flops += float((2.0 * Ho * Wo * taps * kb.cpu() * nb.cpu()).sum())
-            tot_ms += e0.elapsed_time(e1)
-            n += 1
-        return n, tot_ms, tot_flops
+            taps, cin, cout = wshape           # k-major weights [taps][cin][cout] (input channels gathered)
+            kb = kc.double().cpu()
+            nb = nc.double().cpu() if nc is not None else torch.full((B,), float(cout), dtype=torch.float64)
+            flops = float((2.0 * Ho * Wo * taps * kb * nb).sum())
+            nbytes = 4.0 * (Ho * Wo * float(kb.sum()) + taps * cin * cout + Ho * Wo * float(nb.sum()) * (2 if has_res else 1))
+            n, ms, f, by = agg.get(kind, (0, 0.0, 0.0, 0.0))
+            agg[kind] = (n + 1, ms + e0.elapsed_time(e1), f + flops, by + nbytes)
+        return agg
 
 
 def main():
@@ -138,11 +145,14 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="channel")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-emulation GPU baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-legs", action="store_true", help="product path only: no fp32 leg, no dense emulation, no CPU baseline (profiling)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (same kernels, no launch gaps)")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the MFMA convolutions (include/ldn_hip.h: ldn_set_math_mode); fp32 storage either way")
     args = ap.parse_args()
+    if args.no_legs:
+        args.no_dense = args.no_cpu = True
 
     import laudnet_amd
     from laudnet_amd import distributed as D
@@ -186,7 +196,7 @@ def main():
 
     timer = KernelTimer()
     orig_conv_image = ops.conv_image
-    ops.conv_image = timer.wrap(orig_conv_image, lambda a, k: k.get("ksize", 1) == 3)
+    ops.conv_image = timer.wrap(orig_conv_image)
 
     if world > 1:
         torch.distributed.barrier()
@@ -220,24 +230,42 @@ def main():
                    "launch": "hipGraph replay" if args.graph else "eager"},
     }
 
-    n, ms, flops = timer.summary()
-    if n:
-        achieved = flops / (ms * 1e-3) / 1e12
-        traffic = None   # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+    agg = timer.summary()
+    if agg:
+        # per-launch HBM traffic of the stage-3 instance of each kernel from the committed PMC passes (profiles/)
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if args.workload == "channel" and args.batch == 256 and os.path.exists(tj):
-            traffic = json.load(open(tj))["traffic_bytes_per_launch"]
-        if args.math == "fp32":
-            kernel, peak, extra = "k_conv_image (3x3 per-image channel-subset conv, fp32 MFMA)", F32_MFMA_PEAK_TFLOPS, {}
-        else:   # three bf16 MFMAs are executed per algorithmic product: the matrix pipe sees 3x the algorithmic FLOPs
-            kernel, peak = "k_conv_bf3 (3x3 per-image channel-subset conv, bf16x3 split-precision MFMA)", BF16_MFMA_PEAK_TFLOPS
-            extra = {"executed_mfma_tflops": 3 * achieved, "frac_executed": 3 * achieved / peak,
-                     "frac_of_fp32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS}
-        result["roofline"] = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                              "frac": achieved / peak, "traffic": traffic, "launches": n,
-                              "avg_launch_us": 1e3 * ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9, **extra}
+        traffic = json.load(open(tj)) if (args.workload == "channel" and args.batch == 256 and os.path.exists(tj)) else {}
+        mode = args.math
 
-    if rank == 0 and world == 1 and args.math != "fp32":
+        def mfma_roofline(n, ms, flops, nbytes):
+            achieved = flops / (ms * 1e-3) / 1e12
+            if mode == "fp32":
+                kernel, peak, extra = "k_conv_image (3x3 per-image channel-subset conv, fp32 MFMA)", F32_MFMA_PEAK_TFLOPS, {}
+            else:   # three bf16 MFMAs are executed per algorithmic product: the matrix pipe sees 3x the algorithmic FLOPs
+                kernel, peak = "k_conv_bf3 (3x3 per-image channel-subset conv, bf16x3 split-precision MFMA)", BF16_MFMA_PEAK_TFLOPS
+                extra = {"executed_mfma_tflops": 3 * achieved, "frac_executed": 3 * achieved / peak,
+                         "frac_of_fp32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS}
+            return {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": traffic.get(f"conv2_3x3_{mode}", {}).get("traffic_bytes_per_launch"),
+                    "traffic_scope": "stage-3 launch (22.8 GFLOP algorithmic)", "launches": n, "avg_launch_us": 1e3 * ms / n,
+                    "algorithmic_gflop_per_launch": flops / n / 1e9, **extra}
+
+        def hbm_roofline(n, ms, flops, nbytes):
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            return {"kernel": ("k_conv_image" if mode == "fp32" else "k_conv_bf3") + " (1x1 conv3: gathered input channels, "
+                              "dense wide output, residual + ReLU epilogue)", "bound": "hbm", "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic.get(f"conv3_1x1_{mode}", {}).get("traffic_bytes_per_launch"),
+                    "traffic_scope": "stage-3 launch (443 MB algorithmic)", "launches": n, "avg_launch_us": 1e3 * ms / n,
+                    "algorithmic_mbytes_per_launch": nbytes / n / 1e6, "algorithmic_tflops": flops / (ms * 1e-3) / 1e12}
+
+        objs = {k: (mfma_roofline if k == "conv2_3x3" else hbm_roofline)(*v) for k, v in agg.items()}
+        order = sorted(agg, key=lambda k: -agg[k][1])          # dominant = most time inside the timed steps
+        result["roofline"] = dict(objs[order[0]], timed_ms_per_step=agg[order[0]][1] / args.steps)
+        for k in order[1:]:
+            result["roofline_" + k] = dict(objs[k], timed_ms_per_step=agg[k][1] / args.steps)
+
+    if rank == 0 and world == 1 and args.math != "fp32" and not args.no_legs:
         # the same workload with fp32 operands on v_mfma_f32_32x32x2_f32 (reported beside the headline, not as `value`)
         def grab_masks():
             return [m for hb, _ in blocks_of(model) for m in (getattr(hb, "last_channel_mask", None), getattr(hb, "last_spatial_mask", None))

@@ -347,24 +347,53 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
         __syncthreads();
         const int n1 = hidden > 0 ? hidden : G2;     // outputs of the first (or only) layer
         float* dst1 = hidden > 0 ? s_hid : s_log;
-        for (int o = wave; o < n1; o += 4) {
-            float a = 0.f;
-            for (int c = lane; c < C; c += 64) a += w1[(size_t)o * C + c] * s_gap[c];
-            a = wave_sum(a);
+        // each wave owns outputs wave, wave + 4, ...; eight of them per pass so that their weight loads are in flight
+        // together and their cross-lane reductions interleave (per output the summation order is unchanged)
+        constexpr int OB = 8;
+        for (int o0 = wave; o0 < n1; o0 += 4 * OB) {
+            float acc[OB];
+#pragma unroll
+            for (int k = 0; k < OB; ++k) acc[k] = 0.f;
+            for (int c = lane; c < C; c += 64) {
+                const float g = s_gap[c];
+#pragma unroll
+                for (int k = 0; k < OB; ++k) {
+                    const int o = o0 + 4 * k;
+                    if (o < n1) acc[k] += w1[(size_t)o * C + c] * g;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < OB; ++k) acc[k] = wave_sum(acc[k]);
             if (lane == 0) {
-                a += b1[o];
-                dst1[o] = hidden > 0 ? fmaxf(a, 0.f) : a;
+#pragma unroll
+                for (int k = 0; k < OB; ++k) {
+                    const int o = o0 + 4 * k;
+                    if (o < n1) {
+                        const float a = acc[k] + b1[o];
+                        dst1[o] = hidden > 0 ? fmaxf(a, 0.f) : a;
+                    }
+                }
             }
         }
         __syncthreads();
         if (hidden > 0) {
-            // one wave per output, lanes along the hidden axis: w2 rows are read as contiguous 4 * hidden bytes
-            // (a thread-per-output loop touches 64 cache lines per load instruction and dominated this kernel)
-            for (int o = wave; o < G2; o += 4) {
-                float a = 0.f;
-                for (int j = lane; j < hidden; j += 64) a += w2[(size_t)o * hidden + j] * s_hid[j];
-                a = wave_sum(a);
-                if (lane == 0) s_log[o] = a + b2[o];
+            // one thread per output; its weight row is read as 16-byte vectors (consecutive instructions of a lane stay
+            // inside the same cache lines), s_hid reads are LDS broadcasts
+            for (int o = tid; o < G2; o += 256) {
+                float a = b2[o];
+                const float* wr = w2 + (size_t)o * hidden;
+                if ((hidden & 3) == 0 && (reinterpret_cast<uintptr_t>(wr) & 15) == 0) {
+                    for (int j = 0; j < hidden; j += 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(wr + j);
+                        a += v[0] * s_hid[j];
+                        a += v[1] * s_hid[j + 1];
+                        a += v[2] * s_hid[j + 2];
+                        a += v[3] * s_hid[j + 3];
+                    }
+                } else {
+                    for (int j = 0; j < hidden; ++j) a += wr[j] * s_hid[j];
+                }
+                s_log[o] = a;
             }
             __syncthreads();
         }

@@ -78,14 +78,34 @@ __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict_
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = 0.f;
     const int G2 = 2 * g;
-    for (int c = lane; c < C; c += 64) {
-        float s = 0.f;
-        for (int y = y0; y < y1; ++y)
-            for (int xx = x0; xx < x1; ++xx) s += x[((size_t)(b * Hi + y) * Wi + xx) * C + c];
-        s *= inv;
+    if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        // 16 bytes per lane: one wave instruction covers 256 channels of a pixel; the pixel loop is unrolled so that several
+        // KiB per wave are in flight (this kernel is one HBM pass over x)
+        for (int c = lane * 4; c < C; c += 256) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int y = y0; y < y1; ++y) {
+                const float* row = x + ((size_t)(b * Hi + y) * Wi) * C + c;
+#pragma unroll 8
+                for (int xx = x0; xx < x1; ++xx) s += *reinterpret_cast<const f32x4*>(row + (size_t)xx * C);
+            }
+            s *= inv;
 #pragma unroll
-        for (int o = 0; o < 8; ++o)
-            if (o < G2) acc[o] += w[o * C + c] * s;
+            for (int o = 0; o < 8; ++o)
+                if (o < G2) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + o * C + c);
+                    acc[o] += wv[0] * s[0] + wv[1] * s[1] + wv[2] * s[2] + wv[3] * s[3];
+                }
+        }
+    } else {
+        for (int c = lane; c < C; c += 64) {
+            float s = 0.f;
+            for (int y = y0; y < y1; ++y)
+                for (int xx = x0; xx < x1; ++xx) s += x[((size_t)(b * Hi + y) * Wi + xx) * C + c];
+            s *= inv;
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < G2) acc[o] += w[o * C + c] * s;
+        }
     }
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = wave_sum(acc[o]);

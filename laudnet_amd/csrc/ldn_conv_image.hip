@@ -96,7 +96,9 @@ struct Tile {
 
 // Decode blockIdx into (image, M block, N block), fill the LDS tables and synchronise the block.  Returns false
 // (for the whole block) when the block has no work.
-template <int MS, int NS>
+// TABLES = false leaves the per-column scale / post_sub / shift tables to tile_tables(), so that their (dependent)
+// gathers need not finish before the first weight loads are issued.
+template <int MS, int NS, bool TABLES = true>
 __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& o) {
     constexpr int BM = MS * 32, BNX = NS * 32;
     constexpr int BUF = (BM + BNX) * BK;
@@ -130,6 +132,11 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
         HWo = p.m_count ? min(p.m_count[0], p.m_cap) : p.m_cap;
     }
     const int m0 = mt * p.bm, n0 = nt * p.bn;
+    // the channel-list entries this thread will publish are requested BEFORE the counts they are checked against
+    // arrive (the list buffers are allocated for all cin / cout entries): one global round trip instead of two
+    int raw_n = 0, raw_k = 0;
+    if (p.n_idx && tid < BNX && n0 + tid < p.cout) raw_n = p.n_idx[(size_t)b * p.cout + n0 + tid];
+    if (p.k_idx && tid < p.cin) raw_k = p.k_idx[(size_t)b * p.cin + tid];
     const int Kb = p.k_idx ? p.k_cnt[b] : p.cin;
     const int Nb = p.n_idx ? p.n_cnt[b] : p.cout;
     const int Nb4 = min(round_up(Nb, 4), p.cout);
@@ -173,24 +180,40 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
             const int r = i / T, m = m0 + r;
             s_arow[i] = (m < HWo && r < p.bm) ? (p.a_map ? p.a_map[(size_t)(rbase + m) * T + (i - r * T)] : rbase + m) : -1;
         }
-    for (int i = tid; i < BNX; i += 512) {
-        const int j = n0 + i;
+    static_assert(BNX <= 512, "one thread per tile column");
+    if (tid < BNX) {
+        const int i = tid, j = n0 + i;
         const bool in_block = i < p.bn;
-        const int chn = (in_block && j < Nb) ? (p.n_idx ? p.n_idx[(size_t)b * p.cout + j] : j)
-                                             : ((in_block && j < Nb4) ? -1 : -2);
+        const int chn = (in_block && j < Nb) ? (p.n_idx ? raw_n : j) : ((in_block && j < Nb4) ? -1 : -2);
         s_nch[i] = chn;
-        s_sc[i] = chn >= 0 ? p.scale[chn] : 0.f;
-        s_ps[i] = (chn >= 0 && p.post_sub) ? p.post_sub[chn] : 0.f;
-        for (int c = 0; c < p.shift_classes; ++c) s_sh[c * BNX + i] = chn >= 0 ? p.shift[c * p.cout + chn] : 0.f;
+        if (TABLES) {
+            s_sc[i] = chn >= 0 ? p.scale[chn] : 0.f;
+            s_ps[i] = (chn >= 0 && p.post_sub) ? p.post_sub[chn] : 0.f;
+            for (int c = 0; c < p.shift_classes; ++c) s_sh[c * BNX + i] = chn >= 0 ? p.shift[c * p.cout + chn] : 0.f;
+        }
     }
-    if (p.k_idx)
-        for (int i = tid; i < Kb; i += 512) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
+    if (p.k_idx) {
+        if (tid < Kb) s_kidx[tid] = raw_k;
+        for (int i = tid + 512; i < Kb; i += 512) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
+    }
     __syncthreads();
     o.s_sc = s_sc; o.s_ps = s_ps; o.s_sh = s_sh; o.s_pix = s_pix; o.s_cls = s_cls; o.s_nch = s_nch; o.s_kidx = s_kidx;
     o.s_orow = s_orow; o.s_arow = s_arow;
     o.b = b; o.rbase = rbase; o.HWo = HWo; o.m0 = m0; o.n0 = n0; o.Kb = Kb; o.Nb = Nb; o.T = T; o.pad = pad;
     o.msub = msub; o.nsub = nsub;
     return true;
+}
+
+// Per-column epilogue tables of the block (see tile_setup<.., TABLES = false>): filled by `nthreads` threads numbered `idx`.
+template <int NS>
+__device__ __forceinline__ void tile_tables(const ImgArgs& p, const Tile& t, int idx, int nthreads) {
+    constexpr int BNX = NS * 32;
+    for (int i = idx; i < BNX; i += nthreads) {
+        const int chn = t.s_nch[i];
+        t.s_sc[i] = chn >= 0 ? p.scale[chn] : 0.f;
+        t.s_ps[i] = (chn >= 0 && p.post_sub) ? p.post_sub[chn] : 0.f;
+        for (int c = 0; c < p.shift_classes; ++c) t.s_sh[c * BNX + i] = chn >= 0 ? p.shift[c * p.cout + chn] : 0.f;
+    }
 }
 
 // Residual operand of tile (mi, nj) in the layout tile_store consumes (4 x 16 bytes per lane).  Issued one tile ahead of
@@ -716,13 +739,19 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
 #ifdef LDN_TRACE
     unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime(), tr_t0 = __builtin_amdgcn_s_memtime(), tr_bar = 0, tr_mma = 0, tr_iss = 0, tr_a = 0, tr_b = 0, tr_pro = 0, tr_epi = 0;
 #endif
-    if (!tile_setup<MS, NS>(p, smem, t)) return;
+    if (!tile_setup<MS, NS, false>(p, smem, t)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Kb = t.Kb, T = t.T, msub = t.msub, nsub = t.nsub;
     const int cpt = ceil_div(Kb, BK);
     const int nch = T * cpt;
+    if (wave8 < 4) {
+        // the consumers gather the epilogue tables while the producers' first loads are in flight; one extra
+        // workgroup barrier (matched in the producer prologue) publishes them
+        tile_tables<NS>(p, t, tid, 256);
+        block_sync();
+    }
 
     if (wave8 >= 4) {
         // ================================================================ producers (waves 4..7)
@@ -899,6 +928,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
             adv_b();
             issue_a(0, 0);
             adv_a();
+            block_sync();    // matches the consumers' table barrier (vmcnt(0) here costs nothing: store_b(0) needs B(0) anyway)
             store_b(0);
             if (nch > 1) {   // both buffers are free at the start: chunk 1 is staged behind chunk 0, before barrier(0)
                 load_b(tap_b, c0_b);
@@ -935,6 +965,8 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
                 LDN_TRACE_ADD(tr_iss, tr_a, tr_b)     // producer: DMA issue + weight split/store + weight load issue
             }
             block_sync();
+        } else {
+            block_sync();    // no K work at all: still match the consumers' table barrier
         }
 #ifdef LDN_TRACE
         if (tid == 256 && g_trace) {

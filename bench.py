@@ -100,6 +100,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []
+        self.rows = []
 
     def wrap(self, fn):
         def timed(*a, **kw):
@@ -119,6 +120,19 @@ class KernelTimer:
             return out
         return timed
 
+    def wrap_rows(self, fn):
+        """ops.conv_rows (shared-weight packed-row convs of the spatial / layer path): the 3x3 launches."""
+        def timed(*a, **kw):
+            if kw.get("taps", 1) != 9:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.rows.append((e0, e1, kw.get("m_count"), kw.get("m_cap"), tuple(a[1].shape)))
+            return out
+        return timed
+
     def summary(self):
         """-> {kind: (launches, total ms, algorithmic FLOPs, algorithmic bytes)}.  Bytes: activations read once
         (4 * Ho*Wo * sum_b K_b), the weight matrix once, residual read and output written once."""
@@ -133,6 +147,11 @@ class KernelTimer:
             nbytes = 4.0 * (Ho * Wo * float(kb.sum()) + taps * cin * cout + Ho * Wo * float(nb.sum()) * (2 if has_res else 1))
             n, ms, f, by = agg.get(kind, (0, 0.0, 0.0, 0.0))
             agg[kind] = (n + 1, ms + e0.elapsed_time(e1), f + flops, by + nbytes)
+        for e0, e1, mc, cap, wshape in self.rows:          # w [cout][9][cin]; rows = active output pixels of the batch
+            cout, taps, cin = wshape
+            m = float(mc.item()) if mc is not None else float(cap)
+            n, ms, f, by = agg.get("rows_3x3", (0, 0.0, 0.0, 0.0))
+            agg["rows_3x3"] = (n + 1, ms + e0.elapsed_time(e1), f + 2.0 * m * taps * cin * cout, by + 4.0 * (m * (cin + cout) + taps * cin * cout))
         return agg
 
 
@@ -147,7 +166,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-legs", action="store_true", help="product path only: no fp32 leg, no dense emulation, no CPU baseline (profiling)")
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--graph", action="store_true", help="replay the forward as one hipGraph (same kernels, no launch gaps)")
+    ap.add_argument("--graph", action="store_true", help="time the forward replayed as one hipGraph (same kernels, no launch "
+                    "gaps; per-launch HIP events, hence the roofline, need eager launches -- the default run reports the graph "
+                    "replay as the extra leg `hipgraph_replay`)")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the MFMA convolutions (include/ldn_hip.h: ldn_set_math_mode); fp32 storage either way")
     args = ap.parse_args()
@@ -197,6 +218,8 @@ def main():
     timer = KernelTimer()
     orig_conv_image = ops.conv_image
     ops.conv_image = timer.wrap(orig_conv_image)
+    orig_conv_rows = ops.conv_rows
+    ops.conv_rows = timer.wrap_rows(orig_conv_rows)
 
     if world > 1:
         torch.distributed.barrier()
@@ -209,6 +232,7 @@ def main():
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     ops.conv_image = orig_conv_image
+    ops.conv_rows = orig_conv_rows
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -259,19 +283,46 @@ def main():
                     "traffic_scope": "stage-3 launch (443 MB algorithmic)", "launches": n, "avg_launch_us": 1e3 * ms / n,
                     "algorithmic_mbytes_per_launch": nbytes / n / 1e6, "algorithmic_tflops": flops / (ms * 1e-3) / 1e12}
 
-        objs = {k: (mfma_roofline if k == "conv2_3x3" else hbm_roofline)(*v) for k, v in agg.items()}
+        objs = {k: (hbm_roofline if k == "conv3_1x1" else mfma_roofline)(*v) for k, v in agg.items()}
+        if "rows_3x3" in objs:
+            objs["rows_3x3"]["kernel"] = objs["rows_3x3"]["kernel"].replace("3x3 per-image channel-subset conv", "3x3 conv over packed active rows, shared weights")
+            objs["rows_3x3"]["traffic_scope"] = objs["rows_3x3"]["traffic"] = None
         order = sorted(agg, key=lambda k: -agg[k][1])          # dominant = most time inside the timed steps
         result["roofline"] = dict(objs[order[0]], timed_ms_per_step=agg[order[0]][1] / args.steps)
         for k in order[1:]:
             result["roofline_" + k] = dict(objs[k], timed_ms_per_step=agg[k][1] / args.steps)
 
-    if rank == 0 and world == 1 and args.math != "fp32" and not args.no_legs:
+    result.setdefault("roofline", None)   # workloads whose hot kernels are not timed per launch (RegNet grouped conv, --graph)
+    if rank == 0 and world == 1 and not args.graph and not args.no_legs:
+        # same forward, same kernels, replayed as one hipGraph (launch gaps removed)
+        try:
+            from laudnet_amd.laud_resnet import GraphedForward
+            saved = [(hb, getattr(hb, "last_channel_mask", None), getattr(hb, "last_spatial_mask", None)) for hb, _ in blocks_of(model)]
+            gf = GraphedForward(model, x, 1.0)
+            with torch.no_grad():
+                for _ in range(2):
+                    outg = gf(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    outg = gf(x)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            result["hipgraph_replay"] = {"value": args.batch / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt,
+                                         "max_abs_logit_diff_vs_eager": (outg[0] - out[0]).abs().max().item()}
+            del gf
+            for hb, cm, sm in saved:
+                hb.last_channel_mask, hb.last_spatial_mask = cm, sm
+        except Exception as e:   # informative only
+            result["hipgraph_replay"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and args.math != "fp32" and not args.no_legs and not args.graph:
         # the same workload with fp32 operands on v_mfma_f32_32x32x2_f32 (reported beside the headline, not as `value`)
         def grab_masks():
             return [m for hb, _ in blocks_of(model) for m in (getattr(hb, "last_channel_mask", None), getattr(hb, "last_spatial_mask", None))
                     if m is not None]
         masks_head = grab_masks()
         ops.set_math_mode("fp32")
+
         for _ in range(2):
             out32 = step()
         torch.cuda.synchronize()

@@ -1,4 +1,9 @@
-// k_conv_image -- channel mode: one ragged fp32-MFMA GEMM per image (gfx950 / CDNA4).
+// k_conv_image / k_conv_bf3 -- channel mode: one ragged MFMA GEMM per image (gfx950 / CDNA4), in two arithmetics:
+//   k_conv_image : fp32 operands on v_mfma_f32_32x32x2_f32 (math mode 0)
+//   k_conv_bf3   : bf16x3 split precision on v_mfma_f32_32x32x16_bf16, fp32 accumulate (math mode 1); its own header
+//                  comment further down lists what differs (weights split/transposed once per chunk by the producers,
+//                  register-blocked consumers).  Geometry, A staging, tables and the epilogue are shared.
+// This header describes the common structure as first built for the fp32 kernel.
 //
 // For image b the active channel list selects weight rows (output subset) and/or weight columns (input
 // subset) while the weight tile is staged; activations are "left-packed" (column i of image b = channel

@@ -226,7 +226,10 @@ def test_conv_image_dense(ops, B, H, cin, cout, ksize, stride):
 
 
 @pytest.mark.parametrize("B,H,cin,W,gran,stride", [(3, 14, 64, 16, 1, 1), (3, 14, 32, 16, 2, 2), (4, 7, 128, 64, 4, 1),
-                                                    (2, 28, 64, 32, 2, 1), (5, 14, 256, 256, 2, 1)])
+                                                    (2, 28, 64, 32, 2, 1), (5, 14, 256, 256, 2, 1),
+                                                    # the tile shapes of the R101 stages: 6x2 / 4x4 / 8x6 / 2x10 subtiles
+                                                    (2, 56, 64, 64, 2, 1), (3, 28, 128, 128, 2, 1), (3, 7, 512, 512, 2, 1),
+                                                    (3, 14, 256, 512, 2, 2)])
 def test_conv_image_channel_subsets(ops, B, H, cin, W, gran, stride):
     """conv1 (output subset) -> conv2 (input+output subsets, border-class shift table) -> conv3 (input subset),
     against the dense-emulation algebra of laud_resnet.py:115-133 (mask before BN)."""

@@ -52,6 +52,17 @@ def _eval_only(module: nn.Module, x: torch.Tensor):
         raise LdnError("laudnet_amd has no CPU path: move the model and input to a HIP device")
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One auxiliary stream per device for work that is independent of the main chain (projection shortcuts)."""
+    key = str(dev)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 class _PrepCache(nn.Module):
     """Mixin: lazily built, device-resident folded weights; dropped when parameters may have changed."""
 
@@ -391,19 +402,28 @@ class Bottleneck(_PrepCache):
         else:
             mask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
         dev = x.device
+        cout = p["w3"].shape[2]
+        side = None
+        if self.downsample is not None:
+            # the projection shortcut only depends on x: it runs on a side stream next to conv1 / conv2 and is joined
+            # before conv3 (a fork/join that hipGraph capture records as such)
+            identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
+            cur = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ops.conv_image(xn, p["wd"], p["sd"], p["td"], identity, stride=p["ds_stride"], relu=0)
+            out = identity
+        else:
+            identity = xn
+            out = xn if self.inplace_residual else torch.empty_like(xn)
         h1 = torch.empty(B, Hi, Wi, W, device=dev, dtype=torch.float32)
         ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1)
         h2 = torch.empty(B, Ho, Wo, W, device=dev, dtype=torch.float32)
         ops.conv_image(h1, p["w2"], p["s2"], p["t2_tab"], h2, ksize=3, stride=self.stride, k_idx=idx, k_cnt=cnt,
                        kgran=gran, n_idx=idx, n_cnt=cnt, post_sub=p["c2"], relu=1)
-        cout = p["w3"].shape[2]
-        if self.downsample is not None:
-            identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
-            ops.conv_image(xn, p["wd"], p["sd"], p["td"], identity, stride=p["ds_stride"], relu=0)
-            out = identity
-        else:
-            identity = xn
-            out = xn if self.inplace_residual else torch.empty_like(xn)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
         gap_out = torch.empty(B, (Ho * Wo + 31) // 32, cout, device=dev, dtype=torch.float32) if want_gap else None
         ops.conv_image(h2, p["w3"], p["s3"], p["t3c"], out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1,
                        residual=identity, colsum=gap_out)

@@ -374,12 +374,27 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
             float acc[OB];
 #pragma unroll
             for (int k = 0; k < OB; ++k) acc[k] = 0.f;
-            for (int c = lane; c < C; c += 64) {
-                const float g = s_gap[c];
+            if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(w1) & 15) == 0) {
+                // 16 bytes per lane: a wave instruction covers 256 consecutive weights of a row (1 KiB instead of 256 B)
+                for (int c = lane * 4; c < C; c += 256) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(s_gap + c);
 #pragma unroll
-                for (int k = 0; k < OB; ++k) {
-                    const int o = o0 + 4 * k;
-                    if (o < n1) acc[k] += w1[(size_t)o * C + c] * g;
+                    for (int k = 0; k < OB; ++k) {
+                        const int o = o0 + 4 * k;
+                        if (o < n1) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(w1 + (size_t)o * C + c);
+                            acc[k] += wv[0] * g[0] + wv[1] * g[1] + wv[2] * g[2] + wv[3] * g[3];
+                        }
+                    }
+                }
+            } else {
+                for (int c = lane; c < C; c += 64) {
+                    const float g = s_gap[c];
+#pragma unroll
+                    for (int k = 0; k < OB; ++k) {
+                        const int o = o0 + 4 * k;
+                        if (o < n1) acc[k] += w1[(size_t)o * C + c] * g;
+                    }
                 }
             }
 #pragma unroll

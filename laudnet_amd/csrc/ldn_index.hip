@@ -55,6 +55,26 @@ __device__ __forceinline__ int block_rank(bool flag, int* s_w, int& chunk_total)
     return before + r;
 }
 
+// block_rank for a block of NW waves
+template <int NW>
+__device__ __forceinline__ int block_rank_n(bool flag, int* s_w, int& chunk_total) {
+    int wtot;
+    const int r = wave_rank(flag, wtot);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();  // protect s_w from the previous call
+    if ((threadIdx.x & 63) == 0) s_w[wave] = wtot;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int v = s_w[i];
+        before += i < wave ? v : 0;
+        total += v;
+    }
+    chunk_total = total;
+    return before + r;
+}
+
 // ---------------------------------------------------------------------------------------- a1
 // one wave per (image, patch); lanes stride over channels.
 __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict__ x, int B, int Hi, int Wi, int C,
@@ -344,7 +364,8 @@ __global__ __launch_bounds__(256) void k_gap_partial(const float* __restrict__ x
     }
 }
 
-__global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ partial, int HW, int C, int splits,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_channel_mlp(const float* __restrict__ partial, int HW, int C, int splits,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       int hidden, int G, int gran, const float* __restrict__ mask_in,
@@ -354,12 +375,13 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
     float* s_gap = s_f;                 // [C]
     float* s_hid = s_gap + C;           // [max(hidden,1)]
     float* s_log = s_hid + (hidden > 0 ? hidden : 1);  // [2G]
-    __shared__ int s_w[4];
+    constexpr int NW = NT / 64;          // waves per block (one block per image)
+    __shared__ int s_w[NW];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G2 = 2 * G;
     if (!mask_in) {
         const float inv = 1.f / (float)HW;
-        for (int c = tid; c < C; c += 256) {
+        for (int c = tid; c < C; c += NT) {
             float s = 0.f;
             for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
             s_gap[c] = s * inv;
@@ -367,10 +389,10 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
         __syncthreads();
         const int n1 = hidden > 0 ? hidden : G2;     // outputs of the first (or only) layer
         float* dst1 = hidden > 0 ? s_hid : s_log;
-        // each wave owns outputs wave, wave + 4, ...; eight of them per pass so that their weight loads are in flight
+        // each wave owns outputs wave, wave + NW, ...; eight of them per pass so that their weight loads are in flight
         // together and their cross-lane reductions interleave (per output the summation order is unchanged)
         constexpr int OB = 8;
-        for (int o0 = wave; o0 < n1; o0 += 4 * OB) {
+        for (int o0 = wave; o0 < n1; o0 += NW * OB) {
             float acc[OB];
 #pragma unroll
             for (int k = 0; k < OB; ++k) acc[k] = 0.f;
@@ -380,7 +402,7 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
                     const f32x4 g = *reinterpret_cast<const f32x4*>(s_gap + c);
 #pragma unroll
                     for (int k = 0; k < OB; ++k) {
-                        const int o = o0 + 4 * k;
+                        const int o = o0 + NW * k;
                         if (o < n1) {
                             const f32x4 wv = *reinterpret_cast<const f32x4*>(w1 + (size_t)o * C + c);
                             acc[k] += wv[0] * g[0] + wv[1] * g[1] + wv[2] * g[2] + wv[3] * g[3];
@@ -392,7 +414,7 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
                     const float g = s_gap[c];
 #pragma unroll
                     for (int k = 0; k < OB; ++k) {
-                        const int o = o0 + 4 * k;
+                        const int o = o0 + NW * k;
                         if (o < n1) acc[k] += w1[(size_t)o * C + c] * g;
                     }
                 }
@@ -402,7 +424,7 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
             if (lane == 0) {
 #pragma unroll
                 for (int k = 0; k < OB; ++k) {
-                    const int o = o0 + 4 * k;
+                    const int o = o0 + NW * k;
                     if (o < n1) {
                         const float a = acc[k] + b1[o];
                         dst1[o] = hidden > 0 ? fmaxf(a, 0.f) : a;
@@ -414,7 +436,7 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
         if (hidden > 0) {
             // one thread per output; its weight row is read as 16-byte vectors (consecutive instructions of a lane stay
             // inside the same cache lines), s_hid reads are LDS broadcasts
-            for (int o = tid; o < G2; o += 256) {
+            for (int o = tid; o < G2; o += NT) {
                 float a = b2[o];
                 const float* wr = w2 + (size_t)o * hidden;
                 if ((hidden & 3) == 0 && (reinterpret_cast<uintptr_t>(wr) & 15) == 0) {
@@ -432,17 +454,17 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
             }
             __syncthreads();
         }
-        for (int j = tid; j < G; j += 256) mask[(size_t)b * G + j] = s_log[j] >= s_log[G + j] ? 1.f : 0.f;
+        for (int j = tid; j < G; j += NT) mask[(size_t)b * G + j] = s_log[j] >= s_log[G + j] ? 1.f : 0.f;
         if (logits)
-            for (int o = tid; o < G2; o += 256) logits[(size_t)b * G2 + o] = s_log[o];
+            for (int o = tid; o < G2; o += NT) logits[(size_t)b * G2 + o] = s_log[o];
     } else {
-        for (int j = tid; j < G; j += 256) mask[(size_t)b * G + j] = mask_in[(size_t)b * G + j];
+        for (int j = tid; j < G; j += NT) mask[(size_t)b * G + j] = mask_in[(size_t)b * G + j];
     }
     __syncthreads();
     // ordered compaction of the active channels (group j owns [j*gran, (j+1)*gran))
     const int width = G * gran;
     int running = 0;
-    for (int c0 = 0; c0 < width; c0 += 256) {
+    for (int c0 = 0; c0 < width; c0 += NT) {
         const int c = c0 + tid;
         bool f = false;
         if (c < width) {
@@ -450,7 +472,7 @@ __global__ __launch_bounds__(256) void k_channel_mlp(const float* __restrict__ p
             f = mask_in ? mask_in[(size_t)b * G + j] > 0.5f : s_log[j] >= s_log[G + j];
         }
         int tot;
-        const int r = block_rank(f, s_w, tot);
+        const int r = block_rank_n<NW>(f, s_w, tot);
         if (f) ch_idx[(size_t)b * width + running + r] = c;
         running += tot;
     }
@@ -623,7 +645,10 @@ extern "C" int ldn_channel_masker(const float* x, int B, int HW, int C, const fl
         LDN_CHECK_LAUNCH("k_gap_partial");
     }
     const size_t lds2 = (size_t)(C + (hidden > 0 ? hidden : 1) + 2 * G) * sizeof(float);
-    hipLaunchKernelGGL(k_channel_mlp, dim3(B), dim3(256), lds2, st, work, HW, C, splits, w1, b1, w2, b2, hidden, G, gran,
+    // one block per image; 16 waves when there is an MLP to evaluate (its phases are latency chains), 4 for a pure list build
+    if (mask_in) hipLaunchKernelGGL(k_channel_mlp<256>, dim3(B), dim3(256), lds2, st, work, HW, C, splits, w1, b1, w2, b2, hidden, G, gran,
+                                    mask_in, mask, logits, ch_idx, ch_cnt);
+    else hipLaunchKernelGGL(k_channel_mlp<1024>, dim3(B), dim3(1024), lds2, st, work, HW, C, splits, w1, b1, w2, b2, hidden, G, gran,
                        mask_in, mask, logits, ch_idx, ch_cnt);
     LDN_CHECK_LAUNCH("k_channel_mlp");
     return LDN_OK;

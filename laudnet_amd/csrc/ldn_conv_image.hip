@@ -198,8 +198,11 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
         }
     }
     if (p.k_idx) {
+        // positions Kb .. round_up(Kb, 8) name channel 0 (cin is a multiple of 8 whenever a list is given): the last,
+        // partial octet then reads valid weight rows against exact-zero activations -- no per-row validity select
         if (tid < Kb) s_kidx[tid] = raw_k;
         for (int i = tid + 512; i < Kb; i += 512) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
+        if (tid < 8 && Kb + tid < min(round_up(Kb, 8), p.cin)) s_kidx[Kb + tid] = 0;
     }
     __syncthreads();
     o.s_sc = s_sc; o.s_ps = s_ps; o.s_sh = s_sh; o.s_pix = s_pix; o.s_cls = s_cls; o.s_nch = s_nch; o.s_kidx = s_kidx;
@@ -307,10 +310,10 @@ __device__ __forceinline__ void tile_store(const ImgArgs& p, const Tile& t, floa
 // Per-lane description of the 4 output rows (trow + 8 it of m-subtile mi) a lane stores in the epilogue; read from the
 // block tables once per m-subtile instead of once per tile (the table reads are dependent LDS round trips).
 struct RowInfo {
-    long orow[4];   // destination row in out / residual, -1 = no row
-    int cls[4];     // border class * BNX (offset into the shift table)
-    bool relu[4];
+    int orow[4];    // destination row in out / residual, -1 = no row
+    int cls[4];     // border class * BNX (offset into the shift table); bit 30 = apply ReLU to this row
 };
+constexpr int ROW_RELU = 1 << 30;
 
 __device__ __forceinline__ void tile_rows(const ImgArgs& p, const Tile& t, int mi, int lane, RowInfo& ri) {
     const int trow = lane >> 3;
@@ -325,8 +328,8 @@ __device__ __forceinline__ void tile_rows(const ImgArgs& p, const Tile& t, int m
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = mi * 32 + trow + 8 * it;
-        ri.relu[it] = p.relu == 1 || (p.packed && (orw[it] & 0x40000000));
-        ri.orow[it] = pix[it] < 0 ? -1 : (p.packed ? (long)(orw[it] & 0x3fffffff) : (long)t.rbase + t.m0 + row);
+        if (p.relu == 1 || (p.packed && (orw[it] & 0x40000000))) ri.cls[it] |= ROW_RELU;
+        ri.orow[it] = pix[it] < 0 ? -1 : (p.packed ? (orw[it] & 0x3fffffff) : t.rbase + t.m0 + row);
     }
 }
 
@@ -340,7 +343,7 @@ __device__ __forceinline__ void tile_resid_rows(const ImgArgs& p, const Tile& t,
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (col_ok && ri.orow[it] >= 0) v = *reinterpret_cast<const f32x4*>(p.residual + ri.orow[it] * p.ldr + t.n0 + ccol);
+        if (col_ok && ri.orow[it] >= 0) v = *reinterpret_cast<const f32x4*>(p.residual + (size_t)ri.orow[it] * p.ldr + t.n0 + ccol);
         res[it] = v;
     }
 }
@@ -367,7 +370,7 @@ __device__ __forceinline__ void tile_store_rows(const ImgArgs& p, const Tile& t,
 #pragma unroll
             for (int u = 0; u < 2; ++u) {   // the LDS reads of two rows first: one round trip
                 v[u] = *reinterpret_cast<const f32x4*>(scratch + (trow + 8 * (i2 + u)) * 32 + tc4);
-                sh[u] = *reinterpret_cast<const f32x4*>(t.s_sh + ri.cls[i2 + u] + ccol);
+                sh[u] = *reinterpret_cast<const f32x4*>(t.s_sh + (ri.cls[i2 + u] & ~ROW_RELU) + ccol);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -377,12 +380,12 @@ __device__ __forceinline__ void tile_store_rows(const ImgArgs& p, const Tile& t,
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] * sc[e] + sh[u][e];
                 if (p.residual) x += res[it];
-                if (ri.relu[it]) {
+                if (ri.cls[it] & ROW_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
                 }
                 x -= ps;
-                *reinterpret_cast<f32x4*>(p.out + ri.orow[it] * p.ldo + t.n0 + ccol) = x;
+                *reinterpret_cast<f32x4*>(p.out + (size_t)ri.orow[it] * p.ldo + t.n0 + ccol) = x;
                 csum += x;
             }
         }
@@ -809,6 +812,9 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
         int cq[NBT], oct_kn[NBT];   // k-major: column quad / octet of task u
         int cn[NBT][BMODE == B_KN1 ? 4 : (BMODE == B_KN2 ? 2 : 1)];
         float2 rbp[PAIR ? 8 : 1];   // PAIR: the task's 8 k rows x 2 columns
+        bool pr_tail = false, kn_tail[NBT];   // staged octet lies entirely behind K: KSKIP consumers never read it
+#pragma unroll
+        for (int u = 0; u < NBT; ++u) kn_tail[u] = false;
         int pr_oct = -1, pr_col = 0, pr_chn = -1;
         if (PAIR) {
             const int q = wave * 64 + lane;
@@ -838,15 +844,32 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
                 }
             }
         }
+        // k-major weight loads: row = gathered input channel of packed position kpos (positions past Kb name channel 0 and
+        // meet zero activations), columns = the task's channels (columns without a channel read column 0: their
+        // accumulators are multiplied by a zero scale).  No validity selects, 32-bit element offsets.
+        auto kn_row = [&](unsigned tbase, const f32x4& lo4, const f32x4& hi4, int kbase, int j) -> unsigned {
+            // element offset of the weight row of packed position kbase + j (k_idx is always present in the k-major modes)
+            const int kch = p.k_idx ? __float_as_int(j < 4 ? lo4[j] : hi4[j - 4]) : min(kbase + j, p.cin - 1);
+            return (tbase + (unsigned)kch) * (unsigned)p.cout;
+        };
         auto load_b = [&](int tap, int c0) {
+            const unsigned tbase = (unsigned)tap * (unsigned)p.cin;
+            const float* kf = reinterpret_cast<const float*>(t.s_kidx);
             if (PAIR) {
+                if (pr_oct >= 0) {
+                    const int kbase = c0 + pr_oct * 8;
+                    const bool oct_tail = kbase >= Kb;          // octet entirely behind the image's K: nothing to fetch
+                    pr_tail = (kbase & ~15) >= Kb;              // ... and so is its K16 step: KSKIP consumers skip it
+                    if (!oct_tail) {
+                        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(kf + kbase), hi4 = *reinterpret_cast<const f32x4*>(kf + kbase + 4);
+                        const unsigned col = (unsigned)max(pr_chn, 0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int kpos = c0 + pr_oct * 8 + j;
-                    const bool kok = pr_oct >= 0 && pr_chn >= 0 && kpos < Kb;
-                    const int kc = min(max(kpos, 0), Kb - 1);
-                    const int kch = p.k_idx ? t.s_kidx[kc] : kc;
-                    rbp[j] = *reinterpret_cast<const float2*>(kok ? p.w + ((long)tap * p.cin + kch) * p.cout + pr_chn : g_zero16);
+                        for (int j = 0; j < 8; ++j)
+                            rbp[j] = *reinterpret_cast<const float2*>(p.w + (kn_row(tbase, lo4, hi4, kbase, j) + col));
+                    } else if (!(KSKIP && pr_tail)) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rbp[j] = make_float2(0.f, 0.f);
+                    }
                 }
                 return;
             }
@@ -857,23 +880,37 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
                     const float* src = p.w + bbase[u] + (long)tap * p.cin + c;
                     rb[u][0] = *reinterpret_cast<const f32x4*>((bbase[u] >= 0 && c < p.cin) ? src : g_zero16);
                     rb[u][1] = *reinterpret_cast<const f32x4*>((bbase[u] >= 0 && c + 4 < p.cin) ? src + 4 : g_zero16);
-                } else {
+                } else if (oct_kn[u] >= 0) {
+                    const int kbase = c0 + oct_kn[u] * 8;
+                    kn_tail[u] = (kbase & ~15) >= Kb;   // the octet's whole K16 step lies behind K: KSKIP consumers skip it
+                    if (kbase >= Kb) {                  // octet entirely behind the image's K: nothing to fetch
+                        if (!(KSKIP && kn_tail[u])) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int kpos = c0 + oct_kn[u] * 8 + j;
-                        const bool kok = oct_kn[u] >= 0 && kpos < Kb;
-                        const int kc = min(max(kpos, 0), Kb - 1);
-                        const int kch = p.k_idx ? t.s_kidx[kc] : kc;
-                        const float* wr = p.w + ((long)tap * p.cin + kch) * p.cout;
-                        if (BMODE == B_KN4) {
-                            rb[u][j] = *reinterpret_cast<const f32x4*>((kok && cn[u][0] >= 0) ? wr + cn[u][0] : g_zero16);
-                        } else if (BMODE == B_KN2) {
-                            const float2 lo = *reinterpret_cast<const float2*>((kok && cn[u][0] >= 0) ? wr + cn[u][0] : g_zero16);
-                            const float2 hi = *reinterpret_cast<const float2*>((kok && cn[u][1] >= 0) ? wr + cn[u][1] : g_zero16);
+                            for (int j = 0; j < 8; ++j) rb[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        continue;
+                    }
+                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(kf + kbase), hi4 = *reinterpret_cast<const f32x4*>(kf + kbase + 4);
+                    if (BMODE == B_KN4) {
+                        const unsigned col = (unsigned)max(cn[u][0], 0);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            rb[u][j] = *reinterpret_cast<const f32x4*>(p.w + (kn_row(tbase, lo4, hi4, kbase, j) + col));
+                    } else if (BMODE == B_KN2) {
+                        const unsigned c0l = (unsigned)max(cn[u][0], 0), c1l = (unsigned)max(cn[u][1], 0);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned ro = kn_row(tbase, lo4, hi4, kbase, j);
+                            const float2 lo = *reinterpret_cast<const float2*>(p.w + (ro + c0l));
+                            const float2 hi = *reinterpret_cast<const float2*>(p.w + (ro + c1l));
                             rb[u][j][0] = lo.x; rb[u][j][1] = lo.y; rb[u][j][2] = hi.x; rb[u][j][3] = hi.y;
-                        } else {
+                        }
+                    } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) rb[u][j][e] = *((kok && cn[u][e] >= 0) ? wr + cn[u][e] : g_zero16);
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned ro = kn_row(tbase, lo4, hi4, kbase, j);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rb[u][j][e] = p.w[ro + (unsigned)max(cn[u][e], 0)];
                         }
                     }
                 }
@@ -882,7 +919,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
         auto store_b = [&](int buf) {
             float* bt = smem + buf * BUF + BM * BK;
             if (PAIR) {
-                if (pr_oct >= 0) {
+                if (pr_oct >= 0 && !(KSKIP && pr_tail)) {
                     const float* f = reinterpret_cast<const float*>(rbp);   // f[2 j + e] = row j, column e
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
@@ -908,7 +945,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
                         *reinterpret_cast<bf16x8*>(bt + row * BK + ((2 * oct_nk) ^ sw) * 4) = hi;
                         *reinterpret_cast<bf16x8*>(bt + row * BK + ((2 * oct_nk + 1) ^ sw) * 4) = lo;
                     }
-                } else if (oct_kn[u] >= 0) {
+                } else if (oct_kn[u] >= 0 && !(KSKIP && kn_tail[u])) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {      // column e of the quad: its 8 k values sit in rb[u][0..7][e]
                         const f32x4 x0 = {rb[u][0][e], rb[u][1][e], rb[u][2][e], rb[u][3][e]};
@@ -1192,6 +1229,10 @@ static int launch_shape(const ImgArgs& a, hipStream_t st) {
 }
 
 static int dispatch_mode(const ImgArgs& p, int kgran, hipStream_t st) {
+    const long taps = p.packed ? p.ksize : (long)p.ksize * p.ksize;
+    LDN_REQUIRE(!p.k_idx || p.cin % 8 == 0, "conv: an input-channel list needs cin to be a multiple of 8 (got %d)", p.cin);
+    LDN_REQUIRE(taps * p.cin * p.cout < (1L << 31), "conv: weight tensor of %ld elements exceeds the 32-bit offsets of the weight staging",
+                taps * p.cin * p.cout);
     if (!p.k_idx) return launch_shape<B_NK>(p, st);                  // w is [cout][taps][cin]
     const int g = p.n_idx ? kgran : 4;                               // w is [taps][cin][cout]
     if (g % 4 == 0) return launch_shape<B_KN4>(p, st);

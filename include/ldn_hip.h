@@ -122,6 +122,9 @@ int ldn_channel_masker(const float* x, int B, int HW, int C, const float* w1, co
  *         border class (top|bottom<<1)*4 + (left|right<<1) of the taps that fall outside
  *   if residual: v += residual[b,p,j] ; if relu: v = max(v,0) ; if post_sub: v -= post_sub[o]
  *   out[b,p,j] = v for j < Nb (= n_cnt[b] or cout); columns Nb..roundup4(Nb)-1 are written 0.
+ *   scale == NULL (here, in ldn_conv_packed and in ldn_conv_rows) means scale[o] == 1: the caller has multiplied the
+ *   BN scale into w.  With a residual the bf16x3 kernel then starts its accumulators from the residual tile, so its
+ *   epilogue only stores (same result: v = acc + shift + residual).
  *   colsum (optional, dense output only) [B][ceil(Ho*Wo/32)][cout]: sum of out over each run of 32 pixels --
  *   the global-average-pool partials the next block's channel masker needs (a2), fused into this epilogue.
  * A columns are "left-packed": column i of image b is channel k_idx[b,i].

@@ -63,6 +63,7 @@ struct ImgArgs {
     const int32_t* pix_map;          // [rows] flat output pixel (b*Ho*Wo + oy*Wo + ox) for the border classes, or NULL
     const int32_t* relu_if_neg;      // relu == 2: ReLU only where relu_if_neg[row] < 0
     int ntn;    // N blocks per image
+    int mtn;    // M blocks per image
     int bn;     // columns per N block (multiple of 32, <= NS*32)
     int bm;     // pixels per M block (multiple of 32, <= MS*32; balanced over the image)
 };
@@ -88,6 +89,14 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_dst_wave_bas
 // workgroup barrier that also publishes this wave's LDS-DMA / ds_write traffic
 __device__ __forceinline__ void block_sync() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// consumer-side form: consumers never use LDS-DMA, and their only outstanding global loads (residual tiles requested
+// straight into the accumulators) are waited for by the compiler where the accumulators are first used
+__device__ __forceinline__ void block_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -119,11 +128,26 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
-    // image-fastest block order: with B % 8 == 0 every block of image b runs on XCD b % 8, whose L2 then holds
-    // that image's activations; the (shared) weights are resident in every XCD's L2.
-    const int b = bid % p.B;
-    const int t = bid / p.B;
-    const int nt = t % p.ntn, mt = t / p.ntn;
+    // XCD-aware block order.  Workgroups go round-robin to the 8 XCDs (XCD = bid % 8), each with its own 4 MiB L2.  A
+    // "unit" = (image, M block) owns one A tile that all of its ntn N blocks read: the N blocks of a unit get
+    // CONSECUTIVE slots of ONE XCD, so they are co-resident and the A tile comes from HBM once and from that XCD's
+    // L2 (or an in-flight miss) the other ntn - 1 times.  (With N blocks of a unit a whole batch apart in launch
+    // order, the residual / output streams evicted the tile between its uses: conv3 re-fetched A ~8x through the fabric.)
+    // Units are image-fastest, so with B % 8 == 0 everything image b touches stays on XCD b % 8.
+    // With an output-channel list the trailing N blocks of an image may be empty (Nb is data-dependent): those launches keep
+    // N slowest, so that the empty blocks sit at the end of the grid instead of taking every other dispatch slot.
+    int nt, unit;
+    if (p.n_idx) {
+        unit = bid % (p.B * p.mtn);
+        nt = bid / (p.B * p.mtn);
+        if (nt >= p.ntn) return false;
+    } else {
+        const int xcd = bid & 7, slot = bid >> 3;
+        nt = slot % p.ntn;
+        unit = (slot / p.ntn) * 8 + xcd;
+        if (unit >= p.B * p.mtn) return false;
+    }
+    const int b = unit % p.B, mt = unit / p.B;
     // rows of this image: dense mode = its Ho*Wo output pixels; packed mode = its slice of the packed row lists
     int rbase, HWo;
     if (!p.packed) {
@@ -192,7 +216,7 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
         const int chn = (in_block && j < Nb) ? (p.n_idx ? raw_n : j) : ((in_block && j < Nb4) ? -1 : -2);
         s_nch[i] = chn;
         if (TABLES) {
-            s_sc[i] = chn >= 0 ? p.scale[chn] : 0.f;
+            s_sc[i] = chn >= 0 ? (p.scale ? p.scale[chn] : 1.f) : 0.f;
             s_ps[i] = (chn >= 0 && p.post_sub) ? p.post_sub[chn] : 0.f;
             for (int c = 0; c < p.shift_classes; ++c) s_sh[c * BNX + i] = chn >= 0 ? p.shift[c * p.cout + chn] : 0.f;
         }
@@ -218,7 +242,7 @@ __device__ __forceinline__ void tile_tables(const ImgArgs& p, const Tile& t, int
     constexpr int BNX = NS * 32;
     for (int i = idx; i < BNX; i += nthreads) {
         const int chn = t.s_nch[i];
-        t.s_sc[i] = chn >= 0 ? p.scale[chn] : 0.f;
+        t.s_sc[i] = chn >= 0 ? (p.scale ? p.scale[chn] : 1.f) : 0.f;
         t.s_ps[i] = (chn >= 0 && p.post_sub) ? p.post_sub[chn] : 0.f;
         for (int c = 0; c < p.shift_classes; ++c) t.s_sh[c * BNX + i] = chn >= 0 ? p.shift[c * p.cout + chn] : 0.f;
     }
@@ -352,7 +376,7 @@ __device__ __forceinline__ void tile_resid_rows(const ImgArgs& p, const Tile& t,
 // compiler barriers instead of fences around the transpose: LDS instructions of one wave execute in order, and a
 // release fence would also wait for every outstanding global store.
 __device__ __forceinline__ void tile_store_rows(const ImgArgs& p, const Tile& t, float* scratch, const f32x16& acc,
-                                                const RowInfo& ri, int mi, int nj, int lane, const f32x4* res) {
+                                                const RowInfo& ri, int mi, int nj, int lane, const f32x4* res, bool add_res) {
     const int l31 = lane & 31, h = lane >> 5;
     const int trow = lane >> 3, tc4 = (lane & 7) * 4;
 #pragma unroll
@@ -379,7 +403,7 @@ __device__ __forceinline__ void tile_store_rows(const ImgArgs& p, const Tile& t,
                 f32x4 x = v[u];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] * sc[e] + sh[u][e];
-                if (p.residual) x += res[it];
+                if (add_res && p.residual) x += res[it];
                 if (ri.cls[it] & ROW_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
@@ -758,7 +782,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
         // the consumers gather the epilogue tables while the producers' first loads are in flight; one extra
         // workgroup barrier (matched in the producer prologue) publishes them
         tile_tables<NS>(p, t, tid, 256);
-        block_sync();
+        block_sync_lds();
     }
 
     if (wave8 >= 4) {
@@ -1028,12 +1052,36 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
     const int my_am = msub > wm ? (msub - wm + WM - 1) / WM : 0;    // m-subtiles wm, wm + WM, ...
     const int my_cn = nsub > wn ? (nsub - wn + WN - 1) / WN : 0;    // n-subtiles wn, wn + WN, ...
     f32x16 acc[AM][CN];
+    // Weights that carry the BN scale (scale == NULL): the residual tile is requested straight into the accumulators
+    // here, in MFMA C layout (register r of lane (l31, h) = row (r&3) + 8 (r>>2) + 4 h, column l31: every wave
+    // instruction fetches two whole 128-byte lines).  The loads fly during the producers' prologue and are only waited
+    // for at the first MFMA that touches the tile; the epilogue then has no load -> store dependency (on gfx9 loads
+    // and stores share vmcnt, so a residual consumed there waits for every store issued before it).
+    const bool res_acc = p.residual != nullptr && p.scale == nullptr;
 #pragma unroll
-    for (int a = 0; a < AM; ++a)
+    for (int a = 0; a < AM; ++a) {
+        long roff[16];
+        if (res_acc && a < my_am) {
 #pragma unroll
-        for (int c = 0; c < CN; ++c)
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm + WM * a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int pix = t.s_pix[row];
+                const int orw = p.packed ? (t.s_orow[row] & 0x3fffffff) : t.rbase + t.m0 + row;
+                roff[r] = pix < 0 ? -1 : (long)orw * p.ldr + t.n0;
+            }
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+        for (int c = 0; c < CN; ++c) {
+            const int col = (wn + WN * c) * 32 + l31;
+            const bool col_ok = res_acc && a < my_am && c < my_cn && t.s_nch[col] != -2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = 0.f;
+                if (col_ok && roff[r] >= 0) v = p.residual[roff[r] + col];
+                acc[a][c][r] = v;
+            }
+        }
+    }
     const int a_row = (wm * 32 + l31) * BK, b_row = (BM + wn * 32 + l31) * BK;
     int sl[BK / 16][2];                        // swizzled float offsets of this lane's two slots in K16 step ks
 #pragma unroll
@@ -1049,7 +1097,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
             const int kgroups = ceil_div(min(Kb - cin_chunk * BK, BK), 8);   // octets of this chunk that hold data
             if (++cin_chunk == cpt) cin_chunk = 0;
             LDN_TRACE_T(tr_a)
-            block_sync();                      // barrier(ch)
+            block_sync_lds();                  // barrier(ch)
             LDN_TRACE_T(tr_b)
             LDN_TRACE_ADD(tr_bar, tr_a, tr_b)
 #ifdef LDN_TRACE
@@ -1110,7 +1158,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
             LDN_TRACE_T(tr_a)
             LDN_TRACE_ADD(tr_mma, tr_b, tr_a)
         }
-        block_sync();   // every consumer is done with both buffers before buffer 0 becomes the epilogue scratch
+        block_sync_lds();   // every consumer is done with both buffers before buffer 0 becomes the epilogue scratch
     }
     LDN_TRACE_T(tr_epi)
 
@@ -1125,8 +1173,8 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
         for (int c = 0; c < CN; ++c) {
             if (c >= my_cn) break;
             f32x4 res[4];
-            if (p.residual) tile_resid_rows(p, t, ri, wn + WN * c, lane, res);   // in flight during the tile's transpose
-            tile_store_rows(p, t, scratch, acc[a][c], ri, mi, wn + WN * c, lane, res);
+            if (p.residual && !res_acc) tile_resid_rows(p, t, ri, wn + WN * c, lane, res);   // in flight during the tile's transpose
+            tile_store_rows(p, t, scratch, acc[a][c], ri, mi, wn + WN * c, lane, res, !res_acc);
         }
     }
 #ifdef LDN_TRACE
@@ -1167,7 +1215,8 @@ static int launch_bf3(const ImgArgs& p, hipStream_t st) {
     const int msubs = ceil_div(p.packed ? p.m_cap : p.Ho * p.Wo, 32);
     const int mtn = ceil_div(msubs, MS);
     q.bm = ceil_div(msubs, mtn) * 32;
-    const unsigned grid = (unsigned)p.B * mtn * p.ntn;
+    q.mtn = mtn;
+    const unsigned grid = (unsigned)round_up(p.B * mtn, 8) * p.ntn;   // units padded to the 8 XCDs (tile_setup)
     hipLaunchKernelGGL((k_conv_bf3<MS, NS, WM, BMODE, KSKIP, MINW>), dim3(grid), dim3(512), lds, st, q);
     LDN_CHECK_LAUNCH("k_conv_bf3");
     return LDN_OK;
@@ -1199,7 +1248,8 @@ static int launch_k(const ImgArgs& p, hipStream_t st) {
     const int msubs = ceil_div(p.packed ? p.m_cap : p.Ho * p.Wo, 32);
     const int mtn = ceil_div(msubs, MS);              // M blocks per image, then balance their sizes
     q.bm = ceil_div(msubs, mtn) * 32;
-    const unsigned grid = (unsigned)p.B * mtn * p.ntn;
+    q.mtn = mtn;
+    const unsigned grid = (unsigned)round_up(p.B * mtn, 8) * p.ntn;   // units padded to the 8 XCDs (tile_setup)
     hipLaunchKernelGGL((k_conv_image<MS, NS, BMODE, KSKIP, MINW>), dim3(grid), dim3(512), lds, st, q);
     LDN_CHECK_LAUNCH("k_conv_image");
     return LDN_OK;
@@ -1264,7 +1314,7 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
                               int kgran, const int32_t* n_idx, const int32_t* n_cnt, const float* scale,
                               const float* shift, int shift_classes, const float* post_sub, int relu,
                               const float* residual, int ldr, float* out, int ldo, float* colsum, void* stream) {
-    LDN_REQUIRE(a && w && scale && shift && out, "ldn_conv_image: null pointer");
+    LDN_REQUIRE(a && w && shift && out, "ldn_conv_image: null pointer");
     LDN_REQUIRE(!colsum || (!n_idx && (uintptr_t)colsum % 16 == 0), "ldn_conv_image: colsum needs a dense output and 16-byte alignment");
     LDN_REQUIRE(ksize == 1 || ksize == 3, "ldn_conv_image: ksize must be 1 or 3 (got %d)", ksize);
     LDN_REQUIRE(stride >= 1 && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "ldn_conv_image: bad geometry");
@@ -1284,7 +1334,7 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
     LDN_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "ldn_conv_image: a/w must be 16-byte aligned");
     ImgArgs p{a, lda, B, Hi, Wi, ksize, stride, Ho, Wo, w, cin, cout, k_idx, k_cnt, n_idx, n_cnt,
               scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, colsum,
-              0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+              0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     return dispatch_mode(p, kgran, static_cast<hipStream_t>(stream));
 }
 
@@ -1295,7 +1345,7 @@ extern "C" int ldn_conv_packed(const float* a, int lda, int B, const int32_t* ro
                                const int32_t* n_idx, const int32_t* n_cnt, const float* scale, const float* shift,
                                int shift_classes, const float* post_sub, int relu, const int32_t* relu_if_neg,
                                const float* residual, int ldr, float* out, int ldo, void* stream) {
-    LDN_REQUIRE(a && w && scale && shift && out, "ldn_conv_packed: null pointer");
+    LDN_REQUIRE(a && w && shift && out, "ldn_conv_packed: null pointer");
     LDN_REQUIRE(taps == 1 || taps == 9, "ldn_conv_packed: taps must be 1 or 9 (got %d)", taps);
     LDN_REQUIRE(a_map || taps == 1, "ldn_conv_packed: a_map required when taps > 1");
     LDN_REQUIRE(B >= 1 && (row_prefix || B == 1), "ldn_conv_packed: B > 1 needs row_prefix");
@@ -1315,7 +1365,7 @@ extern "C" int ldn_conv_packed(const float* a, int lda, int B, const int32_t* ro
     if (m_cap <= 0) return LDN_OK;
     ImgArgs p{a, lda, B, Hi > 0 ? Hi : 1, Wi > 0 ? Wi : 1, taps, stride >= 1 ? stride : 1, Ho > 0 ? Ho : 1, Wo > 0 ? Wo : 1,
               w, cin, cout, k_idx, k_cnt, n_idx, n_cnt, scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo,
-              nullptr, 1, row_prefix, m_count, m_cap, a_map, out_map, pix_map, relu_if_neg, 0, 0, 0};
+              nullptr, 1, row_prefix, m_count, m_cap, a_map, out_map, pix_map, relu_if_neg, 0, 0, 0, 0};
     return dispatch_mode(p, kgran, static_cast<hipStream_t>(stream));
 }
 

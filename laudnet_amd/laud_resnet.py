@@ -313,6 +313,13 @@ class Bottleneck(_PrepCache):
             p["s1"], p["t1"] = _fold_bn(self.bn1)
             p["s2"], p["t2"] = _fold_bn(self.bn2)
             p["s3"], p["t3"] = _fold_bn(self.bn3)
+            # conv3 carries bn3's scale in its weights and is called with scale=None: the kernel then starts its
+            # accumulators from the residual tile (include/ldn_hip.h, "scale == NULL")
+            w3s = w3 * p["s3"].view(-1, 1)
+            if self.dyn_mode in ("channel", "both"):
+                p["w3"] = w3s.t().reshape(1, W, -1).contiguous()
+            else:
+                p["w3"] = w3s.reshape(-1, 1, W).contiguous()
             if self.downsample is not None:
                 dconv, dbn = self.downsample[0], self.downsample[1]
                 p["wd"] = dconv.weight.detach().reshape(dconv.out_channels, 1, -1).float().contiguous()
@@ -365,7 +372,8 @@ class Bottleneck(_PrepCache):
         if "w2_nk" not in p:
             with torch.no_grad():
                 p["w2_nk"] = self.conv2.weight.detach().float().permute(0, 2, 3, 1).reshape(W, 9, W).contiguous().to(dev)
-                p["w3_nk"] = self.conv3.weight.detach().float().reshape(-1, 1, W).contiguous().to(dev)
+                p["w3_nk"] = (self.conv3.weight.detach().float().reshape(-1, W) * p["s3"].view(-1, 1).to(self.conv3.weight.device)
+                              ).reshape(-1, 1, W).contiguous().to(dev)
         ix = self._dense_ix(B, Ho, Wo, dev)
         x2d = xn.reshape(B * Hi * Wi, Cin)
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
@@ -383,7 +391,7 @@ class Bottleneck(_PrepCache):
         else:
             identity = xn
             out = xn if self.inplace_residual else torch.empty_like(xn)
-        ops.conv_packed(h2, p["w3_nk"], p["s3"], p["t3c"], out.view(B * Ho * Wo, cout), taps=1, m_cap=ix.cap3, relu=1,
+        ops.conv_packed(h2, p["w3_nk"], None, p["t3c"], out.view(B * Ho * Wo, cout), taps=1, m_cap=ix.cap3, relu=1,
                         residual2d=identity.view(B * Ho * Wo, cout))
         self.last_channel_mask = mask
         self.last_gap = None
@@ -425,7 +433,7 @@ class Bottleneck(_PrepCache):
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
         gap_out = torch.empty(B, (Ho * Wo + 31) // 32, cout, device=dev, dtype=torch.float32) if want_gap else None
-        ops.conv_image(h2, p["w3"], p["s3"], p["t3c"], out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1,
+        ops.conv_image(h2, p["w3"], None, p["t3c"], out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1,
                        residual=identity, colsum=gap_out)
         self.last_channel_mask = mask       # kept for parity tooling (bench/tests feed it to the oracle)
         self.last_gap = gap_out
@@ -463,7 +471,7 @@ class Bottleneck(_PrepCache):
             resid = out2d = x2d          # x >= 0 (post-ReLU) inside the network: inactive pixels pass through
         else:
             resid, out2d = x2d, torch.relu(x2d)
-        ops.conv_rows(h2, p["w3"], p["s3"], p["t3"], out2d, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
+        ops.conv_rows(h2, p["w3"], None, p["t3"], out2d, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
                       out_rows=ix.idx3, residual2d=resid)
         self.last_spatial_mask = patch
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), patch, ix
@@ -506,7 +514,7 @@ class Bottleneck(_PrepCache):
             resid = out2d = x2d
         else:
             resid, out2d = x2d, torch.relu(x2d)
-        ops.conv_packed(h2, p["w3"], p["s3"], p["t3c"], out2d, B=B, row_prefix=ix.pre3, m_cap=Ho * Wo, taps=1,
+        ops.conv_packed(h2, p["w3"], None, p["t3c"], out2d, B=B, row_prefix=ix.pre3, m_cap=Ho * Wo, taps=1,
                         out_map=ix.idx3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual2d=resid)
         self.last_channel_mask, self.last_spatial_mask = cmask, patch
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), cmask, ix

@@ -10,6 +10,8 @@ from . import _lib as L
 
 
 def _f32c(t, what):
+    if t is None:
+        return None
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise L.LdnError(f"{what}: expected a contiguous float32 tensor, got {t.dtype} strides {t.stride()}")
     return t

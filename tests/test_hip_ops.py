@@ -196,6 +196,11 @@ def test_conv_rows_3x3_table_scatter(ops, B, H, C, cout, stride):
     y = (want.double() @ w3[:, 0].double().T) * sc.double() + sh.double()
     want_full[idx3] = torch.relu(ident[idx3].double() + y).float()
     assert torch.allclose(res.cpu(), want_full, atol=2e-4, rtol=1e-4)
+    # scale == NULL: weights carry the BN scale, the residual tile starts the accumulators (in-place scatter form)
+    res2 = ident.clone().to(DEV)
+    ops.conv_rows(out, (w3 * sc.view(-1, 1, 1)).to(DEV), None, sh.to(DEV), res2, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3,
+                  relu=1, out_rows=ix.idx3, residual2d=res2)
+    assert torch.allclose(res2.cpu(), want_full, atol=2e-4, rtol=1e-4)
 
 
 # ------------------------------------------------------------------ per-image convolution
@@ -218,6 +223,13 @@ def test_conv_image_dense(ops, B, H, cin, cout, ksize, stride):
     want = want * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
     want = torch.relu(want.permute(0, 2, 3, 1) + resid.double()).float()
     assert torch.allclose(out.cpu(), want, atol=1e-4, rtol=1e-4)
+    # scale == NULL: BN scale multiplied into the weights by the caller, residual-initialised accumulators
+    out2 = torch.full((B, Ho, Ho, cout), float("nan"), device=DEV)
+    ws = w * sc.view(-1, 1, 1, 1)
+    ops.conv_image(x.permute(0, 2, 3, 1).contiguous().to(DEV),
+                   ws.permute(0, 2, 3, 1).reshape(cout, ksize * ksize, cin).contiguous().to(DEV), None, sh.to(DEV),
+                   out2, ksize=ksize, stride=stride, relu=1, residual=resid.to(DEV))
+    assert torch.allclose(out2.cpu(), want, atol=1e-4, rtol=1e-4)
     # fused GAP partials: sums over each run of 32 pixels (row-major), every slot written exactly once
     flat = out.cpu().reshape(B, Ho * Ho, cout).double()
     pad = (-flat.shape[1]) % 32
@@ -265,7 +277,7 @@ def test_conv_image_channel_subsets(ops, B, H, cin, W, gran, stride):
     ops.conv_image(g1, p["w2"], p["s2"], p["t2_tab"], g2, ksize=3, stride=stride, k_idx=idx, k_cnt=cnt, kgran=gran,
                    n_idx=idx, n_cnt=cnt, post_sub=p["c2"], relu=1)
     g3 = torch.empty(B, Ho, Ho, 4 * W, device=DEV)  # p['w2'] / p['w3'] are k-major here (channel mode)
-    ops.conv_image(g2, p["w3"], p["s3"], p["t3c"], g3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=0)
+    ops.conv_image(g2, p["w3"], None, p["t3c"], g3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=0)
     # unpack the left-packed h1/h2 and compare on the active channels
     cidx, ccnt = idx.cpu().long(), cnt.cpu()
     c1, c2 = p["c1"].cpu(), p["c2"].cpu()

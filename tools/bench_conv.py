@@ -53,7 +53,7 @@ def main():
             "conv2": (lambda: ops.conv_image(h1, w2, sW, tab, h2, ksize=3, stride=1, k_idx=idx, k_cnt=cnt, kgran=args.gran,
                                              n_idx=idx, n_cnt=cnt, post_sub=cW, relu=1),
                       float((2.0 * hw * 9 * cntf * cntf).sum()), 8.0 * hw * float(cntf.sum())),
-            "conv3": (lambda: ops.conv_image(h2, w3, sC, tC, out, k_idx=idx, k_cnt=cnt, kgran=args.gran, relu=1, residual=x),
+            "conv3": (lambda: ops.conv_image(h2, w3, None, tC, out, k_idx=idx, k_cnt=cnt, kgran=args.gran, relu=1, residual=x),
                       float((2.0 * hw * Cin * cntf).sum()), 8.0 * B * hw * Cin + 4.0 * hw * float(cntf.sum())),
         }
         # dense counterparts (shared n-major weights, no channel lists): what the same layers cost without skipping

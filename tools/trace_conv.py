@@ -36,7 +36,7 @@ fns = {
     "conv1": lambda: ops.conv_image(x, w1, sW, tW, h1, n_idx=idx, n_cnt=cnt, post_sub=cW, relu=1),
     "conv2": lambda: ops.conv_image(h1, w2, sW, tab, h2, ksize=3, stride=1, k_idx=idx, k_cnt=cnt, kgran=gran, n_idx=idx,
                                     n_cnt=cnt, post_sub=cW, relu=1),
-    "conv3": lambda: ops.conv_image(h2, w3, sC, tC, out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual=x),
+    "conv3": lambda: ops.conv_image(h2, w3, None, tC, out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual=x),
 }
 fn = fns[kind]
 lib = _lib.load()

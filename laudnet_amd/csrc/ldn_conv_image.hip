@@ -36,7 +36,7 @@
 #include "ldn_common.h"
 
 #ifndef LDN_ABLATE
-#define LDN_ABLATE 0   // tuning only: 1 = no MFMA, 2 = no A loads in the K loop, 4 = no weight loads, 8 = no weight split/store (results are wrong)
+#define LDN_ABLATE 0   // tuning only: 1 = no MFMA, 2 = no A loads in the K loop, 4 = no weight loads, 8 = no weight split/store, 16 = no output stores, 32 = no residual loads (results are wrong)
 #endif
 
 namespace ldn {
@@ -409,6 +409,9 @@ __device__ __forceinline__ void tile_store_rows(const ImgArgs& p, const Tile& t,
                     for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
                 }
                 x -= ps;
+#if LDN_ABLATE & 16
+                if (x[0] == 12345.678f)
+#endif
                 *reinterpret_cast<f32x4*>(p.out + (size_t)ri.orow[it] * p.ldo + t.n0 + ccol) = x;
                 csum += x;
             }
@@ -1077,7 +1080,9 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = 0.f;
+#if !(LDN_ABLATE & 32)
                 if (col_ok && roff[r] >= 0) v = p.residual[roff[r] + col];
+#endif
                 acc[a][c][r] = v;
             }
         }
@@ -1189,6 +1194,415 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
 #endif
 }
 
+// ================================================================================================ streaming 1x1 kernel
+// k_conv1x1_stream -- the wide 1x1 convolutions that close a bottleneck (conv3: gathered input channels, all output
+// channels, residual + ReLU) and the dense 1x1 projections, bf16x3 arithmetic.  Measured on k_conv_bf3 (tools/ablate):
+// with ALL of its K-loop loads, residual loads and output stores removed a stage-3 conv3 launch still took 131 of 184 us --
+// its 4096 short blocks (5 K chunks each) spend their time in per-block latency chains (lists -> weights -> first chunk,
+// two-deep staging, transposing epilogue), not on bandwidth.  This kernel removes the chains instead of the bytes:
+//   * ONE persistent workgroup owns up to 1024 consecutive output rows of an image and walks ALL of their
+//     (M block of 128 rows) x (N tile of 128 columns) x (K chunk of 32) steps as one flat sequence: set-up, channel list
+//     and row tables are paid once, and the staging pipeline never drains between tiles.
+//   * the producers only issue LDS-DMA: raw fp32 A tiles into a ring of FOUR 16 KiB slots, raw fp32 weight tiles into a
+//     ring of THREE.  Every iteration issues exactly 8 DMA instructions per producer wave and then waits with
+//     s_waitcnt vmcnt(8) -- not 0 -- so the chunk issued two iterations ago has landed while two more are in flight:
+//     memory latency is covered inside the block, not by co-resident blocks.  No load returns into a register, so no
+//     register is ever "in flight" across a loop edge.
+//   * the landed weight tile is converted LDS -> LDS by the producers (k-major tiles are transposed on the way) into the
+//     bf16 hi|lo rows the consumers read (double buffer); A is split by the consumers as in k_conv_bf3.
+//   * the residual tile is requested straight into the accumulators at the start of every tile (weights carry the BN
+//     scale, scale == NULL), and the epilogue stores straight from the MFMA C layout (lane = column: every wave store
+//     covers two whole 128-byte lines): no LDS scratch, no transposes, no load -> store dependency.
+// All producer LDS traffic is inline asm: the compiler must assume that an LDS access may alias an LDS-DMA load in
+// flight and would otherwise put s_waitcnt vmcnt(0) in front of every one of them.
+// BMODE: B_KN4 = k-major weights [cin][cout] with a per-image input-channel list (conv3 of channel / both mode),
+//        B_NK  = n-major weights [cout][cin], no lists (conv3 of spatial / layer mode, projection shortcuts, dense execution).
+constexpr int ST_BM = 128, ST_BN = 128;
+constexpr int ST_TILE = ST_BM * BK;                       // 4096 floats = 16 KiB: one A slot, one raw-B slot, one converted-B slot
+constexpr int ST_A_SLOTS = 4, ST_B_SLOTS = 3;
+constexpr int ST_OFF_BRAW = ST_A_SLOTS * ST_TILE, ST_OFF_CB = ST_OFF_BRAW + ST_B_SLOTS * ST_TILE;
+constexpr int ST_LDS_FLOATS = ST_OFF_CB + 2 * ST_TILE;    // 9 slots = 144 KiB
+constexpr int ST_MAXROWS = 1024;                          // rows per workgroup (8 M blocks)
+constexpr int ST_ROW_RELU = 1 << 30;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 8, "add the immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* ptr) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)ptr;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_write16(unsigned addr, const bf16x8& v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ int lds_read4_wait(unsigned addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// eight 8-byte / two 16-byte reads with ONE wait (the outputs are only valid after the asm block)
+__device__ __forceinline__ void lds_read8x8_wait(unsigned addr, f32x2 (&f)[8]) {
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:512\n\tds_read_b64 %2, %8 offset:1024\n\t"
+                 "ds_read_b64 %3, %8 offset:1536\n\tds_read_b64 %4, %8 offset:2048\n\tds_read_b64 %5, %8 offset:2560\n\t"
+                 "ds_read_b64 %6, %8 offset:3072\n\tds_read_b64 %7, %8 offset:3584\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
+                 : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_read4x4_wait(unsigned addr, int (&k)[4]) {   // four dwords 8 bytes apart, one wait
+    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:8\n\tds_read_b32 %2, %4 offset:16\n\tds_read_b32 %3, %4 offset:24\n\t"
+                 "s_waitcnt lgkmcnt(0)" : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_read2x16_wait(unsigned a0, unsigned a1, f32x4& x0, f32x4& x1) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(a0), "v"(a1) : "memory");
+}
+
+template <int BMODE>
+__global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
+    constexpr bool KN = BMODE != B_NK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* s_arow = reinterpret_cast<int*>(smem + ST_LDS_FLOATS);   // [ST_MAXROWS] A row (-1 = zero row)
+    int* s_orow = s_arow + ST_MAXROWS;                            // [ST_MAXROWS] out row | ROW_RELU (-1 = none)
+    int* s_kidx = s_orow + ST_MAXROWS;                            // [cin + 32] (KN only)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // image-fastest block order: with B % 8 == 0 everything image b touches stays on XCD b % 8
+    // (p.mtn row blocks per image) x (p.ntn column ranges of p.bn N tiles each: only used when there are too few rows to fill the chip)
+    const int b = blockIdx.x % p.B, jrest = blockIdx.x / p.B;
+    const int jblk = jrest % p.mtn, nt_base = (jrest / p.mtn) * p.bn;
+    int rbase, HWo;
+    if (!p.packed) { HWo = p.Ho * p.Wo; rbase = b * HWo; }
+    else if (p.row_prefix) { rbase = p.row_prefix[b]; HWo = p.row_prefix[b + 1] - rbase; }
+    else { rbase = 0; HWo = p.m_count ? min(p.m_count[0], p.m_cap) : p.m_cap; }
+    const int r0 = jblk * p.bm;                       // first row of this workgroup inside the image (multiple of 128)
+    if (r0 >= HWo) return;
+    const int nrows = min(p.bm, HWo - r0);
+    const int nmb = ceil_div(nrows, ST_BM);
+    int raw_k = 0;
+    if (KN && tid < p.cin) raw_k = p.k_idx[(size_t)b * p.cin + tid];       // requested before the count it is checked against
+    const int Kb = KN ? p.k_cnt[b] : p.cin;
+    const int Kb4 = KN ? round_up(Kb, 4) : p.cin;
+    const int cpt = max(1, ceil_div(Kb, BK));         // Kb == 0: one all-zero chunk, so that every tile still has an epilogue
+    const int ntn = min(p.bn, p.cout / ST_BN - nt_base);   // N tiles of this workgroup: nt_base .. nt_base + ntn - 1
+    const int G = nmb * ntn * cpt;                    // K chunks of this workgroup, flattened over (M block, N tile, chunk)
+
+    for (int i = tid; i < nmb * ST_BM; i += 512) {
+        const int m = r0 + i;
+        int ar = -1, orw = -1;
+        if (i < nrows) {
+            if (!p.packed) {
+                const int oy = m / p.Wo, ox = m - oy * p.Wo;
+                ar = (b * p.Hi + oy * p.stride) * p.Wi + ox * p.stride;
+                orw = rbase + m;
+            } else {
+                ar = p.a_map ? p.a_map[rbase + m] : rbase + m;
+                orw = p.out_map ? p.out_map[rbase + m] : rbase + m;
+            }
+            if (p.relu == 1 || (p.relu == 2 && p.relu_if_neg[rbase + m] < 0)) orw |= ST_ROW_RELU;
+        }
+        s_arow[i] = ar;
+        s_orow[i] = orw;
+    }
+    if (KN) {
+        // list positions Kb .. cpt * 32 name channel 0: they meet exact-zero activations (A columns >= roundup4(Kb) are staged
+        // from the zero line, columns Kb .. roundup4(Kb) were written as zeros by the producing conv)
+        if (tid < Kb) s_kidx[tid] = raw_k;
+        for (int i = tid + 512; i < Kb; i += 512) s_kidx[i] = p.k_idx[(size_t)b * p.cin + i];
+        if (tid < 32 && Kb + tid < cpt * BK) s_kidx[Kb + tid] = 0;
+    }
+    __syncthreads();
+
+    if (wave8 >= 4) {
+        // ================================================================ producers (waves 4..7)
+        const int wave = wave8 - 4;
+#ifndef LDN_STREAM_PRIO
+#define LDN_STREAM_PRIO 2
+#endif
+        __builtin_amdgcn_s_setprio(LDN_STREAM_PRIO);
+        const unsigned lds_arow = lds_addr(s_arow), lds_kidx = lds_addr(s_kidx), lds0 = lds_addr(smem);
+        // every load address is "base + (valid ? offset : offset of the zero line)": one instruction per slot, never a branch
+        const long zoff_a = g_zero16 - p.a, zoff_w = g_zero16 - p.w;
+        // ---- A (and the n-major weight tile): one wave instruction = 8 rows x 128 B; this lane moves physical slot
+        //      (lane & 7) of row (wave + 4u) * 8 + (lane >> 3), whose logical slot is slot ^ ((row >> 1) & 7)
+        const int rg = lane >> 3, pslot = lane & 7;
+        const int kq = (pslot ^ (((rg >> 1) + 4 * (wave & 1)) & 7)) * 4;
+        long aoff[4];
+        auto set_mb = [&](int mb) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ar = lds_read4_wait(lds_arow + 4u * (unsigned)(mb * ST_BM + (wave + 4 * u) * 8 + rg));
+                aoff[u] = ar < 0 ? -1 : (long)ar * p.lda;
+            }
+        };
+        int c_mb = 0, c_nt = 0, c_c0 = 0, issued = 0;   // issue cursor; past G the same instructions run on the zero line
+        auto issue = [&](int aslot, int bslot) {
+            float* abase = smem + aslot * ST_TILE;
+            float* bbase = smem + ST_OFF_BRAW + bslot * ST_TILE;
+            const bool live = issued < G;
+            ++issued;
+            const int c = c_c0 + kq;
+            const int n0 = (nt_base + c_nt) * ST_BN;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                glds16(p.a + ((!(LDN_ABLATE & 2) && live && aoff[u] >= 0 && c < Kb4) ? aoff[u] + c : zoff_a), abase + (wave + 4 * u) * 8 * BK);
+            if constexpr (KN) {
+                // raw tile [32 k rows][128 columns]: instruction q = wave + 4u covers k rows 2q, 2q+1 (512 B each)
+                // A wave DMAs exactly the rows it converts itself (octet `wave` = instructions 4 wave .. 4 wave + 3): its own
+                // vmcnt is the only thing that orders its LDS reads behind a DMA -- there is no barrier before convert()
+                const int kr = lane >> 5, col4 = (lane & 31) * 4;
+                int kchs[4];   // list entries c_c0 + 8 wave + 2u + kr, u = 0..3: 2 entries = 8 bytes apart
+                lds_read4x4_wait(lds_kidx + 4u * (unsigned)(c_c0 + 8 * wave + kr), kchs);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = 4 * wave + u;
+                    const int kch = kchs[u];
+                    glds16(p.w + ((!(LDN_ABLATE & 4) && live) ? (long)((unsigned)kch * (unsigned)p.cout + (unsigned)(n0 + col4)) : zoff_w), bbase + q * 256);
+                }
+            } else {
+                // raw tile [128 n rows][32 k]: exactly the A pattern (swizzled 128-byte rows); k positions >= cin meet zero
+                // activations, so out-of-range slots may read anything finite: the zero line
+                // a wave DMAs the 8-row groups it converts itself (rows (wave + 4t) * 16 .. + 15, t = 0, 1): see the k-major case
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int grp = 2 * (wave + 4 * (u >> 1)) + (u & 1);            // rows grp * 8 .. grp * 8 + 7
+                    const int cb_ = c_c0 + (pslot ^ (((rg >> 1) + 4 * (u & 1)) & 7)) * 4;   // logical slot of this lane in that group
+                    const long roff = (long)(n0 + grp * 8 + rg) * p.cin + cb_;
+                    glds16(p.w + ((!(LDN_ABLATE & 4) && live && cb_ < p.cin) ? roff : zoff_w), bbase + grp * 8 * BK);
+                }
+            }
+            if (issued < G) {   // advance the cursor (it parks on the last chunk once the sequence is exhausted)
+                c_c0 += BK;
+                if (c_c0 >= cpt * BK) {
+                    c_c0 = 0;
+                    if (++c_nt == ntn) { c_nt = 0; ++c_mb; set_mb(c_mb); }
+                }
+            }
+        };
+        // landed raw weight tile -> bf16 hi|lo rows [n][4 octets x (8 hi | 8 lo)], slots XOR-swizzled like the A rows
+        const int rl = ((lane & 7) << 1) | (lane >> 5), oct_nk = (lane >> 3) & 3;
+        auto convert = [&](int bslot, int cslot) {
+            const unsigned raw = lds0 + 4u * (unsigned)(ST_OFF_BRAW + bslot * ST_TILE);
+            const unsigned cb = lds0 + 4u * (unsigned)(ST_OFF_CB + cslot * ST_TILE);
+            const int sw = lane & 7;
+            if constexpr (KN) {
+                // task (octet = wave, column pair = lane): 8 k rows x 2 columns, transposed in registers
+                f32x2 f[8];
+                lds_read8x8_wait(raw + (unsigned)(wave * 8 * 512 + lane * 8), f);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const f32x4 x0 = {f[0][e], f[1][e], f[2][e], f[3][e]};
+                    const f32x4 x1 = {f[4][e], f[5][e], f[6][e], f[7][e]};
+                    bf16x8 hi, lo;
+                    split_bf16(x0, x1, hi, lo);
+                    const int row = 2 * lane + e;     // (row >> 1) & 7 == lane & 7
+                    lds_write16(cb + 4u * (unsigned)(row * BK + ((2 * wave) ^ sw) * 4), hi);
+                    lds_write16(cb + 4u * (unsigned)(row * BK + ((2 * wave + 1) ^ sw) * 4), lo);
+                }
+            } else {
+                // two (row, octet) tasks per lane: row = (wave + 4t) * 16 + rl ((row >> 1) & 7 == lane & 7), 8 consecutive k
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = (wave + 4 * t) * 16 + rl;
+                    f32x4 x0, x1;
+                    lds_read2x16_wait(raw + 4u * (unsigned)(row * BK + ((2 * oct_nk) ^ sw) * 4),
+                                      raw + 4u * (unsigned)(row * BK + ((2 * oct_nk + 1) ^ sw) * 4), x0, x1);
+                    bf16x8 hi, lo;
+                    split_bf16(x0, x1, hi, lo);
+                    lds_write16(cb + 4u * (unsigned)(row * BK + ((2 * oct_nk) ^ sw) * 4), hi);
+                    lds_write16(cb + 4u * (unsigned)(row * BK + ((2 * oct_nk + 1) ^ sw) * 4), lo);
+                }
+            }
+        };
+        // iteration i (i = -3 .. G-1): [barrier(i)] ; chunk i+1 has landed ; weights(i+1): raw -> converted buffer (i+1) & 1 ;
+        // issue chunk i+3 ; publish.  A(i+3) overwrites chunk i-1, which the consumers left before barrier(i); the raw
+        // weight slot of chunk i+3 was converted at iteration i-1.
+        set_mb(0);
+        int tile_cc = 0;
+        for (int i = -3; i < G; ++i) {
+            if (i >= 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+#ifdef LDN_STREAM_SAFE
+            wait_vmcnt<0>();
+#else
+            wait_vmcnt<8>();      // the 8 DMA instructions of iteration i-1 (chunk i+2) may still fly; chunk i+1 is in
+#endif
+#if !(LDN_ABLATE & 8)
+            if (i >= -1 && i + 1 < G) convert((i + 1) % ST_B_SLOTS, (i + 1) & 1);
+#endif
+            issue((i + 3) & 3, (i + 3) % ST_B_SLOTS);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (i >= 0 && ++tile_cc == cpt) {   // chunk i closes a tile: barrier E of the consumers' epilogue
+                tile_cc = 0;
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        wait_vmcnt<0>();     // no LDS-DMA may be in flight when the workgroup's LDS is released
+        return;
+    }
+
+    // ==================================================================== consumers (waves 0..3): 2 x 2 wave grid
+    const int wave = wave8;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int swl = (l31 >> 1) & 7;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int a_row = (wm * 32 + l31) * BK, b_row = (wn * 32 + l31) * BK;
+    int sl[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        sl[ks][0] = ((4 * ks + 2 * h) ^ swl) * 4;
+        sl[ks][1] = ((4 * ks + 2 * h + 1) ^ swl) * 4;
+    }
+    const bool res_acc = p.residual != nullptr;
+    f32x16 acc[2][2];
+    int g = 0;
+    for (int mb = 0; mb < nmb; ++mb) {
+        for (int nt = 0; nt < ntn; ++nt) {
+            const int n0 = (nt_base + nt) * ST_BN;
+            // ---- tile start: the residual of the whole tile is requested now, 16 bytes per lane in the layout the epilogue
+            //      stores in (lane = row trow + 8 it, 4 consecutive channels), and only consumed a K loop later: by then the
+            //      loads AND the previous tile's stores have long completed (on gfx9 loads and stores share vmcnt, so a
+            //      load consumed while stores are pending waits for every one of them)
+            const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+            f32x4 res[2][2][4];
+            int orw[2][4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) orw[a][it] = s_orow[mb * ST_BM + (wm + 2 * a) * 32 + trow + 8 * it];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int ccol = n0 + (wn + 2 * c) * 32 + tc4;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        // rows without a pixel (and launches without a residual) read the zero line: no branches
+                        const float* src = (!(LDN_ABLATE & 32) && res_acc && orw[a][it] >= 0)
+                                               ? p.residual + (size_t)(orw[a][it] & (ST_ROW_RELU - 1)) * p.ldr + ccol : g_zero16;
+                        res[a][c][it] = *reinterpret_cast<const f32x4*>(src);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+                }
+            }
+            // ---- K loop of the tile
+            for (int cc = 0; cc < cpt; ++cc, ++g) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();          // barrier(g): A(g) is in slot g % 4, its weights in buffer g % 2
+                asm volatile("" ::: "memory");
+#if LDN_ABLATE & 1
+                continue;
+#endif
+                const float* tb = smem + (g & 3) * ST_TILE;                 // A slot of chunk g
+                const float* tw = smem + ST_OFF_CB + (g & 1) * ST_TILE;     // converted weights of chunk g
+                const int krem = Kb - cc * BK;         // K positions of this chunk that hold data
+                f32x4 ar[2][2];
+                bf16x8 bh, bl;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    ar[a][0] = *reinterpret_cast<const f32x4*>(tb + a_row + a * (64 * BK) + sl[0][0]);
+                    ar[a][1] = *reinterpret_cast<const f32x4*>(tb + a_row + a * (64 * BK) + sl[0][1]);
+                }
+                bh = *reinterpret_cast<const bf16x8*>(tw + b_row + sl[0][0]);
+                bl = *reinterpret_cast<const bf16x8*>(tw + b_row + sl[0][1]);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks == 1 && krem <= 16) break;
+                    bf16x8 ah[2], al[2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) split_bf16(ar[a][0], ar[a][1], ah[a], al[a]);
+                    if (ks == 0) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            ar[a][0] = *reinterpret_cast<const f32x4*>(tb + a_row + a * (64 * BK) + sl[1][0]);
+                            ar[a][1] = *reinterpret_cast<const f32x4*>(tb + a_row + a * (64 * BK) + sl[1][1]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const bf16x8 ch_ = bh, cl_ = bl;
+                        if (c == 0) {
+                            bh = *reinterpret_cast<const bf16x8*>(tw + b_row + 64 * BK + sl[ks][0]);
+                            bl = *reinterpret_cast<const bf16x8*>(tw + b_row + 64 * BK + sl[ks][1]);
+                        } else if (ks == 0) {
+                            bh = *reinterpret_cast<const bf16x8*>(tw + b_row + sl[1][0]);
+                            bl = *reinterpret_cast<const bf16x8*>(tw + b_row + sl[1][1]);
+                        }
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], ch_, acc[a][c], 0, 0, 0);
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], cl_, acc[a][c], 0, 0, 0);
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], ch_, acc[a][c], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // ---- epilogue.  Barrier E (matched by the producers at every tile end): every consumer has left the A slot of
+            //      the tile's last chunk, which nobody refills before barrier(g) -- it is the scratch of the per-wave 32x32
+            //      transposes that turn the MFMA C layout (lane = column) into 16 bytes per lane along the channel axis.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            float* scratch = smem + ((g - 1) & 3) * ST_TILE + wave * 1024;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#if LDN_ABLATE & 64
+                if (acc[a][0][0] != 12345.678f) continue;
+#endif
+                const int mi = wm + 2 * a;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int ccol = n0 + (wn + 2 * c) * 32 + tc4;
+                    const f32x4 sh4 = *reinterpret_cast<const f32x4*>(p.shift + ccol);
+                    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f};
+                    if (p.scale) sc4 = *reinterpret_cast<const f32x4*>(p.scale + ccol);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[a][c][r];
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 v[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const f32x4*>(scratch + (trow + 8 * it) * 32 + tc4);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int o = orw[a][it];
+                        f32x4 x = v[it] * sc4 + sh4 + res[a][c][it];
+                        if (o & ST_ROW_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+                        }
+                        if (o >= 0) {
+#if LDN_ABLATE & 16
+                            if (x[0] == 12345.678f)
+#endif
+                            *reinterpret_cast<f32x4*>(p.out + (size_t)(o & (ST_ROW_RELU - 1)) * p.ldo + ccol) = x;
+                            csum += x;
+                        }
+                    }
+                    if (p.colsum) {   // fused global-average-pool partials of the 32-pixel subtile (dense image mode only)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = csum[e];
+                            x += __shfl_xor(x, 8, 64);
+                            x += __shfl_xor(x, 16, 64);
+                            x += __shfl_xor(x, 32, 64);
+                            csum[e] = x;
+                        }
+                        const int sub = ((r0 + mb * ST_BM) >> 5) + mi;
+                        if (trow == 0 && sub * 32 < HWo)
+                            *reinterpret_cast<f32x4*>(p.colsum + ((size_t)b * ceil_div(HWo, 32) + sub) * p.cout + ccol) = csum;
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host
 static int g_math_mode = -1;   // 0 = fp32 MFMA, 1 = bf16x3 split precision (initial value from env LDN_MATH_MODE)
 static int math_mode() {
@@ -1278,11 +1692,52 @@ static int launch_shape(const ImgArgs& a, hipStream_t st) {
     return launch_k<4, 10, BMODE, false>(p, st);
 }
 
+// rows per workgroup of k_conv1x1_stream (tuning: env LDN_STREAM_ROWS, multiple of 128, <= 1024; 0 disables the kernel)
+static int stream_rows() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LDN_STREAM_ROWS");
+        v = e ? atoi(e) : 512;
+        if (v > ST_MAXROWS) v = ST_MAXROWS;
+    }
+    return v;
+}
+
+template <int BMODE>
+static int launch_stream(const ImgArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)ST_LDS_FLOATS * sizeof(float) + (size_t)(2 * ST_MAXROWS + p.cin + 32) * sizeof(int);
+    LDN_REQUIRE(lds <= 160 * 1024, "k_conv1x1_stream: %zu B of LDS exceed 160 KiB", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_conv1x1_stream<BMODE>), lds),
+                "k_conv1x1_stream: cannot reserve %zu B of LDS", lds);
+    ImgArgs q = p;
+    const int rows = p.packed ? p.m_cap : p.Ho * p.Wo;
+    int rpb = stream_rows();                           // rows per workgroup: fewer when that is needed to fill the chip
+    while (rpb > ST_BM && p.B * ceil_div(rows, rpb) < 512) rpb /= 2;
+    int nblk = ceil_div(rows, rpb);
+    q.bm = round_up(ceil_div(rows, nblk), ST_BM);      // balanced, whole M blocks
+    nblk = ceil_div(rows, q.bm);
+    q.mtn = nblk;
+    // too few row blocks to fill the chip (shared-weight launches over a few thousand packed rows): split the N tiles too
+    const int ntiles = p.cout / ST_BN;
+    int nsplit = 1;
+    while (p.B * nblk * nsplit < 512 && nsplit < ntiles) nsplit *= 2;
+    q.bn = ceil_div(ntiles, nsplit);
+    q.ntn = ceil_div(ntiles, q.bn);
+    hipLaunchKernelGGL((k_conv1x1_stream<BMODE>), dim3((unsigned)p.B * nblk * q.ntn), dim3(512), lds, st, q);
+    LDN_CHECK_LAUNCH("k_conv1x1_stream");
+    return LDN_OK;
+}
+
 static int dispatch_mode(const ImgArgs& p, int kgran, hipStream_t st) {
     const long taps = p.packed ? p.ksize : (long)p.ksize * p.ksize;
     LDN_REQUIRE(!p.k_idx || p.cin % 8 == 0, "conv: an input-channel list needs cin to be a multiple of 8 (got %d)", p.cin);
     LDN_REQUIRE(taps * p.cin * p.cout < (1L << 31), "conv: weight tensor of %ld elements exceeds the 32-bit offsets of the weight staging",
                 taps * p.cin * p.cout);
+    // wide 1x1 convolutions without an output-channel list: the persistent streaming kernel (bf16x3 arithmetic only)
+    if (math_mode() == 1 && stream_rows() >= ST_BM && taps == 1 && !p.n_idx && !p.post_sub && p.shift_classes == 1 &&
+        p.cout % ST_BN == 0 && p.cout >= 2 * ST_BN && !(p.residual && p.scale) && p.cin <= 1024 &&
+        (p.packed ? p.m_cap : p.Ho * p.Wo) >= 96)   // (7x7 images would leave most of every 128-row M block empty)
+        return p.k_idx ? launch_stream<B_KN4>(p, st) : launch_stream<B_NK>(p, st);
     if (!p.k_idx) return launch_shape<B_NK>(p, st);                  // w is [cout][taps][cin]
     const int g = p.n_idx ? kgran : 4;                               // w is [taps][cin][cout]
     if (g % 4 == 0) return launch_shape<B_KN4>(p, st);

@@ -71,6 +71,7 @@ struct ImgArgs {
 constexpr int BK = 32;   // K chunk = one 128-byte LDS row
 
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float g_one16[4] = {1.f, 1.f, 1.f, 1.f};
 
 #ifdef LDN_TRACE   // tuning only: per-block timestamps {t0, t1, hw_id, xcc_id, ntiles | barrier wait, mma | issue}
 __device__ unsigned long long* g_trace = nullptr;
@@ -240,6 +241,8 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
 template <int NS>
 __device__ __forceinline__ void tile_tables(const ImgArgs& p, const Tile& t, int idx, int nthreads) {
     constexpr int BNX = NS * 32;
+    // (issuing all of these gathers unconditionally and selecting afterwards measured 3-7 % SLOWER: the burst competes with
+    //  the producers' first weight loads, which are on the critical path; the conditional form trickles behind them)
     for (int i = idx; i < BNX; i += nthreads) {
         const int chn = t.s_nch[i];
         t.s_sc[i] = chn >= 0 ? (p.scale ? p.scale[chn] : 1.f) : 0.f;
@@ -1469,6 +1472,13 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
             const int trow = lane >> 3, tc4 = (lane & 7) * 4;
             f32x4 res[2][2][4];
             int orw[2][4];
+            f32x4 sh4[2], sc4[2];       // per-column epilogue constants: requested here for the same reason
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int ccol = n0 + (wn + 2 * c) * 32 + tc4;
+                sh4[c] = *reinterpret_cast<const f32x4*>(p.shift + ccol);
+                sc4[c] = *reinterpret_cast<const f32x4*>(p.scale ? p.scale + ccol : g_one16);
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -1555,9 +1565,6 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int ccol = n0 + (wn + 2 * c) * 32 + tc4;
-                    const f32x4 sh4 = *reinterpret_cast<const f32x4*>(p.shift + ccol);
-                    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f};
-                    if (p.scale) sc4 = *reinterpret_cast<const f32x4*>(p.scale + ccol);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[a][c][r];
                     asm volatile("" ::: "memory");
@@ -1569,7 +1576,7 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int o = orw[a][it];
-                        f32x4 x = v[it] * sc4 + sh4 + res[a][c][it];
+                        f32x4 x = v[it] * sc4[c] + sh4[c] + res[a][c][it];
                         if (o & ST_ROW_RELU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);

@@ -1022,16 +1022,21 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
                 LDN_TRACE_T(tr_a)
                 LDN_TRACE_ADD(tr_bar, tr_b, tr_a)     // producer: waiting at the barrier for the consumers
                 if (ch >= 1 && ch + 1 < nch) {
-#if !(LDN_ABLATE & 2)
-                    issue_a(c0_a, buf ^ 1);
-#endif
-                    adv_a();
+                    // Order matters: the compiler must assume that an LDS access may alias an LDS-DMA load in flight and puts
+                    // s_waitcnt vmcnt(0) in front of the first ds_write / ds_read that follows one.  With the A tile's DMA
+                    // issued FIRST, the weight split/store (ds_write) and the channel-list reads of load_b (ds_read) each
+                    // waited for it, and only then were the weight loads issued: two memory latencies in series per chunk.
+                    // LDS work first, then every load of the iteration back to back, one wait at the barrier.
 #if !(LDN_ABLATE & 8)
                     store_b(buf ^ 1);
 #endif
 #if !(LDN_ABLATE & 4)
                     if (ch + 2 < nch) { load_b(tap_b, c0_b); adv_b(); }
 #endif
+#if !(LDN_ABLATE & 2)
+                    issue_a(c0_a, buf ^ 1);
+#endif
+                    adv_a();
                 }
                 LDN_TRACE_T(tr_b)
                 LDN_TRACE_ADD(tr_iss, tr_a, tr_b)     // producer: DMA issue + weight split/store + weight load issue

@@ -276,7 +276,7 @@ def main():
 
         def hbm_roofline(n, ms, flops, nbytes):
             achieved = nbytes / (ms * 1e-3) / 1e9
-            return {"kernel": ("k_conv_image" if mode == "fp32" else "k_conv_bf3") + " (1x1 conv3: gathered input channels, "
+            return {"kernel": ("k_conv_image" if mode == "fp32" else "k_conv1x1_stream") + " (1x1 conv3: gathered input channels, "
                               "dense wide output, residual + ReLU epilogue)", "bound": "hbm", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic.get(f"conv3_1x1_{mode}", {}).get("traffic_bytes_per_launch"),

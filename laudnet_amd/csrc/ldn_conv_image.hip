@@ -1225,6 +1225,9 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
 // flight and would otherwise put s_waitcnt vmcnt(0) in front of every one of them.
 // BMODE: B_KN4 = k-major weights [cin][cout] with a per-image input-channel list (conv3 of channel / both mode),
 //        B_NK  = n-major weights [cout][cin], no lists (conv3 of spatial / layer mode, projection shortcuts, dense execution).
+#ifndef LDN_STREAM_NT
+#define LDN_STREAM_NT 3   // 1: residual loads non-temporal, 2: output stores non-temporal.  Both stream through the XCD's L2 exactly
+#endif                    // once; without the hint they evict the A tile / weight rows every N tile re-reads (measured: 20.0 -> 19.6 ms per step)
 constexpr int ST_BM = 128, ST_BN = 128;
 constexpr int ST_TILE = ST_BM * BK;                       // 4096 floats = 16 KiB: one A slot, one raw-B slot, one converted-B slot
 constexpr int ST_A_SLOTS = 4, ST_B_SLOTS = 3;
@@ -1496,7 +1499,11 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
                         // rows without a pixel (and launches without a residual) read the zero line: no branches
                         const float* src = (!(LDN_ABLATE & 32) && res_acc && orw[a][it] >= 0)
                                                ? p.residual + (size_t)(orw[a][it] & (ST_ROW_RELU - 1)) * p.ldr + ccol : g_zero16;
+#if LDN_STREAM_NT & 1
+                        res[a][c][it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+#else
                         res[a][c][it] = *reinterpret_cast<const f32x4*>(src);
+#endif
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
@@ -1590,7 +1597,11 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
 #if LDN_ABLATE & 16
                             if (x[0] == 12345.678f)
 #endif
+#if LDN_STREAM_NT & 2
+                            __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p.out + (size_t)(o & (ST_ROW_RELU - 1)) * p.ldo + ccol));
+#else
                             *reinterpret_cast<f32x4*>(p.out + (size_t)(o & (ST_ROW_RELU - 1)) * p.ldo + ccol) = x;
+#endif
                             csum += x;
                         }
                     }

@@ -14,6 +14,7 @@ for w in channel spatial layer regnet; do
   python $R/tools/rocpd_stats.py $(ls /tmp/prof_$w/*.db | head -1) 30 "$EXCL" > $OUT/stats_$w.txt 2>&1
 done
 [ -n "$ONLY_STATS" ] && exit 0
+rm -f $OUT/pmc_traffic.txt $OUT/pmc_sq.txt
 # 2. PMC passes (separate runs per counter, kernel-trace only) over the stage-3 instances of the two dominant kernels
 for m in 1 0; do
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -28,5 +29,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_M
   rm -rf /tmp/pmc_sq
   LDN_MATH_MODE=1 timeout 300 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_sq -o r -- python $R/tools/bench_conv.py --stage 3 --kinds conv2,conv3 --iters 3 > /tmp/pmc_sq.log 2>&1
   echo "== $set" >> $OUT/pmc_sq.txt
-  python $R/tools/rocpd_pmc.py $(ls /tmp/pmc_sq/*.db | head -1) k_conv_bf3 2>&1 | awk 'NR==1 || !seen[$2$3$4$5$6$7$8]++' >> $OUT/pmc_sq.txt
+  python $R/tools/rocpd_pmc.py $(ls /tmp/pmc_sq/*.db | head -1) k_conv 2>&1 | awk 'NR==1 || !seen[$2$3$4$5$6$7$8]++' >> $OUT/pmc_sq.txt
 done

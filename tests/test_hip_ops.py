@@ -291,3 +291,90 @@ def test_conv_image_channel_subsets(ops, B, H, cin, W, gran, stride):
         pad_hi = min((n + 3) // 4 * 4, W)
         assert bool((g1[b, :, :, n:pad_hi] == 0).all()) and bool((g2[b, :, :, n:pad_hi] == 0).all())
     assert torch.allclose(g3.cpu(), y3.permute(0, 2, 3, 1), atol=5e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ the wide 1x1 convs (k_conv1x1_stream in bf16x3 mode)
+def _ref_rows(a, w, sc, sh, a_rows=None):
+    x = a if a_rows is None else a[a_rows.long()]
+    y = x.double() @ w[:, 0].double().T
+    if sc is not None:
+        y = y * sc.double()
+    return y + sh.double()
+
+
+@pytest.mark.parametrize("rows,cin,cout,count", [(1500, 64, 256, 1500), (12544, 512, 2048, 12544), (3000, 96, 384, 1777),
+                                                 (600, 160, 512, 0), (200, 1024, 256, 130)])
+def test_wide_1x1_rows_scatter_residual(ops, rows, cin, cout, count):
+    """conv3 of the spatial / layer path at the widths that take the persistent streaming kernel in bf16x3 mode
+    (cout % 128 == 0, cout >= 256): gathered A rows, device-side row count, scatter-add into the residual stream in place,
+    BN scale folded into the weights (scale == NULL) and as a separate vector; rows beyond the count untouched.
+    The 12544-row case is the stage-4 dense execution of the headline model (N tiles split over workgroups)."""
+    src_rows = rows + 37
+    a = seeded_randn((src_rows, cin), 51)
+    w = seeded_randn((cout, 1, cin), 52) * (2.0 / cin) ** 0.5
+    sc, sh = _affine(cout, 53)
+    g = torch.Generator().manual_seed(54)
+    a_rows = torch.randperm(src_rows, generator=g)[:rows].to(torch.int32)
+    out_rows = torch.randperm(rows, generator=g).to(torch.int32)
+    ident = seeded_randn((rows, cout), 55)
+    cnt = torch.tensor([count], dtype=torch.int32, device=DEV)
+    want = ident.clone()
+    y = _ref_rows(a, w, sc, sh, a_rows[:count])
+    want[out_rows[:count].long()] = torch.relu(ident[out_rows[:count].long()].double() + y).float()
+    for prescaled in (True, False):
+        res = ident.clone().to(DEV)
+        if prescaled:
+            ops.conv_rows(a.to(DEV), (w * sc.view(-1, 1, 1)).to(DEV), None, sh.to(DEV), res, a_rows=a_rows.to(DEV), taps=1,
+                          m_count=cnt, m_cap=rows, relu=1, out_rows=out_rows.to(DEV), residual2d=res)
+        else:   # separate scale + residual: stays on the general kernel (same contract)
+            ops.conv_rows(a.to(DEV), w.to(DEV), sc.to(DEV), sh.to(DEV), res, a_rows=a_rows.to(DEV), taps=1,
+                          m_count=cnt, m_cap=rows, relu=1, out_rows=out_rows.to(DEV), residual2d=res)
+        assert torch.allclose(res.cpu(), want, atol=2e-4, rtol=1e-4), f"prescaled={prescaled}"
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(1000, 64, 256), (5000, 256, 512)])
+def test_wide_1x1_rows_conditional_relu(ops, rows, cin, cout):
+    """The strided projection shortcut of the spatial path: separate scale vector, no residual, ReLU only on the rows whose
+    flag is negative (relu == 2)."""
+    a = seeded_randn((rows, cin), 61)
+    w = seeded_randn((cout, 1, cin), 62) * (2.0 / cin) ** 0.5
+    sc, sh = _affine(cout, 63)
+    flag = torch.where(seeded_bernoulli((rows,), 0.5, 64) > 0.5, torch.tensor(-1), torch.tensor(3)).to(torch.int32)
+    out = torch.full((rows, cout), float("nan"), device=DEV)
+    ops.conv_rows(a.to(DEV), w.to(DEV), sc.to(DEV), sh.to(DEV), out, taps=1, m_cap=rows, relu=2, relu_if_neg=flag.to(DEV))
+    y = _ref_rows(a, w, sc, sh)
+    want = torch.where((flag < 0).view(-1, 1), torch.relu(y), y).float()
+    assert torch.allclose(out.cpu(), want, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,W,cout,gran,p", [(4, 14, 256, 1024, 2, 0.62), (3, 28, 128, 512, 2, 0.5), (2, 56, 64, 256, 1, 0.6),
+                                               (5, 14, 64, 256, 2, 0.0), (3, 10, 32, 384, 4, 1.0)])
+def test_wide_1x1_image_gathered_inputs(ops, B, H, W, cout, gran, p):
+    """conv3 of channel mode: left-packed input columns (garbage beyond roundup4(count)), k-major weights gathered by the
+    per-image channel list (images with NO active channel included), residual in place, fused GAP partials."""
+    G = W // gran
+    gm = seeded_bernoulli((B, G), p, 71)
+    _, idx, cnt, _ = ops.channel_masker(None, None, None, None, None, G, gran, mask_in=gm.to(DEV))
+    h2 = seeded_randn((B, H, H, W), 72)
+    cidx, ccnt = idx.cpu().long(), cnt.cpu()
+    for b in range(B):
+        n = int(ccnt[b])
+        h2[b, :, :, n:] = float("nan")
+        h2[b, :, :, n:min((n + 3) // 4 * 4, W)] = 0
+    w = seeded_randn((1, W, cout), 73) * (2.0 / W) ** 0.5
+    _, sh = _affine(cout, 74)
+    x = seeded_randn((B, H, H, cout), 75)
+    out = x.clone().to(DEV)
+    colsum = torch.full((B, (H * H + 31) // 32, cout), float("nan"), device=DEV)
+    ops.conv_image(h2.to(DEV), w.to(DEV), None, sh.to(DEV), out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual=out,
+                   colsum=colsum)
+    want = torch.empty(B, H, H, cout, dtype=torch.float64)
+    for b in range(B):
+        n = int(ccnt[b])
+        ch = cidx[b, :n]
+        want[b] = torch.relu(h2[b, :, :, :n].double() @ w[0, ch].double() + sh.double() + x[b].double())
+    assert torch.allclose(out.cpu(), want.float(), atol=2e-4, rtol=1e-4)
+    flat = out.cpu().reshape(B, H * H, cout).double()
+    pad = (-flat.shape[1]) % 32
+    flat = torch.cat([flat, flat.new_zeros(B, pad, cout)], dim=1).reshape(B, -1, 32, cout).sum(dim=2)
+    assert torch.allclose(colsum.cpu().double(), flat, atol=1e-3, rtol=1e-5)

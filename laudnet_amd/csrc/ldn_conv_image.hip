@@ -1480,12 +1480,13 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
             const int trow = lane >> 3, tc4 = (lane & 7) * 4;
             f32x4 res[2][2][4];
             int orw[2][4];
-            f32x4 sh4[2], sc4[2];       // per-column epilogue constants: requested here for the same reason
+            f32x4 sh4[2], sc4[2], ps4[2];   // per-column epilogue constants: requested here for the same reason
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int ccol = n0 + (wn + 2 * c) * 32 + tc4;
                 sh4[c] = *reinterpret_cast<const f32x4*>(p.shift + ccol);
                 sc4[c] = *reinterpret_cast<const f32x4*>(p.scale ? p.scale + ccol : g_one16);
+                ps4[c] = *reinterpret_cast<const f32x4*>(p.post_sub ? p.post_sub + ccol : g_zero16);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -1593,6 +1594,7 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
                         }
+                        x -= ps4[c];
                         if (o >= 0) {
 #if LDN_ABLATE & 16
                             if (x[0] == 12345.678f)
@@ -1757,7 +1759,7 @@ static int dispatch_mode(const ImgArgs& p, int kgran, hipStream_t st) {
     LDN_REQUIRE(taps * p.cin * p.cout < (1L << 31), "conv: weight tensor of %ld elements exceeds the 32-bit offsets of the weight staging",
                 taps * p.cin * p.cout);
     // wide 1x1 convolutions without an output-channel list: the persistent streaming kernel (bf16x3 arithmetic only)
-    if (math_mode() == 1 && stream_rows() >= ST_BM && taps == 1 && !p.n_idx && !p.post_sub && p.shift_classes == 1 &&
+    if (math_mode() == 1 && stream_rows() >= ST_BM && taps == 1 && !p.n_idx && p.shift_classes == 1 &&
         p.cout % ST_BN == 0 && p.cout >= 2 * ST_BN && !(p.residual && p.scale) && p.cin <= 1024 &&
         (p.packed ? p.m_cap : p.Ho * p.Wo) >= 96)   // (7x7 images would leave most of every 128-row M block empty)
         return p.k_idx ? launch_stream<B_KN4>(p, st) : launch_stream<B_NK>(p, st);

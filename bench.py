@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="time the forward replayed as one hipGraph (same kernels, no launch "
                     "gaps; per-launch HIP events, hence the roofline, need eager launches -- the default run reports the graph "
                     "replay as the extra leg `hipgraph_replay`)")
+    ap.add_argument("--keep", type=float, default=None, help="keep probability the maskers are calibrated to (default: the "
+                    "workload's target-0.5 operating point: 0.62 for channel units, 0.5 for spatial / layer units)")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the MFMA convolutions (include/ldn_hip.h: ldn_set_math_mode); fp32 storage either way")
     args = ap.parse_args()
@@ -199,6 +201,9 @@ def main():
     model = model.to(dev)
     torch.backends.cudnn.benchmark = True
     x = seeded_randn((args.batch, 3, 224, 224), 1000 + rank).to(dev).contiguous(memory_format=torch.channels_last)
+    if args.keep is not None:
+        wl = dict(wl, p_channel=args.keep if wl["p_channel"] is not None else None,
+                  p_spatial=args.keep if wl["p_spatial"] is not None else None, name=wl["name"] + f" (keep {args.keep})")
     calibrate_maskers(model, x, wl["p_channel"], wl["p_spatial"])
     calibrated_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 

@@ -782,8 +782,13 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
     const int lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Kb = t.Kb, T = t.T, msub = t.msub, nsub = t.nsub;
-    const int cpt = ceil_div(Kb, BK);
-    const int nch = T * cpt;
+    // ONE K axis over (tap, channel): tap t owns positions [t Kp, (t+1) Kp).  With gathered input channels Kp is the image's
+    // K_b rounded to 8 (an octet never straddles taps), so a 3x3 over K_b = 162 channels walks ceil(9 * 168 / 32) = 48 chunks
+    // instead of 9 * 6 = 54 -- 12 instead of 18 at stage 1 (K_b ~ 40): staging instructions, not MACs, are what a chunk costs.
+    // Shared weights keep every tap padded to the chunk width (their K is a multiple of 32 in every shipped model).
+    const int Kp = KN ? max(round_up(Kb, 8), BK) : round_up(p.cin, BK);
+    const int Ktot = T * Kp;
+    const int nch = Kb > 0 ? ceil_div(Ktot, BK) : 0;
     if (wave8 < 4) {
         // the consumers gather the epilogue tables while the producers' first loads are in flight; one extra
         // workgroup barrier (matched in the producer prologue) publishes them
@@ -798,16 +803,17 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
         const int rg = lane >> 3, pslot = lane & 7;
         const int qt = pslot ^ (((rg >> 1) + 4 * (wave & 1)) & 7);
         const int kq = qt * 4;
-        long aoff[MS];
+        long aoffA[MS], aoffB[MS];   // row offsets of the tap the chunk starts in / of the next tap (a chunk spans <= 2 taps: Kp >= 32)
+        int tcur = 0;
         const int Kb4 = p.k_idx ? round_up(Kb, 4) : p.cin;
         __builtin_amdgcn_s_setprio(2);
-        auto set_tap = [&](int tap) {
+        auto set_tap = [&](int tap, long (&aoff)[MS]) {
             const int ksz = p.packed ? 3 : p.ksize;
             const int ky = tap / ksz, kx = tap - ky * ksz;
 #pragma unroll
             for (int u = 0; u < MS; ++u) {
                 long off = -1;
-                if (u < msub) {
+                if (u < msub && tap < T) {
                     const int row = (wave + 4 * u) * 8 + rg;
                     if (p.packed) {
                         const int ar = t.s_arow[row * T + tap];
@@ -825,12 +831,17 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
             }
         };
         auto issue_a = [&](int c0, int buf) {
-            const int c = c0 + kq;
+            const int f = c0 + kq;                       // flat K position of this lane's 16-byte slot
+            const int bound = (tcur + 1) * Kp;
+            const bool nxt = f >= bound;                 // the slot belongs to the next tap
+            const int c = f - (nxt ? bound : tcur * Kp); // channel position inside its tap
             float* base = smem + buf * BUF;
 #pragma unroll
             for (int u = 0; u < MS; ++u)
-                if (u < msub)
-                    glds16((aoff[u] >= 0 && c < Kb4) ? p.a + aoff[u] + c : g_zero16, base + (wave + 4 * u) * 8 * BK);
+                if (u < msub) {
+                    const long off = nxt ? aoffB[u] : aoffA[u];
+                    glds16((off >= 0 && c < Kb4) ? p.a + off + c : g_zero16, base + (wave + 4 * u) * 8 * BK);
+                }
         };
 
         // ---- B: global -> VGPR -> split -> LDS rows [n][4 octets x (8 hi | 8 lo)], slots XOR-swizzled like the A rows
@@ -882,14 +893,16 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
             const int kch = p.k_idx ? __float_as_int(j < 4 ? lo4[j] : hi4[j - 4]) : min(kbase + j, p.cin - 1);
             return (tbase + (unsigned)kch) * (unsigned)p.cout;
         };
-        auto load_b = [&](int tap, int c0) {
-            const unsigned tbase = (unsigned)tap * (unsigned)p.cin;
+        const int Kb8 = round_up(Kb, 8);
+        auto load_b = [&](int c0) {
             const float* kf = reinterpret_cast<const float*>(t.s_kidx);
             if (PAIR) {
                 if (pr_oct >= 0) {
-                    const int kbase = c0 + pr_oct * 8;
-                    const bool oct_tail = kbase >= Kb;          // octet entirely behind the image's K: nothing to fetch
-                    pr_tail = (kbase & ~15) >= Kb;              // ... and so is its K16 step: KSKIP consumers skip it
+                    const int fbase = c0 + pr_oct * 8;          // flat K position of the octet
+                    const int tap = fbase / Kp, kbase = fbase - tap * Kp;
+                    const unsigned tbase = (unsigned)tap * (unsigned)p.cin;
+                    const bool oct_tail = fbase >= Ktot || kbase >= Kb8;   // octet holds no channel: nothing to fetch
+                    pr_tail = (fbase & ~15) >= Ktot;            // its whole K16 step lies behind K: KSKIP consumers skip it
                     if (!oct_tail) {
                         const f32x4 lo4 = *reinterpret_cast<const f32x4*>(kf + kbase), hi4 = *reinterpret_cast<const f32x4*>(kf + kbase + 4);
                         const unsigned col = (unsigned)max(pr_chn, 0);
@@ -906,14 +919,17 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
 #pragma unroll
             for (int u = 0; u < NBT; ++u) {
                 if (!KN) {
-                    const int c = c0 + oct_nk * 8;
+                    const int fb = c0 + oct_nk * 8;
+                    const int tap = fb / Kp, c = fb - tap * Kp;
                     const float* src = p.w + bbase[u] + (long)tap * p.cin + c;
-                    rb[u][0] = *reinterpret_cast<const f32x4*>((bbase[u] >= 0 && c < p.cin) ? src : g_zero16);
-                    rb[u][1] = *reinterpret_cast<const f32x4*>((bbase[u] >= 0 && c + 4 < p.cin) ? src + 4 : g_zero16);
+                    rb[u][0] = *reinterpret_cast<const f32x4*>((bbase[u] >= 0 && tap < T && c < p.cin) ? src : g_zero16);
+                    rb[u][1] = *reinterpret_cast<const f32x4*>((bbase[u] >= 0 && tap < T && c + 4 < p.cin) ? src + 4 : g_zero16);
                 } else if (oct_kn[u] >= 0) {
-                    const int kbase = c0 + oct_kn[u] * 8;
-                    kn_tail[u] = (kbase & ~15) >= Kb;   // the octet's whole K16 step lies behind K: KSKIP consumers skip it
-                    if (kbase >= Kb) {                  // octet entirely behind the image's K: nothing to fetch
+                    const int fbase = c0 + oct_kn[u] * 8;
+                    const int tap = fbase / Kp, kbase = fbase - tap * Kp;
+                    const unsigned tbase = (unsigned)tap * (unsigned)p.cin;
+                    kn_tail[u] = (fbase & ~15) >= Ktot;   // the octet's whole K16 step lies behind K: KSKIP consumers skip it
+                    if (fbase >= Ktot || kbase >= Kb8) {  // octet holds no channel: nothing to fetch
                         if (!(KSKIP && kn_tail[u])) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) rb[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -992,23 +1008,32 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
 
         if (nch > 0) {
             // two cursors: A is DMA'd one chunk ahead of the consumers, B is loaded into VGPRs two chunks ahead
-            int tap_a = 0, c0_a = 0, tap_b = 0, c0_b = 0;
-            auto adv_a = [&]() { c0_a += BK; if (c0_a >= Kb) { c0_a = 0; ++tap_a; if (tap_a < T) set_tap(tap_a); } };
-            auto adv_b = [&]() { c0_b += BK; if (c0_b >= Kb) { c0_b = 0; ++tap_b; } };
-            set_tap(0);
-            load_b(0, 0);
+            int c0_a = 0, c0_b = 0;      // flat K positions
+            auto adv_a = [&]() {
+                c0_a += BK;
+                if (c0_a >= (tcur + 1) * Kp) {   // the next chunk starts in the next tap
+                    ++tcur;
+#pragma unroll
+                    for (int u = 0; u < MS; ++u) aoffA[u] = aoffB[u];
+                    set_tap(tcur + 1, aoffB);
+                }
+            };
+            auto adv_b = [&]() { c0_b += BK; };
+            set_tap(0, aoffA);
+            set_tap(1, aoffB);
+            load_b(0);
             adv_b();
             issue_a(0, 0);
             adv_a();
             block_sync();    // matches the consumers' table barrier (vmcnt(0) here costs nothing: store_b(0) needs B(0) anyway)
             store_b(0);
             if (nch > 1) {   // both buffers are free at the start: chunk 1 is staged behind chunk 0, before barrier(0)
-                load_b(tap_b, c0_b);
+                load_b(c0_b);
                 adv_b();
                 issue_a(c0_a, 1);
                 adv_a();
                 store_b(1);
-                if (nch > 2) { load_b(tap_b, c0_b); adv_b(); }
+                if (nch > 2) { load_b(c0_b); adv_b(); }
             }
             for (int ch = 0; ch < nch; ++ch) {
                 const int buf = ch & 1;
@@ -1031,7 +1056,7 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
                     store_b(buf ^ 1);
 #endif
 #if !(LDN_ABLATE & 4)
-                    if (ch + 2 < nch) { load_b(tap_b, c0_b); adv_b(); }
+                    if (ch + 2 < nch) { load_b(c0_b); adv_b(); }
 #endif
 #if !(LDN_ABLATE & 2)
                     issue_a(c0_a, buf ^ 1);
@@ -1104,11 +1129,9 @@ __global__ __launch_bounds__(512, MINW) void k_conv_bf3(const ImgArgs p) {
     }
 
     if (nch > 0) {
-        int cin_chunk = 0;
         for (int ch = 0; ch < nch; ++ch) {
             const int buf = ch & 1;
-            const int kgroups = ceil_div(min(Kb - cin_chunk * BK, BK), 8);   // octets of this chunk that hold data
-            if (++cin_chunk == cpt) cin_chunk = 0;
+            const int kgroups = ceil_div(min(Ktot - ch * BK, BK), 8);   // octets of this chunk that lie inside K (only the last chunk is partial)
             LDN_TRACE_T(tr_a)
             block_sync_lds();                  // barrier(ch)
             LDN_TRACE_T(tr_b)

@@ -386,7 +386,7 @@ class Bottleneck(_PrepCache):
         cout = p["w3_nk"].shape[0]
         if self.downsample is not None:
             identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
-            ops.conv_image(xn, p["wd"], p["sd"], p["td"], identity, stride=p["ds_stride"], relu=0)
+            self._shortcut(xn, p, identity)
             out = identity
         else:
             identity = xn
@@ -397,6 +397,17 @@ class Bottleneck(_PrepCache):
         self.last_gap = None
         self.last_channel_cnt = cnt
         return ops.from_nhwc(out), mask
+
+    def _shortcut(self, xn, p, identity):
+        """Projection shortcut (laud_resnet.py:138-141).  Maps of fewer than 96 pixels run as ONE list of strided pixel rows that
+        spans the batch (M tiles then hold rows of several images) instead of per-image tiles that would be mostly empty."""
+        B, Hi, Wi, Cin = xn.shape
+        _, Ho, Wo, cout = identity.shape
+        if Ho * Wo < 96:
+            ops.conv_packed(xn.reshape(B * Hi * Wi, Cin), p["wd"], p["sd"], p["td"], identity.view(B * Ho * Wo, cout), taps=1,
+                            m_cap=B * Ho * Wo, a_map=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], xn.device), relu=0)
+        else:
+            ops.conv_image(xn, p["wd"], p["sd"], p["td"], identity, stride=p["ds_stride"], relu=0)
 
     def _run_channel(self, x, p, gap_in=None, want_gap=False):
         B, Cin, Hi, Wi = x.shape
@@ -420,7 +431,7 @@ class Bottleneck(_PrepCache):
             side = _side_stream(dev)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                ops.conv_image(xn, p["wd"], p["sd"], p["td"], identity, stride=p["ds_stride"], relu=0)
+                self._shortcut(xn, p, identity)
             out = identity
         else:
             identity = xn

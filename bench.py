@@ -93,6 +93,49 @@ def calibrate_maskers(model, x, p_channel, p_spatial):
             state = runner(state, 1.0)
 
 
+def audit_masker_decisions(model, ref, x, ops, headline_math):
+    """How many masker decisions of the HIP path differ from the ORACLE's own maskers (PyTorch fp32 on the same GPU) when
+    both see the SAME block input, per arithmetic mode.  The block inputs are the HIP path's own (captured through the
+    model's debug tap with in-place updates off), so every block is audited on the activations it really sees; a decision
+    can only differ where |keep logit - drop logit| is within the two implementations' reduction-order noise."""
+    res = {}
+    rblocks = [(b.f if hasattr(b, "f") else b) for _, b in ref.blocks()]
+    for math in ("fp32", "bf16x3"):
+        ops.set_math_mode(math)
+        flips = total = 0
+        worst_margin = 0.0
+        taps = []
+        model._tap = lambda j, blk, xin: taps.append((j, blk, xin))
+        saved = model.inplace_residual
+        model.inplace_residual = False
+        try:
+            with torch.no_grad():
+                model(x, 1.0)
+                for j, blk, xin in taps:
+                    rb = rblocks[j]
+                    if getattr(rb, "masker_channel", None) is not None and getattr(blk, "last_channel_mask", None) is not None:
+                        lg = rb.masker_channel.logits(xin).reshape(xin.shape[0], 2, -1)
+                        mine = blk.last_channel_mask.reshape(xin.shape[0], -1)
+                    elif getattr(rb, "masker_spatial", None) is not None and getattr(blk, "last_spatial_mask", None) is not None:
+                        lg = rb.masker_spatial.logits(xin).reshape(xin.shape[0], 2, -1)
+                        mine = blk.last_spatial_mask.reshape(xin.shape[0], -1)
+                    else:
+                        continue
+                    theirs = (lg[:, 0] >= lg[:, 1]).float()
+                    diff = mine != theirs
+                    flips += int(diff.sum())
+                    total += diff.numel()
+                    if bool(diff.any()):
+                        worst_margin = max(worst_margin, float((lg[:, 0] - lg[:, 1]).abs()[diff].max()))
+        finally:
+            model._tap = None
+            model.inplace_residual = saved
+        res[math] = {"decisions_differing_from_oracle_maskers": flips, "decisions_total": total,
+                     "largest_oracle_logit_margin_at_a_differing_decision": worst_margin}
+    ops.set_math_mode(headline_math)
+    return res
+
+
 class KernelTimer:
     """HIP-event timing of the channel-mode conv launches on the launch stream (torch's current stream == the stream
     the C ABI is given): two event records per launch.  Launches are classified as
@@ -195,9 +238,21 @@ def main():
     from laudnet_amd import ops
     from fill import fill_state_dict, seeded_randn
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL rendezvous on
+        # 127.0.0.1) and hand over; rank 0 of that job prints the JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank, world, local = D.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     laudnet_amd.load_library()   # fail loudly if the HIP extension is missing
@@ -225,9 +280,14 @@ def main():
         from laudnet_amd.laud_resnet import GraphedForward
         graphed = GraphedForward(model, x, 1.0)
 
-    def step():
+    recompute = D.recompute_for(model, x.shape)
+
+    def forward_local():
         with torch.no_grad():
-            return D.gather_outputs(graphed(x) if graphed is not None else model(x, 1.0))
+            return graphed(x) if graphed is not None else model(x, 1.0)
+
+    def step():
+        return D.gather_outputs(forward_local(), recompute)
 
     for _ in range(args.warmup):
         out = step()
@@ -244,9 +304,16 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pending = None
     for i in range(args.steps):
         timer.step = i
-        out = step()
+        # the exchange of batch i (all-gather of logits + all-reduce of sparsities, issued asynchronously on RCCL's stream)
+        # overlaps the forward of batch i+1; every batch's global 7-tuple is completed inside the timed region
+        nxt = D.gather_outputs_async(forward_local(), recompute)
+        if pending is not None:
+            out = pending.wait()
+        pending = nxt
+    out = pending.wait()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -262,7 +329,7 @@ def main():
     flops_perc = out[5].float().mean().item()
     flops_per_img = out[6].item()
     result = {
-        "metric": "images/sec, " + wl["name"].split(" ")[0] + " @224 bs256 (dynamic-inference hot path)",
+        "metric": "images/sec, " + wl["name"].split(" ")[0] + f" @224 bs{args.batch} (dynamic-inference hot path)",
         "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.math == "fp32" else "bf16x3 (fp32 tensors; each fp32 product = 3 bf16 MFMA products of hi/lo splits, fp32 accumulate)",
@@ -271,7 +338,11 @@ def main():
                    "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                    "parallelism": f"dp{world} (batch shards, all-gather logits + all-reduce stats over RCCL)",
                    "mean_block_flops_ratio": round(flops_perc, 4), "module_macs_per_image": flops_per_img,
-                   "launch": "hipGraph replay" if args.graph else "eager"},
+                   "launch": "hipGraph replay" if args.graph else "eager",
+                   "math_mode": args.math + (" (per-call argument of the C ABI; fp32 storage; the fp32-MFMA figure of the same "
+                                             "workload is `fp32_mfma_mode`)" if args.math != "fp32" else ""),
+                   "timed_region": "includes two HIP-event records around every conv2/conv3-type launch of every other step "
+                                   "(the `roofline` samples); LDN_BENCH_NO_EVENTS=1 times without them"},
     }
 
     agg = timer.summary()
@@ -381,27 +452,39 @@ def main():
                     rb.forced_channel_mask = None if cm is None else cm.clone()
                     rb.forced_spatial_mask = None if sm is None else sm.clone()
                 with torch.no_grad():
-                    for _ in range(2):
+                    for _ in range(10):            # MIOpen autotune on, 10 warm-up + 50 timed iterations
                         want = refg(x, 1.0)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    reps = 3
+                    reps = 50
                     for _ in range(reps):
                         want = refg(x, 1.0)
                     torch.cuda.synchronize()
                     dt = (time.perf_counter() - t0) / reps
                 err = (out[0] - want[0]).abs().max().item()
                 result["dense_emulation_gpu"] = {"value": args.batch / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt,
-                                                 "kind": "oracle dense emulation, PyTorch-ROCm fp32 channels_last, same GPU",
+                                                 "kind": "oracle dense emulation, PyTorch-ROCm fp32 channels_last, same GPU, "
+                                                         "MIOpen autotune on, 10 warm-up + 50 timed forwards",
                                                  "max_abs_logit_diff_vs_hip_same_masks": err,
                                                  "logit_scale": want[0].abs().max().item()}
                 result["realised_speedup_vs_dense_emulation"] = result["value"] / (args.batch / dt)
+                if "fp32_mfma_mode" in result:   # like-for-like: fp32 multiply on both sides
+                    result["realised_speedup_fp32_mode"] = result["fp32_mfma_mode"]["value"] / (args.batch / dt)
+                try:
+                    result["masker_decision_audit"] = audit_masker_decisions(model, refg, x, ops, args.math)
+                except Exception as e:   # informative only
+                    result["masker_decision_audit"] = {"error": repr(e)[:200]}
                 ref = ref.cpu()
             except Exception as e:  # the baseline is informative only
                 result["dense_emulation_gpu"] = {"error": repr(e)[:200]}
         if not args.no_cpu:
-            cores = min(os.cpu_count() or 1, 32)   # torch CPU convs stop scaling (and thrash) far below 256 threads
+            host_cores = os.cpu_count() or 1
+            cores = min(host_cores, 32)   # torch CPU convs stop scaling (and thrash) far below 256 threads
             torch.set_num_threads(cores)
+            try:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except Exception:
+                cpu_model = "unknown"
             for rb in ((b.f if hasattr(b, "f") else b) for _, b in ref.blocks()):
                 rb.forced_channel_mask = rb.forced_spatial_mask = None
             xc = x[: args.cpu_batch].cpu().contiguous()
@@ -415,6 +498,7 @@ def main():
                     reps += 1
                 dt = (time.perf_counter() - t0) / reps
             result["cpu_baseline"] = {"value": args.cpu_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+                                      "host": f"{host_cores} logical cores, {cpu_model}",
                                       "sample": f"{reps} forward passes of batch {args.cpu_batch} (same model/weights/inputs), "
                                                 f"oracle dense emulation in torch fp32 on {cores} threads"}
     # second half of the BASELINE metric: the reference's analytic predictor with MI355X parameters (tools/predict_speedup.py,

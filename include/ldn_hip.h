@@ -19,6 +19,7 @@
 #ifndef LDN_HIP_H
 #define LDN_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -33,16 +34,21 @@ const char* ldn_last_error(void);
 int ldn_version(void);
 /* number of compute units of the current device (used by callers to size persistent grids) */
 int ldn_device_cus(int* cus);
-/* Arithmetic of the MFMA convolutions (ldn_conv_image / ldn_conv_packed / ldn_conv_rows), process-wide:
- *   0 = fp32 operands on v_mfma_f32_32x32x2_f32 (fp32 multiply, fp32 accumulate);
- *   1 = "bf16x3" split precision: each fp32 operand x is split in registers into bf16 hi + bf16 lo
+/* Arithmetic of the MFMA convolutions -- the `math_mode` ARGUMENT of ldn_conv_image / ldn_conv_packed / ldn_conv_rows /
+ * ldn_bottleneck_tail (the library keeps no mutable state: two threads or streams may use different modes concurrently):
+ *   LDN_MATH_FP32   (0) = fp32 operands on v_mfma_f32_32x32x2_f32 (fp32 multiply, fp32 accumulate);
+ *   LDN_MATH_BF16X3 (1) = "bf16x3" split precision: each fp32 operand x is split into bf16 hi + bf16 lo
  *       (round-to-nearest-even both), the product is hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_bf16 with
  *       fp32 accumulation; per-product relative error <= ~2^-16 (measured: 5e-6 relative on a K=2304 conv),
  *       inside the north star's 1e-3 fp32 parity tolerance.  Storage stays fp32 everywhere.
- * The initial value is taken from the environment variable LDN_MATH_MODE (default 0).  The reference has no
- * counterpart (cuDNN chooses its own algorithms, TF32 included, behind torch.backends.cudnn.allow_tf32). */
-int ldn_set_math_mode(int mode);
-int ldn_get_math_mode(void);
+ *   LDN_MATH_DEFAULT (-1) = the read-only process default, taken once from the environment variable LDN_MATH_MODE
+ *       (0 if unset); ldn_default_math_mode() returns it.
+ * The reference has no counterpart (cuDNN chooses its own algorithms, TF32 included, behind
+ * torch.backends.cudnn.allow_tf32). */
+#define LDN_MATH_DEFAULT (-1)
+#define LDN_MATH_FP32 0
+#define LDN_MATH_BF16X3 1
+int ldn_default_math_mode(void);
 
 /* ---- a1: Masker_spatial.forward, eval branch (models/utils.py:47-65) ------------------------
  * x [B,Hi,Wi,C] NHWC -> adaptive average pool to SxS (only if S < Hi, utils.py:48; bins
@@ -51,6 +57,8 @@ int ldn_get_math_mode(void);
  * B * ldn_channel_masker_splits(Hi*Wi) * C entries, only needed for S == 1 (layer skip: whole-image window). */
 int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w /*[2g,C]*/,
                        const float* bias /*[2g]*/, int g, int S, float* mask, float* logits, float* work, void* stream);
+/* bytes of `work` the call above needs for this shape (0 = none); every *_workspace_bytes twin below follows the same rule */
+size_t ldn_spatial_masker_workspace_bytes(int B, int Hi, int Wi, int C, int S);
 
 /* ---- a4/a11: F.interpolate(nearest) + ExpandMask x2 -> packed index lists -------------------
  * (laud_resnet.py:106-110, models/utils.py:74-89).  patch_mask [B,S,S] fp32 {0,1} (one mask
@@ -72,6 +80,7 @@ int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float
 int ldn_mask_to_index(const float* patch_mask, int B, int S, int Ho, int Wo, int stride, int32_t* idx3,
                       int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
                       int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work, void* stream);
+size_t ldn_mask_to_index_workspace_bytes(int B);
 
 /* ---- K2/K5: stand-alone row gather / masked scatter-add (DyNetSimulator simulate_gather,
  * simulate_scatter_add; laud_resnet.py:133,143-144) ----------------------------------------- */
@@ -94,7 +103,7 @@ int ldn_scatter_add_relu(const float* packed, int ld_packed, const int32_t* rows
 int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                   const float* w, int cin, int cout, const float* scale, const float* shift, int relu,
                   const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
-                  float* out, int ldo, void* stream);
+                  float* out, int ldo, int math_mode, void* stream);
 
 /* ---- a2: Masker_channel_MLP.forward, eval branch (models/utils.py:113-131) + index build ----
  * x [B,HW,C] NHWC -> global average pool -> Linear(C,hidden)+ReLU+Linear(hidden,2G) (hidden>0)
@@ -111,6 +120,7 @@ int ldn_channel_masker(const float* x, int B, int HW, int C, const float* w1, co
                        const float* b2, int hidden, int G, int gran, const float* mask_in, float* mask,
                        float* logits, int32_t* ch_idx, int32_t* ch_cnt, float* work, const float* gap_partial,
                        int gap_splits, void* stream);
+size_t ldn_channel_masker_workspace_bytes(int B, int HW, int C);
 
 /* ---- a7 (channel mode): per-image channel-subset convolution --------------------------------
  * (laud_resnet.py:115-144 with apply_channel_mask, models/utils.py:18-25; also the plain dense
@@ -137,7 +147,7 @@ int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, in
                    const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt, int kgran,
                    const int32_t* n_idx, const int32_t* n_cnt, const float* scale, const float* shift,
                    int shift_classes, const float* post_sub, int relu, const float* residual, int ldr,
-                   float* out, int ldo, float* colsum, void* stream);
+                   float* out, int ldo, float* colsum, int math_mode, void* stream);
 
 /* ---- a7 (spatial / layer / both): the same kernel over PACKED PIXEL LISTS ---------------------
  * Image b owns the packed rows [row_prefix[b], row_prefix[b+1]) (B == 1, row_prefix == NULL: rows [0, *m_count),
@@ -153,7 +163,8 @@ int ldn_conv_packed(const float* a, int lda, int B, const int32_t* row_prefix, c
                     int Ho, int Wo, int stride, const float* w, int cin, int cout, const int32_t* k_idx,
                     const int32_t* k_cnt, int kgran, const int32_t* n_idx, const int32_t* n_cnt, const float* scale,
                     const float* shift, int shift_classes, const float* post_sub, int relu,
-                    const int32_t* relu_if_neg, const float* residual, int ldr, float* out, int ldo, void* stream);
+                    const int32_t* relu_if_neg, const float* residual, int ldr, float* out, int ldo, int math_mode,
+                    void* stream);
 
 /* ---- a9: LAD-RegNet BottleneckTransform (laud_regnet.py:157-217), layer-skip execution ------------------------
  * b: grouped 3x3 conv (+BN+ReLU) over packed rows: out[r,c] = act(scale[c]*sum_{t<9} sum_{i<gw}
@@ -166,6 +177,7 @@ int ldn_grouped_conv3x3_rows(const float* a, int lda, const int32_t* nbr, const 
  *    w1 [S][C], w2 [C][S].  work: B*(ldn_channel_masker_splits(max_rows_per_image)+1)*C floats. */
 int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B, int C, int S, const float* w1, const float* b1,
                   const float* w2, const float* b2, int max_rows_per_image, float* work, void* stream);
+size_t ldn_se_packed_workspace_bytes(int B, int C, int max_rows_per_image);
 
 #ifdef __cplusplus
 }

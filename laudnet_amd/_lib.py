@@ -18,21 +18,24 @@ SIGNATURES = {
     "ldn_last_error": ([], C.c_char_p),
     "ldn_version": ([], _I),
     "ldn_device_cus": ([C.POINTER(_I)], _I),
-    "ldn_set_math_mode": ([_I], _I),
-    "ldn_get_math_mode": ([], _I),
+    "ldn_default_math_mode": ([], _I),
     "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P], _I),
+    "ldn_spatial_masker_workspace_bytes": ([_I, _I, _I, _I, _I], C.c_size_t),
     "ldn_mask_to_index": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "ldn_mask_to_index_workspace_bytes": ([_I], C.c_size_t),
     "ldn_gather_rows": ([_P, _I, _P, _P, _I, _I, _P, _I, _P], _I),
     "ldn_scatter_add_relu": ([_P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P], _I),
-    "ldn_conv_rows": ([_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P], _I),
+    "ldn_conv_rows": ([_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P], _I),
     "ldn_channel_masker_splits": ([_I], _I),
     "ldn_channel_masker": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P], _I),
+    "ldn_channel_masker_workspace_bytes": ([_I, _I, _I], C.c_size_t),
     "ldn_conv_packed": ([_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P,
-                         _I, _P, _I, _P, _P, _I, _P, _I, _P], _I),
+                         _I, _P, _I, _P, _P, _I, _P, _I, _I, _P], _I),
     "ldn_grouped_conv3x3_rows": ([_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P], _I),
     "ldn_se_packed": ([_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P], _I),
+    "ldn_se_packed_workspace_bytes": ([_I, _I, _I], C.c_size_t),
     "ldn_conv_image": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I,
-                        _P, _I, _P, _I, _P, _P], _I),
+                        _P, _I, _P, _I, _P, _I, _P], _I),
 }
 
 _lib = None
@@ -66,8 +69,10 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(t=None):
+    """Launch stream = the current stream OF THE TENSORS' DEVICE (require_device has checked that it is also the current
+    device, which is what the HIP runtime launches on)."""
+    return C.c_void_p(torch.cuda.current_stream(t.device if t is not None else None).cuda_stream)
 
 
 def check(status: int, what: str):
@@ -77,6 +82,16 @@ def check(status: int, what: str):
 
 
 def require_device(*tensors):
+    """Every tensor must live on ONE HIP device and that device must be the current one: libldn_hip.so launches on the
+    runtime's current device and takes the stream from it -- a tensor on another GPU would be a foreign pointer there."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise LdnError("laudnet_amd ops need tensors on a HIP device (cuda:N); there is no CPU path")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise LdnError(f"tensor on {t.device} but the current device is cuda:{cur}: wrap the call in "
+                           f"torch.cuda.device({t.device.index}) (kernels are launched on the current device's stream)")

@@ -66,6 +66,7 @@ struct ImgArgs {
     int mtn;    // M blocks per image
     int bn;     // columns per N block (multiple of 32, <= NS*32)
     int bm;     // pixels per M block (multiple of 32, <= MS*32; balanced over the image)
+    int math;   // 0 = fp32 MFMA, 1 = bf16x3 (resolved by the entry point, never read from a global)
 };
 
 constexpr int BK = 32;   // K chunk = one 128-byte LDS row
@@ -1652,13 +1653,12 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------- host
-static int g_math_mode = -1;   // 0 = fp32 MFMA, 1 = bf16x3 split precision (initial value from env LDN_MATH_MODE)
-static int math_mode() {
-    if (g_math_mode < 0) {
-        const char* e = getenv("LDN_MATH_MODE");
-        g_math_mode = (e && e[0] == '1') ? 1 : 0;
-    }
-    return g_math_mode;
+// Arithmetic of a launch: 0 = fp32 MFMA, 1 = bf16x3 split precision.  It is an ARGUMENT of every conv entry point (ImgArgs::math);
+// LDN_MATH_DEFAULT (-1) resolves to the read-only process default taken once from the environment (LDN_MATH_MODE).  The library
+// keeps no mutable state.
+static int default_math_mode() {
+    static const int v = [] { const char* e = getenv("LDN_MATH_MODE"); return (e && e[0] == '1') ? 1 : 0; }();
+    return v;
 }
 
 static size_t tile_lds_bytes(const ImgArgs& p, int MS, int NS) {
@@ -1686,7 +1686,7 @@ static int launch_bf3(const ImgArgs& p, hipStream_t st) {
 
 template <int MS, int NS, int BMODE, bool KSKIP>
 static int launch_k(const ImgArgs& p, hipStream_t st) {
-    if (math_mode() == 1) {
+    if (p.math == 1) {
         // consumer wave grid WM x 4/WM: every wave owns whole m-subtiles (A fragments are split once and reused);
         // 4 x 1 for the tall 8 x 6 tile, 2 x 2 otherwise; 7x7 images (<= 2 m-subtiles) get a 2-subtile-high tile
         const int msubs = ceil_div(p.packed ? p.m_cap : p.Ho * p.Wo, 32);
@@ -1782,7 +1782,7 @@ static int dispatch_mode(const ImgArgs& p, int kgran, hipStream_t st) {
     LDN_REQUIRE(taps * p.cin * p.cout < (1L << 31), "conv: weight tensor of %ld elements exceeds the 32-bit offsets of the weight staging",
                 taps * p.cin * p.cout);
     // wide 1x1 convolutions without an output-channel list: the persistent streaming kernel (bf16x3 arithmetic only)
-    if (math_mode() == 1 && stream_rows() >= ST_BM && taps == 1 && !p.n_idx && p.shift_classes == 1 &&
+    if (p.math == 1 && stream_rows() >= ST_BM && taps == 1 && !p.n_idx && p.shift_classes == 1 &&
         p.cout % ST_BN == 0 && p.cout >= 2 * ST_BN && !(p.residual && p.scale) && p.cin <= 1024 &&
         (p.packed ? p.m_cap : p.Ho * p.Wo) >= 96)   // (7x7 images would leave most of every 128-row M block empty)
         return p.k_idx ? launch_stream<B_KN4>(p, st) : launch_stream<B_NK>(p, st);
@@ -1797,13 +1797,13 @@ static int dispatch_mode(const ImgArgs& p, int kgran, hipStream_t st) {
 
 using namespace ldn;
 
-extern "C" int ldn_set_math_mode(int mode) {
-    LDN_REQUIRE(mode == 0 || mode == 1, "ldn_set_math_mode: mode must be 0 (fp32) or 1 (bf16x3), got %d", mode);
-    g_math_mode = mode;
+extern "C" int ldn_default_math_mode(void) { return default_math_mode(); }
+
+static int resolve_math(int math_mode, int* out) {
+    LDN_REQUIRE(math_mode >= -1 && math_mode <= 1, "math_mode must be LDN_MATH_DEFAULT (-1), LDN_MATH_FP32 (0) or LDN_MATH_BF16X3 (1), got %d", math_mode);
+    *out = math_mode < 0 ? default_math_mode() : math_mode;
     return LDN_OK;
 }
-
-extern "C" int ldn_get_math_mode(void) { return math_mode(); }
 
 #ifdef LDN_TRACE
 extern "C" int ldn_debug_set_trace(void* buf) {
@@ -1816,8 +1816,11 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
                               const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt,
                               int kgran, const int32_t* n_idx, const int32_t* n_cnt, const float* scale,
                               const float* shift, int shift_classes, const float* post_sub, int relu,
-                              const float* residual, int ldr, float* out, int ldo, float* colsum, void* stream) {
+                              const float* residual, int ldr, float* out, int ldo, float* colsum, int math_mode,
+                              void* stream) {
     LDN_REQUIRE(a && w && shift && out, "ldn_conv_image: null pointer");
+    int math;
+    if (int rc = resolve_math(math_mode, &math)) return rc;
     LDN_REQUIRE(!colsum || (!n_idx && (uintptr_t)colsum % 16 == 0), "ldn_conv_image: colsum needs a dense output and 16-byte alignment");
     LDN_REQUIRE(ksize == 1 || ksize == 3, "ldn_conv_image: ksize must be 1 or 3 (got %d)", ksize);
     LDN_REQUIRE(stride >= 1 && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "ldn_conv_image: bad geometry");
@@ -1837,7 +1840,7 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
     LDN_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "ldn_conv_image: a/w must be 16-byte aligned");
     ImgArgs p{a, lda, B, Hi, Wi, ksize, stride, Ho, Wo, w, cin, cout, k_idx, k_cnt, n_idx, n_cnt,
               scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, colsum,
-              0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+              0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, math};
     return dispatch_mode(p, kgran, static_cast<hipStream_t>(stream));
 }
 
@@ -1847,8 +1850,10 @@ extern "C" int ldn_conv_packed(const float* a, int lda, int B, const int32_t* ro
                                int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt, int kgran,
                                const int32_t* n_idx, const int32_t* n_cnt, const float* scale, const float* shift,
                                int shift_classes, const float* post_sub, int relu, const int32_t* relu_if_neg,
-                               const float* residual, int ldr, float* out, int ldo, void* stream) {
+                               const float* residual, int ldr, float* out, int ldo, int math_mode, void* stream) {
     LDN_REQUIRE(a && w && shift && out, "ldn_conv_packed: null pointer");
+    int math;
+    if (int rc = resolve_math(math_mode, &math)) return rc;
     LDN_REQUIRE(taps == 1 || taps == 9, "ldn_conv_packed: taps must be 1 or 9 (got %d)", taps);
     LDN_REQUIRE(a_map || taps == 1, "ldn_conv_packed: a_map required when taps > 1");
     LDN_REQUIRE(B >= 1 && (row_prefix || B == 1), "ldn_conv_packed: B > 1 needs row_prefix");
@@ -1868,7 +1873,7 @@ extern "C" int ldn_conv_packed(const float* a, int lda, int B, const int32_t* ro
     if (m_cap <= 0) return LDN_OK;
     ImgArgs p{a, lda, B, Hi > 0 ? Hi : 1, Wi > 0 ? Wi : 1, taps, stride >= 1 ? stride : 1, Ho > 0 ? Ho : 1, Wo > 0 ? Wo : 1,
               w, cin, cout, k_idx, k_cnt, n_idx, n_cnt, scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo,
-              nullptr, 1, row_prefix, m_count, m_cap, a_map, out_map, pix_map, relu_if_neg, 0, 0, 0, 0};
+              nullptr, 1, row_prefix, m_count, m_cap, a_map, out_map, pix_map, relu_if_neg, 0, 0, 0, 0, math};
     return dispatch_mode(p, kgran, static_cast<hipStream_t>(stream));
 }
 
@@ -1876,8 +1881,8 @@ extern "C" int ldn_conv_packed(const float* a, int lda, int B, const int32_t* ro
 extern "C" int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count,
                              int m_cap, const float* w, int cin, int cout, const float* scale, const float* shift,
                              int relu, const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual,
-                             int ldr, float* out, int ldo, void* stream) {
+                             int ldr, float* out, int ldo, int math_mode, void* stream) {
     return ldn_conv_packed(a, lda, 1, nullptr, m_count, m_cap, a_rows, taps, out_rows, nullptr, 0, 0, 0, 0, 1, w, cin, cout,
                            nullptr, nullptr, 1, nullptr, nullptr, scale, shift, 1, nullptr, relu, relu_if_neg, residual, ldr,
-                           out, ldo, stream);
+                           out, ldo, math_mode, stream);
 }

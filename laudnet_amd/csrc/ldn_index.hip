@@ -533,6 +533,15 @@ extern "C" int ldn_device_cus(int* cus) {
     return LDN_OK;
 }
 
+extern "C" size_t ldn_spatial_masker_workspace_bytes(int B, int Hi, int Wi, int C, int S) {
+    if (!(S < Hi && S == 1)) return 0;   // only the whole-image window (layer skip) is reduced in two stages
+    return (size_t)B * ldn_channel_masker_splits(Hi * Wi) * C * sizeof(float);
+}
+extern "C" size_t ldn_mask_to_index_workspace_bytes(int B) { return (size_t)3 * B * sizeof(int32_t); }
+extern "C" size_t ldn_channel_masker_workspace_bytes(int B, int HW, int C) {
+    return (size_t)B * ldn_channel_masker_splits(HW) * C * sizeof(float);
+}
+
 extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w, const float* bias,
                                   int g, int S, float* mask, float* logits, float* work, void* stream) {
     LDN_REQUIRE(x && w && bias && mask, "ldn_spatial_masker: null pointer");

@@ -195,6 +195,10 @@ extern "C" int ldn_grouped_conv3x3_rows(const float* a, int lda, const int32_t* 
     return LDN_OK;
 }
 
+extern "C" size_t ldn_se_packed_workspace_bytes(int B, int C, int max_rows_per_image) {
+    return (size_t)B * (ldn_channel_masker_splits(max_rows_per_image) + 1) * C * sizeof(float);
+}
+
 extern "C" int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B, int C, int S, const float* w1,
                              const float* b1, const float* w2, const float* b2, int max_rows_per_image, float* work,
                              void* stream) {

@@ -3,10 +3,18 @@ contiguously, weights replicated.  Images are independent in eval mode (BN runni
 masks), so the data path has no collective; the only exchange per batch is
 
   1. all_gather of the logits  [B_local,1000] fp32  -> [B_global,1000] on every rank, and
-  2. one all_reduce(SUM) of a packed statistics vector (per-block sparsities, flops_perc, flops)
+  2. one all_reduce(SUM) of the packed per-block sparsities (each is a mean over the rank's shard;
+     shards are equal-sized, so SUM / world is the global-batch mean, i.e. sum(mask) / count over the
+     global batch),
 
-so that the returned 7-tuple equals what a single device would report for the global batch when shards
-are equal-sized (the reference averages per-rank means the same way, train/main.py:673-683).
+after which flops_perc / flops are RECOMPUTED from the global sparsities with the model's own
+shape-only FLOPs table (`model.flops_from_sparsities`): they contain channel_sparsity**2
+(laud_resnet.py:129), so averaging per-rank values would not give the single-device result.  The
+returned 7-tuple therefore EQUALS what one device reports for the global batch (tests/test_distributed.py
+asserts 1e-6).  (The reference itself averages per-rank values, train/main.py:673-683.)
+
+Both collectives are issued asynchronously on the backend's own stream (`gather_outputs_async`), so the
+exchange of batch i overlaps the forward of batch i+1; `wait()` joins it.
 Backend "nccl" is RCCL on ROCm (xGMI); the same code runs on "gloo" for the CPU tests.
 """
 from __future__ import annotations
@@ -40,30 +48,66 @@ def shard_bounds(global_batch: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
-def _pack_stats(outputs):
-    _, s3, s2, s1, cs, perc, flops = outputs
+def _pack_sparsities(outputs):
+    _, s3, s2, s1, cs, _, _ = outputs
     parts = [t.reshape(-1).float() for group in (s3, s2, s1, cs) for t in group]
-    parts += [perc.reshape(-1).float(), flops.reshape(-1).float()]
     return torch.cat(parts), [p.numel() for p in parts]
 
 
-def _unpack_stats(vec, sizes, n_stages):
-    chunks = list(torch.split(vec, sizes))
-    groups = [chunks[i * n_stages:(i + 1) * n_stages] for i in range(4)]
-    perc, flops = chunks[4 * n_stages], chunks[4 * n_stages + 1].reshape(())
-    return groups, perc, flops
+class PendingGather:
+    """Handle of an exchange in flight (gather_outputs_async).  wait() -> the global-batch 7-tuple."""
+
+    def __init__(self, outputs, full, vec, sizes, works, world, recompute):
+        self._o, self._full, self._vec, self._sizes = outputs, full, vec, sizes
+        self._works, self._world, self._recompute = works, world, recompute
+
+    def wait(self):
+        for w in self._works:
+            w.wait()          # NCCL/RCCL: the current stream waits for the collective's stream; gloo: host wait
+        n_stages = len(self._o[1])
+        chunks = list(torch.split(self._vec / self._world, self._sizes))
+        groups = [chunks[i * n_stages:(i + 1) * n_stages] for i in range(4)]
+        if self._recompute is not None:
+            perc, flops = self._recompute(*groups)
+        else:
+            # no FLOPs table given: average the per-rank values like the reference does (train/main.py:673-683); NOT equal to
+            # the single-device result when channel sparsities differ between shards
+            pf = torch.cat([self._o[5].reshape(-1).float(), self._o[6].reshape(-1).float()])
+            dist.all_reduce(pf, op=dist.ReduceOp.SUM)
+            pf = pf / self._world
+            perc, flops = pf[:-1], pf[-1].reshape(())
+        return (self._full, list(groups[0]), list(groups[1]), list(groups[2]), list(groups[3]), perc, flops)
 
 
-def gather_outputs(outputs, group=None):
-    """(logits_local, s3[4], s2[4], s1[4], cs[4], flops_perc, flops) -> the same tuple for the GLOBAL batch."""
+class _Ready:
+    def __init__(self, outputs):
+        self._o = outputs
+
+    def wait(self):
+        return self._o
+
+
+def gather_outputs_async(outputs, recompute=None, group=None):
+    """Start the exchange for (logits_local, s3[4], s2[4], s1[4], cs[4], flops_perc, flops); returns a handle whose wait()
+    yields the same tuple for the GLOBAL batch.  `recompute(s3, s2, s1, cs) -> (flops_perc, flops)` is the model's
+    `flops_from_sparsities` bound to the input shape (see module docstring)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return outputs
+        return _Ready(outputs)
     world = dist.get_world_size(group)
     logits = outputs[0].contiguous()
     full = torch.empty((world * logits.shape[0],) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device)
-    dist.all_gather_into_tensor(full, logits, group=group)
-    vec, sizes = _pack_stats(outputs)
-    dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
-    vec = vec / world
-    groups, perc, flops = _unpack_stats(vec, sizes, len(outputs[1]))
-    return (full, list(groups[0]), list(groups[1]), list(groups[2]), list(groups[3]), perc, flops)
+    vec, sizes = _pack_sparsities(outputs)
+    works = [dist.all_gather_into_tensor(full, logits, group=group, async_op=True),
+             dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group, async_op=True)]
+    return PendingGather(outputs, full, vec, sizes, works, world, recompute)
+
+
+def gather_outputs(outputs, recompute=None, group=None):
+    """Blocking form of gather_outputs_async."""
+    return gather_outputs_async(outputs, recompute, group).wait()
+
+
+def recompute_for(model, x_shape):
+    """The `recompute` callable for a laudnet_amd model and an input shape [B_local, C, H, W] (the per-image FLOPs table does
+    not depend on the batch size)."""
+    return lambda s3, s2, s1, cs: model.flops_from_sparsities(tuple(x_shape), s3, s2, s1, cs)

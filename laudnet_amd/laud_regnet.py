@@ -115,7 +115,7 @@ class BottleneckTransform(_PrepCache):
         self._init_cache()
 
     def prepared(self, device):
-        if self._prep is not None:
+        if self._cache_valid():
             return self._prep
         if not self.has_se:
             raise LdnError("HIP path: RegNet-X (no SE) is not built -- the reference itself fails on it (self.se undefined)")
@@ -133,7 +133,7 @@ class BottleneckTransform(_PrepCache):
             p["se_b1"] = self.se.fc1.bias.detach().float().contiguous()
             p["se_w2"] = self.se.fc2.weight.detach().reshape(w_b, s).float().contiguous()
             p["se_b2"] = self.se.fc2.bias.detach().float().contiguous()
-            self._prep = {k: v.to(device) for k, v in p.items()}
+            self._cache_store({k: v.to(device) for k, v in p.items()})
         return self._prep
 
 
@@ -162,11 +162,11 @@ class ResBottleneckBlock(_PrepCache):
         self._init_cache()
 
     def _proj(self, device):
-        if self._prep is None:
+        if not self._cache_valid():
             with torch.no_grad():
                 sp, tp = _fold_bn(self.proj[1])
                 w = self.proj[0].weight.detach().reshape(self.proj[0].out_channels, 1, -1).float().contiguous()
-                self._prep = (w.to(device), sp.to(device), tp.to(device))
+                self._cache_store((w.to(device), sp.to(device), tp.to(device)))
         return self._prep
 
     def _ds_rows(self, B, Hi, Wi, Ho, Wo, s, dev):
@@ -195,9 +195,11 @@ class ResBottleneckBlock(_PrepCache):
         return (masker, f.conv1_flops_per_pixel * px_in, f.conv2_flops_per_pixel * px_out,
                 f.conv3_flops_per_pixel * px_out, proj, f.se_flops_per_pixel)
 
-    def run_dynamic(self, x):
-        """-> (out, stats[4] = s3, s2, s1, channel sparsity)"""
+    def run_dynamic(self, x, inplace=None):
+        """-> (out, stats[4] = s3, s2, s1, channel sparsity).  inplace: update the residual stream in place (only the owner
+        of x may ask for it: LAD_RegNet.forward does for its own intermediates; the module default never mutates its input)."""
         _eval_only(self, x)
+        inplace = bool(self.inplace_residual if inplace is None else inplace) and self.proj is None
         f = self.f
         if f.dyn_mode != "spatial" or f.mask_size != 1 or f.masker_spatial.mask_channel_group != 1:
             raise LdnError("HIP path (round 1): LAD-RegNet runs layer skip only -- dyn_mode='spatial' with "
@@ -230,7 +232,7 @@ class ResBottleneckBlock(_PrepCache):
             ops.conv_rows(x2d, wp, sp, tp, out2d, a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, self.stride, dev), taps=1,
                           m_cap=ix.cap3, relu=2, relu_if_neg=ix.pos3)
             resid = out2d
-        elif self.inplace_residual:
+        elif inplace:
             resid = out2d = x2d
         else:
             resid, out2d = x2d, torch.relu(x2d)
@@ -354,46 +356,68 @@ class LAD_RegNet(nn.Module):
             elif isinstance(m, nn.Linear) and "masker" not in name:
                 nn.init.normal_(m.weight, mean=0.0, std=0.01)
                 nn.init.zeros_(m.bias)
-        for m in self.modules():   # the network owns its intermediate activations (see laud_resnet.ResNet)
-            if isinstance(m, ResBottleneckBlock) and m.proj is None:
-                m.inplace_residual = True
+        self._tap = None
+        self.inplace_residual = True   # the network owns its intermediate activations (see laud_resnet.ResNet)
 
     def blocks(self):
         return [blk for stage in self.trunk_output.children() for blk in stage.children()]
 
     def forward(self, x, temperature):
         _eval_only(self, x)
-        c_in = x.shape[1]
+        in_shape = tuple(x.shape)
         x = x.contiguous(memory_format=torch.channels_last)
         x = self.stem(x)                                            # static stem: library ops
-        flops = c_in * x.shape[1] * x.shape[2] * x.shape[3] * (3 * 3)
-        stats, terms = [], []
+        stats = []
         sizes = [len(list(stage.children())) for stage in self.trunk_output.children()]
-        for blk in self.blocks():
-            terms.append(blk.flops_terms(x.shape))
-            x, st = blk.run_dynamic(x)
+        for j, blk in enumerate(self.blocks()):
+            if self._tap is not None:     # debug tap (bench / tests): sees every block's input; off by default
+                self._tap(j, blk.f, x)
+            x, st = blk.run_dynamic(x, inplace=self.inplace_residual)
             stats.append(st)
         st = torch.stack(stats)
-        key = (str(x.device), tuple(terms))
-        if getattr(self, "_terms_key", None) != key:
-            self._terms_key = key
-            self._terms = torch.tensor(terms, dtype=torch.float32, device=x.device)      # [n_blocks, 6]
-        tm = self._terms
         s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+        perc, flops = self.flops_from_sparsities(in_shape, s3, s2, s1, cs)
+        x = self.avgpool(x)
+        x = x.flatten(start_dim=1)
+        x = self.fc(x)
+        split = lambda v: list(torch.split(v, sizes))
+        return x, split(s3), split(s2), split(s1), split(cs), perc, flops
+
+    # ---- FLOPs bookkeeping (laud_regnet.py:179-203, 286-292, 576-611) from the input shape and the sparsities only
+    def flops_table(self, x_shape):
+        """(terms [n_blocks][6] = masker, a, b, c, proj, se per block; static FLOPs of stem, average pool, classifier)."""
+        _, c_in, h, w = x_shape
+        conv = self.stem[0]
+        k, s, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        h, w = (h + 2 * pd - k) // s + 1, (w + 2 * pd - k) // s + 1
+        c = conv.out_channels
+        static = c_in * c * h * w * k * k
+        terms = []
+        for blk in self.blocks():
+            terms.append(blk.flops_terms((1, c, h, w)))
+            c = blk.f.c[0].out_channels
+            h, w = (h - 1) // blk.stride + 1, (w - 1) // blk.stride + 1
+        static += c + c * self.fc.out_features
+        return terms, static
+
+    def flops_from_sparsities(self, x_shape, s3, s2, s1, cs):
+        """(flops_perc [n_blocks], flops) from per-block sparsities; see laud_resnet.ResNet.flops_from_sparsities."""
+        flat = lambda v: torch.cat([t.reshape(-1) for t in v]) if isinstance(v, (list, tuple)) else v
+        s3, s2, s1, cs = (flat(v).double() for v in (s3, s2, s1, cs))   # fp64 inside: the result does not depend on summation order
+        key = (str(s3.device), tuple(x_shape[1:]))
+        if getattr(self, "_terms_key", None) != key:
+            terms, static = self.flops_table(x_shape)
+            self._terms_key = key
+            self._terms = torch.tensor(terms, dtype=torch.float64, device=s3.device)      # [n_blocks, 6]
+            self._static_flops = float(static)
+        tm = self._terms
         sparse = tm[:, 0] + tm[:, 1] * cs * s1
         sparse = sparse + tm[:, 2] * cs ** 2 * s2
         sparse = sparse + tm[:, 3] * cs * s3
         sparse = sparse + tm[:, 4]
         perc = sparse / tm[:, :5].sum(dim=1)
-        flops = flops + sparse.sum() + tm[:, 5].sum()
-        x = self.avgpool(x)
-        flops = flops + x.shape[1] * x.shape[2] * x.shape[3]
-        x = x.flatten(start_dim=1)
-        c_in = x.shape[1]
-        x = self.fc(x)
-        flops = flops + c_in * x.shape[1]
-        split = lambda v: list(torch.split(v, sizes))
-        return x, split(s3), split(s2), split(s1), split(cs), perc, flops
+        flops = sparse.sum() + tm[:, 5].sum() + self._static_flops
+        return perc.float(), flops.float()
 
     def get_optim_policies(self):
         backbone_params, masker_params = [], []

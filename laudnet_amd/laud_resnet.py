@@ -63,22 +63,49 @@ def _side_stream(dev):
     return _SIDE_STREAMS[key]
 
 
+def _after_load(module, _incompatible_keys):
+    module._drop_cache()
+
+
 class _PrepCache(nn.Module):
-    """Mixin: lazily built, device-resident folded weights; dropped when parameters may have changed."""
+    """Mixin: lazily built, device-resident folded weights.  The cache is keyed on (data_ptr, _version) of every parameter
+    and buffer of the module's OWN sub-tree, so in-place edits (p.data.copy_, BN re-estimation, an optimizer step) are
+    noticed like load_state_dict / .to() / train() are; `invalidate()` is the public way to drop it by hand."""
 
     def _init_cache(self):
         self._prep = None
-        self.register_load_state_dict_post_hook(lambda m, _k: m._drop_cache())
+        self._prep_key = None
+        self._prep_src = None
+        self.register_load_state_dict_post_hook(_after_load)   # a module-level function: the module stays picklable
 
     def _drop_cache(self):
         self._prep = None
+        self._prep_key = None
+        self._prep_src = None
+
+    invalidate = _drop_cache
+
+    def _src_key(self):
+        src = self._prep_src
+        if src is None:
+            src = self._prep_src = [t for t in list(self.parameters()) + list(self.buffers())]
+        return tuple((t.data_ptr(), t._version) for t in src)
+
+    def _cache_valid(self):
+        """True when self._prep was built from the tensors as they are now."""
+        return self._prep is not None and self._prep_key == self._src_key()
+
+    def _cache_store(self, prep):
+        self._prep = prep
+        self._prep_key = self._src_key()
+        return prep
 
     def train(self, mode: bool = True):
-        self._prep = None
+        self._drop_cache()
         return super().train(mode)
 
     def _apply(self, fn, *a, **kw):
-        self._prep = None
+        self._drop_cache()
         return super()._apply(fn, *a, **kw)
 
 
@@ -105,10 +132,10 @@ class Masker_spatial(_PrepCache):
 
     def forward(self, x, temperature, want_logits=False):
         _eval_only(self, x)
-        if self._prep is None:
+        if not self._cache_valid():
             with torch.no_grad():
-                self._prep = (self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1).float().contiguous(),
-                              self.conv.bias.detach().float().contiguous())
+                self._cache_store((self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1).float().contiguous(),
+                                   self.conv.bias.detach().float().contiguous()))
         w, b = self._prep
         mask, logits = ops.spatial_masker(ops.as_nhwc(x), w, b, self.mask_channel_group, self.mask_size, want_logits)
         out = (mask, mask.mean(), self.flops_for(x))
@@ -156,14 +183,14 @@ class Masker_channel_MLP(_PrepCache):
         return x.shape[1] * x.shape[2] * x.shape[3] + self.conv_flops
 
     def _weights(self):
-        if self._prep is None:
+        if not self._cache_valid():
             with torch.no_grad():
                 f = lambda t: t.detach().float().contiguous()
                 if self.layers == 2:
-                    self._prep = (f(self.conv[0].weight), f(self.conv[0].bias), f(self.conv[2].weight),
-                                  f(self.conv[2].bias))
+                    self._cache_store((f(self.conv[0].weight), f(self.conv[0].bias), f(self.conv[2].weight),
+                                       f(self.conv[2].bias)))
                 else:
-                    self._prep = (f(self.conv.weight), f(self.conv.bias), None, None)
+                    self._cache_store((f(self.conv.weight), f(self.conv.bias), None, None))
         return self._prep
 
     accepts_fused_gap = True
@@ -211,12 +238,12 @@ class Masker_channel_conv_linear(_PrepCache):
                                       mask_in=mask_in.float().contiguous())
         if self.mid % 4 != 0:
             raise LdnError("Masker_channel_conv_linear on the HIP path needs in_channels//reduction % 4 == 0")
-        if self._prep is None:
+        if not self._cache_valid():
             with torch.no_grad():
                 sc, sh = _fold_bn(self.conv[1])
-                self._prep = (self.conv[0].weight.detach().reshape(self.mid, 1, -1).float().contiguous(), sc, sh,
-                              self.linear.weight.detach().float().contiguous(),
-                              self.linear.bias.detach().float().contiguous())
+                self._cache_store((self.conv[0].weight.detach().reshape(self.mid, 1, -1).float().contiguous(), sc, sh,
+                                   self.linear.weight.detach().float().contiguous(),
+                                   self.linear.bias.detach().float().contiguous()))
         w, sc, sh, lw, lb = self._prep
         xn = ops.as_nhwc(x)
         b, h, wd, _ = xn.shape
@@ -285,7 +312,10 @@ class Bottleneck(_PrepCache):
         # build-only hooks (default off)
         self.forced_spatial_mask = None
         self.forced_channel_mask = None
-        self.inplace_residual = False   # set by ResNet for its own intermediate tensors
+        # The residual stream may be updated IN PLACE (inactive pixels / layers then cost no HBM traffic), but only when the
+        # caller owns the input tensor: ResNet.forward passes inplace=True for its own intermediates.  The module-level
+        # default never mutates its input (reference semantics for Bottleneck.forward, hooks and feature taps).
+        self.inplace_residual = False
         # how a channel-mode block is executed: "gather" = per-image channel-subset convs (MACs skipped), "dense" =
         # shared-weight convs over multi-image row tiles with the mask applied to the conv outputs (no MACs skipped),
         # "auto" = dense on maps of <= 64 pixels, where streaming a private weight subset per image costs more than the
@@ -343,7 +373,7 @@ class Bottleneck(_PrepCache):
                 p["c1"], p["c2"], p["t2_tab"] = c1.contiguous(), c2.contiguous(), tab.contiguous()
                 bias3 = self.conv3.weight.detach().reshape(-1, W).float() @ c2
                 p["t3c"] = (p["t3"] + p["s3"] * bias3).contiguous()
-            self._prep = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in p.items()}
+            self._cache_store({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in p.items()})
         return self._prep
 
     # ---- execution ----------------------------------------------------------------------------
@@ -390,7 +420,7 @@ class Bottleneck(_PrepCache):
             out = identity
         else:
             identity = xn
-            out = xn if self.inplace_residual else torch.empty_like(xn)
+            out = xn if self._inplace else torch.empty_like(xn)
         ops.conv_packed(h2, p["w3_nk"], None, p["t3c"], out.view(B * Ho * Wo, cout), taps=1, m_cap=ix.cap3, relu=1,
                         residual2d=identity.view(B * Ho * Wo, cout))
         self.last_channel_mask = mask
@@ -413,7 +443,13 @@ class Bottleneck(_PrepCache):
         B, Cin, Hi, Wi = x.shape
         W, gran = self.width, self.channel_dyn_granularity
         Ho, Wo = (Hi - 1) // self.stride + 1, (Wi - 1) // self.stride + 1
-        if self.channel_exec == "dense" or (self.channel_exec == "auto" and Ho * Wo <= 64):
+        # dense execution uses the packed-row machinery, whose index set hard-codes Hi = Ho*stride on square maps: odd maps in
+        # front of a stride-2 block (208 / 240 px inputs: 13x13, 15x15) and non-square maps stay on the gather path, which
+        # takes the geometry explicitly
+        dense_ok = Ho == Wo and Hi == Ho * self.stride and Wi == Wo * self.stride
+        if self.channel_exec == "dense" and not dense_ok:
+            raise LdnError(f"Bottleneck: channel_exec='dense' needs a square map with Hi == Ho*stride (got {Hi}x{Wi} -> {Ho}x{Wo})")
+        if dense_ok and (self.channel_exec == "dense" or (self.channel_exec == "auto" and Ho * Wo <= 64)):
             return self._run_channel_dense(x, p)
         xn = ops.as_nhwc(x)
         if gap_in is not None and getattr(self.masker_channel, "accepts_fused_gap", False):
@@ -435,7 +471,7 @@ class Bottleneck(_PrepCache):
             out = identity
         else:
             identity = xn
-            out = xn if self.inplace_residual else torch.empty_like(xn)
+            out = xn if self._inplace else torch.empty_like(xn)
         h1 = torch.empty(B, Hi, Wi, W, device=dev, dtype=torch.float32)
         ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1)
         h2 = torch.empty(B, Ho, Wo, W, device=dev, dtype=torch.float32)
@@ -478,7 +514,7 @@ class Bottleneck(_PrepCache):
             ops.conv_rows(x2d, p["wd"], p["sd"], p["td"], out2d, a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev),
                           taps=1, m_cap=ix.cap3, relu=2, relu_if_neg=ix.pos3)
             resid = out2d
-        elif self.inplace_residual:
+        elif self._inplace:
             resid = out2d = x2d          # x >= 0 (post-ReLU) inside the network: inactive pixels pass through
         else:
             resid, out2d = x2d, torch.relu(x2d)
@@ -521,7 +557,7 @@ class Bottleneck(_PrepCache):
                           a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev), taps=1, m_cap=ix.cap3, relu=2,
                           relu_if_neg=ix.pos3)
             resid = out2d
-        elif self.inplace_residual:
+        elif self._inplace:
             resid = out2d = x2d
         else:
             resid, out2d = x2d, torch.relu(x2d)
@@ -540,12 +576,14 @@ class Bottleneck(_PrepCache):
             cache[key] = ((b * Hi + y) * Wi + xx).reshape(-1).to(torch.int32).contiguous()
         return cache[key]
 
-    def run_dynamic(self, x, gap_in=None, want_gap=False, defer_stats=False):
+    def run_dynamic(self, x, gap_in=None, want_gap=False, defer_stats=False, inplace=None):
         """Execute the block on the HIP path.  gap_in / want_gap: fused global-average-pool hand-off between
         consecutive channel-mode blocks (the conv3 epilogue leaves the channel sums the next masker needs).  Returns (out, stats[4] = {s3, s2, s1, channel sparsity} as a device
         tensor).  The FLOPs bookkeeping is separate (flops_terms) so a whole network can do it once, vectorised."""
         _eval_only(self, x)
-        p = self._prep if self._prep is not None else self._prepare(x.device)
+        p = self._prep if self._cache_valid() else self._prepare(x.device)
+        # in-place residual update: only on request (ResNet.forward, for tensors it owns) or by explicit opt-in on the module
+        self._inplace = bool(self.inplace_residual if inplace is None else inplace) and self.downsample is None
         if self.dyn_mode == "both":
             out, cmask, ix = self._run_both(x, p)
             stats = torch.cat((ix.stats, cmask.mean().reshape(1)))
@@ -651,11 +689,11 @@ class ResNet(nn.Module):
             for m in self.modules():
                 if isinstance(m, Bottleneck):
                     nn.init.constant_(m.bn3.weight, 0)
-        # the network owns its intermediate activations: blocks without a downsample branch may update
-        # the residual stream in place (their input is post-ReLU, hence >= 0)
-        for m in self.modules():
-            if isinstance(m, Bottleneck) and m.downsample is None:
-                m.inplace_residual = True
+        # The network owns its intermediate activations: forward() asks blocks without a downsample branch to update the
+        # residual stream in place (their input is post-ReLU, hence >= 0).  Set False to keep every block input intact
+        # (forward hooks / feature taps on block inputs).
+        self.inplace_residual = True
+        self._tap = None
 
     def _make_layer(self, block, planes, blocks, stride=1, dilate=False, output_size=56,
                     spatial_mask_channel_group=1, mask_spatial_granularity=1, channel_dyn_granularity=1,
@@ -684,54 +722,82 @@ class ResNet(nn.Module):
 
     def forward(self, x, temperature):
         _eval_only(self, x)
-        c_in = x.shape[1]
+        in_shape = tuple(x.shape)
         # static stem (laud_resnet.py:318-324): plain library ops, channels-last so the blocks see NHWC rows
         x = x.contiguous(memory_format=torch.channels_last)
         # eval-mode stem = conv with the BN folded into its weights, then max-pool, then ReLU on the pooled map
         # (relu(maxpool(y)) == maxpool(relu(y)): both are monotone) -- two full-resolution passes fewer than conv, bn, relu
         w, b = self._folded_stem()
         x = F.conv2d(x, w, b, self.conv1.stride, self.conv1.padding)
-        flops = c_in * x.shape[1] * x.shape[2] * x.shape[3] * self.conv1.weight.shape[2] * self.conv1.weight.shape[3]
         x = self.maxpool(x).relu_()
-        flops += x.shape[1] * x.shape[2] * x.shape[3] * 9
 
         # dynamic blocks: each returns its 4 sparsities as a device vector; the FLOPs bookkeeping of
         # laud_resnet.py:112-147,329-347 is done ONCE below on [n_blocks] vectors (no per-block scalar kernels)
-        stats, terms, sizes = [], [], []
+        stats = []
         blocks = [blk for i in range(4) for blk in getattr(self, f"layer{i + 1}")]
         sizes = [len(getattr(self, f"layer{i + 1}")) for i in range(4)]
         gap = None
         for j, blk in enumerate(blocks):
-            terms.append(blk.flops_terms(x.shape))
             nxt = blocks[j + 1] if j + 1 < len(blocks) else None
             # a channel-mode block leaves the GAP partials of its output for the next block's MLP masker
             want_gap = (nxt is not None and blk.dyn_mode == "channel" and nxt.dyn_mode == "channel"
                         and getattr(nxt.masker_channel, "accepts_fused_gap", False) and nxt.forced_channel_mask is None)
-            x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap, defer_stats=True)
+            if self._tap is not None:     # debug tap (bench / tests): sees every block's input; off by default
+                self._tap(j, blk, x)
+            x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap, defer_stats=True, inplace=self.inplace_residual)
             gap = getattr(blk, "last_gap", None) if want_gap else None
             stats.append(st)
         st = self._stack_stats(stats, x.device)                    # [n_blocks, 4] = s3, s2, s1, cs
-        key = (str(x.device), tuple(terms))
-        if getattr(self, "_terms_key", None) != key:
-            self._terms_key = key
-            self._terms = torch.tensor(terms, dtype=torch.float32, device=x.device)   # [n_blocks, 5]
-        tm = self._terms
         s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+        perc, flops = self.flops_from_sparsities(in_shape, s3, s2, s1, cs)
+
+        x = self.avgpool(x)
+        x = torch.flatten(x, 1)
+        x = self.fc(x)
+        split = lambda v: list(torch.split(v, sizes))
+        return x, split(s3), split(s2), split(s1), split(cs), perc, flops
+
+    # ---- FLOPs bookkeeping (laud_resnet.py:112-147, 321-356) as a function of the input SHAPE and the sparsities only
+    def flops_table(self, x_shape):
+        """Shape-only constants: (terms [n_blocks][5] = masker, conv1, conv2, conv3, downsample per block; static FLOPs of the
+        stem, max-pool, average pool and classifier).  No tensor is touched: usable on any host (laudnet_amd.distributed
+        recomputes the global-batch flops_perc / flops from all-reduced sparsities with it)."""
+        _, c_in, h, w = x_shape
+        k, s, pd = self.conv1.kernel_size[0], self.conv1.stride[0], self.conv1.padding[0]
+        h, w = (h + 2 * pd - k) // s + 1, (w + 2 * pd - k) // s + 1
+        c = self.conv1.out_channels
+        static = c_in * c * h * w * k * k
+        h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        static += c * h * w * 9
+        terms = []
+        for i in range(4):
+            for blk in getattr(self, f"layer{i + 1}"):
+                terms.append(blk.flops_terms((1, c, h, w)))
+                c = blk.conv3.out_channels
+                h, w = (h - 1) // blk.stride + 1, (w - 1) // blk.stride + 1
+        static += c            # adaptive average pool to 1x1: x.shape[1] * 1 * 1 after pooling (laud_resnet.py:350)
+        static += c * self.fc.out_features
+        return terms, static
+
+    def flops_from_sparsities(self, x_shape, s3, s2, s1, cs):
+        """(flops_perc [n_blocks], flops) from per-block sparsities (flat [n_blocks] tensors or per-stage lists).  This is the
+        ONLY place the model forms them: forward() calls it, and so does the multi-GPU gather with global-batch sparsities."""
+        flat = lambda v: torch.cat([t.reshape(-1) for t in v]) if isinstance(v, (list, tuple)) else v
+        s3, s2, s1, cs = (flat(v).double() for v in (s3, s2, s1, cs))   # fp64 inside: the result does not depend on summation order
+        key = (str(s3.device), tuple(x_shape[1:]))
+        if getattr(self, "_terms_key", None) != key:
+            terms, static = self.flops_table(x_shape)
+            self._terms_key = key
+            self._terms = torch.tensor(terms, dtype=torch.float64, device=s3.device)   # [n_blocks, 5]
+            self._static_flops = float(static)
+        tm = self._terms
         sparse = tm[:, 0] + tm[:, 1] * cs * s1
         sparse = sparse + tm[:, 2] * cs ** 2 * s2
         sparse = sparse + tm[:, 3] * cs * s3
         sparse = sparse + tm[:, 4]
         perc = sparse / tm.sum(dim=1)
-        flops = flops + sparse.sum()
-
-        x = self.avgpool(x)
-        flops = flops + x.shape[1] * x.shape[2] * x.shape[3]
-        x = torch.flatten(x, 1)
-        c_in = x.shape[1]
-        x = self.fc(x)
-        flops = flops + c_in * x.shape[1]
-        split = lambda v: list(torch.split(v, sizes))
-        return x, split(s3), split(s2), split(s1), split(cs), perc, flops
+        flops = sparse.sum() + self._static_flops
+        return perc.float(), flops.float()
 
     def _folded_stem(self):
         """conv1 weights scaled by bn1's eval affine (laud_resnet.py:318-320), cached until a parameter or buffer changes."""

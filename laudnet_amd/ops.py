@@ -2,6 +2,7 @@
 memory and the current stream; every computation below runs in libldn_hip.so.  No fallbacks."""
 from __future__ import annotations
 
+import threading
 from dataclasses import dataclass
 
 import torch
@@ -24,18 +25,32 @@ def _i32c(t, what):
 
 
 MATH_MODES = {"fp32": 0, "bf16x3": 1}
+_math = threading.local()   # the host-side default; the C library itself is stateless (math_mode is an argument of every conv call)
 
 
 def set_math_mode(mode):
-    """Arithmetic of the MFMA convolutions: "fp32" or "bf16x3" (see ldn_set_math_mode in include/ldn_hip.h)."""
-    if mode not in MATH_MODES:
+    """Default arithmetic of the MFMA convolutions issued from THIS thread: "fp32", "bf16x3" or None (= the library's
+    read-only process default, env LDN_MATH_MODE).  Passed to libldn_hip.so as the math_mode argument of each call."""
+    if mode is not None and mode not in MATH_MODES:
         raise L.LdnError(f"set_math_mode: unknown mode {mode!r} (expected one of {sorted(MATH_MODES)})")
-    L.check(L.load().ldn_set_math_mode(MATH_MODES[mode]), "ldn_set_math_mode")
+    _math.mode = mode
 
 
 def get_math_mode():
-    m = L.load().ldn_get_math_mode()
-    return next(k for k, v in MATH_MODES.items() if v == m)
+    mode = getattr(_math, "mode", None)
+    if mode is None:
+        m = L.load().ldn_default_math_mode()
+        mode = next(k for k, v in MATH_MODES.items() if v == m)
+    return mode
+
+
+def _mm(math=None):
+    mode = math if math is not None else getattr(_math, "mode", None)
+    return -1 if mode is None else MATH_MODES[mode]
+
+
+def _work(nbytes, dev):
+    return torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32) if nbytes else None
 
 
 def as_nhwc(x):
@@ -67,9 +82,7 @@ def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False):
     sy, sx = (mask_size, mask_size) if pooled else (H, W)
     mask = torch.empty(B, groups, sy, sx, device=x_nhwc.device, dtype=torch.float32)
     logits = torch.empty(B, 2 * groups, sy, sx, device=x_nhwc.device, dtype=torch.float32) if want_logits else None
-    work = None
-    if pooled and mask_size == 1:
-        work = torch.empty(B * lib.ldn_channel_masker_splits(H * W) * C, device=x_nhwc.device, dtype=torch.float32)
+    work = _work(lib.ldn_spatial_masker_workspace_bytes(B, H, W, C, mask_size), x_nhwc.device)
     L.check(lib.ldn_spatial_masker(L.ptr(_f32c(x_nhwc, "x")), B, H, W, C, L.ptr(_f32c(weight, "w")),
                                    L.ptr(_f32c(bias, "bias")), groups, mask_size, L.ptr(mask), L.ptr(logits), L.ptr(work),
                                    L.stream_ptr()), "ldn_spatial_masker")
@@ -106,7 +119,7 @@ def mask_to_index(patch_mask, out_h, out_w, stride):
                   pos1=torch.empty(cap1, **i32), nbr=torch.empty(cap3 * 9, **i32), cnt=torch.empty(2, **i32),
                   pre3=torch.empty(B + 1, **i32), pre1=torch.empty(B + 1, **i32),
                   stats=torch.empty(3, device=dev, dtype=torch.float32), cap3=cap3, cap1=cap1)
-    work = torch.empty(3 * B, **i32)
+    work = torch.empty(lib.ldn_mask_to_index_workspace_bytes(B) // 4, **i32)
     L.check(lib.ldn_mask_to_index(L.ptr(_f32c(patch_mask, "patch_mask")), B, S, out_h, out_w, stride, L.ptr(ix.idx3),
                                   L.ptr(ix.pos3), L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr), L.ptr(ix.cnt),
                                   L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr()),
@@ -141,7 +154,7 @@ def scatter_add_relu(packed, rows, identity2d, out2d=None, count=None, cap=None)
 
 # ---------------------------------------------------------------------------------------- a7 rows
 def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None, m_cap=None, relu=1,
-              relu_if_neg=None, out_rows=None, residual2d=None):
+              relu_if_neg=None, out_rows=None, residual2d=None, math=None):
     """Packed-row convolution (see ldn_conv_rows).  a2d [rows,lda>=cin]; w [cout,taps,cin]; out2d [rows,ldo]."""
     L.require_device(a2d, w, out2d)
     lib = L.load()
@@ -155,7 +168,7 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
                               L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,
                               L.ptr(_i32c(relu_if_neg, "relu_if_neg")), L.ptr(_i32c(out_rows, "out_rows")),
                               L.ptr(residual2d), residual2d.stride(0) if residual2d is not None else 0,
-                              L.ptr(_f32c(out2d, "out")), out2d.stride(0), L.stream_ptr()), "ldn_conv_rows")
+                              L.ptr(_f32c(out2d, "out")), out2d.stride(0), _mm(math), L.stream_ptr(out2d)), "ldn_conv_rows")
     return out2d
 
 
@@ -184,8 +197,7 @@ def channel_masker(x_nhwc, w1, b1, w2, b2, groups, gran, mask_in=None, want_logi
         B, H, W, C = x_nhwc.shape
         HW = H * W
         hidden = 0 if w2 is None else w1.shape[0]
-        splits = lib.ldn_channel_masker_splits(HW)
-        work = torch.empty(B * splits * C, device=dev, dtype=torch.float32)
+        work = _work(lib.ldn_channel_masker_workspace_bytes(B, HW, C), dev)
     width = groups * gran
     mask = torch.empty(B, groups, device=dev, dtype=torch.float32)
     idx = torch.empty(B, width, device=dev, dtype=torch.int32)
@@ -200,7 +212,7 @@ def channel_masker(x_nhwc, w1, b1, w2, b2, groups, gran, mask_in=None, want_logi
 
 # ---------------------------------------------------------------------------------------- a7 image
 def conv_image(a_nhwc, w, scale, shift, out_nhwc, *, ksize=1, stride=1, k_idx=None, k_cnt=None, kgran=1, n_idx=None,
-               n_cnt=None, post_sub=None, relu=1, residual=None, colsum=None):
+               n_cnt=None, post_sub=None, relu=1, residual=None, colsum=None, math=None):
     """Per-image channel-subset convolution (see ldn_conv_image).
     a_nhwc [B,Hi,Wi,lda]; w [cout,ksize*ksize,cin] without k_idx, [ksize*ksize,cin,cout] (k-major) with k_idx;
     shift [cout] or [16,cout]; out_nhwc [B,Ho,Wo,ldo]."""
@@ -220,14 +232,15 @@ def conv_image(a_nhwc, w, scale, shift, out_nhwc, *, ksize=1, stride=1, k_idx=No
                                L.ptr(_i32c(n_idx, "n_idx")), L.ptr(_i32c(n_cnt, "n_cnt")),
                                L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), classes, L.ptr(post_sub),
                                relu, L.ptr(residual), residual.shape[-1] if residual is not None else 0,
-                               L.ptr(_f32c(out_nhwc, "out")), ldo, L.ptr(colsum), L.stream_ptr()), "ldn_conv_image")
+                               L.ptr(_f32c(out_nhwc, "out")), ldo, L.ptr(colsum), _mm(math), L.stream_ptr(out_nhwc)),
+            "ldn_conv_image")
     return out_nhwc
 
 
 # ---------------------------------------------------------------------------------------- a7 packed (+ channel lists)
 def conv_packed(a2d, w, scale, shift, out2d, *, B=1, row_prefix=None, m_count=None, m_cap=None, a_map=None, taps=1,
                 out_map=None, pix_map=None, geom=None, k_idx=None, k_cnt=None, kgran=1, n_idx=None, n_cnt=None,
-                post_sub=None, relu=1, relu_if_neg=None, residual2d=None):
+                post_sub=None, relu=1, relu_if_neg=None, residual2d=None, math=None):
     """Convolution over packed pixel lists with optional per-image channel subsets (see ldn_conv_packed).
     geom = (Hi, Wi, Ho, Wo, stride) is only needed with a 16-class shift table."""
     L.require_device(a2d, w, out2d)
@@ -248,7 +261,7 @@ def conv_packed(a2d, w, scale, shift, out2d, *, B=1, row_prefix=None, m_count=No
                                 L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), classes, L.ptr(post_sub), relu,
                                 L.ptr(_i32c(relu_if_neg, "relu_if_neg")), L.ptr(residual2d),
                                 residual2d.stride(0) if residual2d is not None else 0, L.ptr(_f32c(out2d, "out")),
-                                out2d.stride(0), L.stream_ptr()), "ldn_conv_packed")
+                                out2d.stride(0), _mm(math), L.stream_ptr(out2d)), "ldn_conv_packed")
     return out2d
 
 
@@ -273,8 +286,7 @@ def se_packed(a2d, row_prefix, w1, b1, w2, b2, max_rows_per_image):
     lib = L.load()
     B = row_prefix.numel() - 1
     S, C = w1.shape
-    splits = lib.ldn_channel_masker_splits(max_rows_per_image)
-    work = torch.empty(B * (splits + 1) * C, device=a2d.device, dtype=torch.float32)
+    work = _work(lib.ldn_se_packed_workspace_bytes(B, C, max_rows_per_image), a2d.device)
     L.check(lib.ldn_se_packed(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(row_prefix, "row_prefix")), B, C, S,
                               L.ptr(_f32c(w1, "w1")), L.ptr(_f32c(b1, "b1")), L.ptr(_f32c(w2, "w2")), L.ptr(_f32c(b2, "b2")),
                               max_rows_per_image, L.ptr(work), L.stream_ptr()), "ldn_se_packed")

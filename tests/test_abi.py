@@ -35,26 +35,49 @@ def test_argument_validation_without_gpu():
     from laudnet_amd import _lib
     lib = _lib.load()
     # NULL pointers / bad shapes are rejected before any launch
-    assert lib.ldn_conv_rows(None, 0, None, 1, None, 10, None, 8, 8, None, None, 1, None, None, None, 0, None, 8, None) == -1
+    assert lib.ldn_conv_rows(None, 0, None, 1, None, 10, None, 8, 8, None, None, 1, None, None, None, 0, None, 8, -1, None) == -1
     assert b"null" in lib.ldn_last_error()
     assert lib.ldn_gather_rows(None, 4, None, None, 1, 3, None, 4, None) == -1
     assert lib.ldn_channel_masker_splits(3136) >= 1
 
 
-def test_math_mode_switch_without_gpu():
+def test_math_mode_is_an_argument_not_a_global():
+    """no global mutable state.  The library exports no setter; the mode travels as the math_mode argument of
+    every conv call (validated before any launch); the host-side default is thread-local."""
+    import threading
     from laudnet_amd import _lib, ops
     lib = _lib.load()
+    assert not hasattr(lib, "ldn_set_math_mode") and not hasattr(lib, "ldn_get_math_mode")
+    assert lib.ldn_default_math_mode() in (0, 1)
+    # a bad mode is an argument error of the call itself (checked after the pointer checks: give it non-NULL dummies)
+    dummy = ctypes.c_void_p(16)
+    assert lib.ldn_conv_rows(dummy, 8, None, 1, None, 10, dummy, 8, 8, None, dummy, 1, None, None, None, 0, dummy, 8, 7, None) == -1
+    assert b"math_mode" in lib.ldn_last_error()
     before = ops.get_math_mode()
     try:
         ops.set_math_mode("bf16x3")
-        assert ops.get_math_mode() == "bf16x3" and lib.ldn_get_math_mode() == 1
-        ops.set_math_mode("fp32")
-        assert lib.ldn_get_math_mode() == 0
-        assert lib.ldn_set_math_mode(7) == -1 and b"mode" in lib.ldn_last_error()
+        assert ops.get_math_mode() == "bf16x3" and ops._mm() == 1 and ops._mm("fp32") == 0
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ops._mm()))   # another thread does not inherit this thread's default
+        t.start()
+        t.join()
+        assert seen == [-1]
         with pytest.raises(_lib.LdnError):
             ops.set_math_mode("tf32")
     finally:
-        ops.set_math_mode(before)
+        ops.set_math_mode(before if before != ops.get_math_mode() else None)
+        ops.set_math_mode(None)
+
+
+def test_workspace_twins_without_gpu():
+    from laudnet_amd import _lib
+    lib = _lib.load()
+    splits = lib.ldn_channel_masker_splits(3136)
+    assert lib.ldn_channel_masker_workspace_bytes(256, 3136, 256) == 256 * splits * 256 * 4
+    assert lib.ldn_spatial_masker_workspace_bytes(4, 56, 56, 64, 14) == 0          # pooled to 14x14: no scratch
+    assert lib.ldn_spatial_masker_workspace_bytes(4, 56, 56, 64, 1) == 4 * splits * 64 * 4
+    assert lib.ldn_mask_to_index_workspace_bytes(256) == 3 * 256 * 4
+    assert lib.ldn_se_packed_workspace_bytes(8, 320, 196) == 8 * (lib.ldn_channel_masker_splits(196) + 1) * 320 * 4
 
 
 @pytest.mark.parametrize("name", ["r50_spatial_g1", "r101_channel2222", "r101_spatial4421", "r101_layer", "r50_mixed"])

@@ -1,6 +1,8 @@
-"""N>1 path on CPU: two gloo ranks shard a batch, run the (oracle) model on their shard and exchange results with
-laudnet_amd.distributed.gather_outputs -- the same function bench.py uses over RCCL.  The gathered 7-tuple must equal
-the single-process result on the full batch (logits bit-for-bit per shard order; statistics as global-batch means)."""
+"""N>1 path on CPU: gloo ranks shard a batch, run the (oracle) model on their shard and exchange results with
+laudnet_amd.distributed.gather_outputs -- the same function bench.py uses over RCCL.  The gathered 7-tuple must EQUAL the
+single-process result on the full batch: logits per shard order, sparsities as global-batch means, and flops_perc / flops
+recomputed from the global sparsities with the product model's shape-only FLOPs table (they contain channel_sparsity**2,
+laud_resnet.py:129, so averaging per-rank values would be wrong whenever shards keep different channel fractions)."""
 import os
 import socket
 import sys
@@ -12,6 +14,10 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+KW = dict(dyn_mode=["channel", "spatial", "layer", "channel"], channel_dyn_granularity=[2, 2, 2, 2],
+          channel_masker_layers=[2, 2, 2, 2], mask_spatial_granularity=[2, 2, 2, 1], width_mult=0.125,
+          input_size=64, num_classes=10)
+
 
 def _free_port():
     with socket.socket() as s:
@@ -19,54 +25,90 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(seed=3):
+def _build(batch, seed=3):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    from fill import fill_state_dict, seeded_randn
+    from fill import fill_state_dict, seeded_bernoulli, seeded_randn
     from oracle import torch_ref as TR
-    kw = dict(dyn_mode=["channel", "spatial", "layer", "channel"], channel_dyn_granularity=[2, 2, 2, 2],
-              channel_masker_layers=[2, 2, 2, 2], mask_spatial_granularity=[2, 2, 2, 1], width_mult=0.125,
-              input_size=64, num_classes=10)
-    model = TR.resnet50_ref(**kw).eval()
+    model = TR.resnet50_ref(**KW).eval()
     model.load_state_dict(fill_state_dict(model.state_dict(), seed))
-    x = seeded_randn((4, 3, 64, 64), 11)
+    x = seeded_randn((batch, 3, 64, 64), 11)
+    # UNEVEN masks: image b keeps a fraction of its channel groups / patches that grows with b, so every shard has a
+    # different channel sparsity (the case in which mean-of-per-rank flops differs from the global-batch flops)
+    for i, (_, blk) in enumerate(model.blocks()):
+        keep = torch.linspace(0.15, 0.95, batch)
+        if blk.masker_channel is not None:
+            g = blk.masker_channel.groups
+            blk.full_channel_mask = torch.stack([seeded_bernoulli((g,), float(keep[b]), 100 * i + b) for b in range(batch)])
+        if blk.masker_spatial is not None:
+            ms = blk.masker_spatial
+            shape = (ms.groups, ms.mask_size, ms.mask_size)
+            blk.full_spatial_mask = torch.stack([seeded_bernoulli(shape, float(keep[b]), 7000 + 100 * i + b) for b in range(batch)])
     return model, x
 
 
-def _worker(rank, world, port, out_path):
+def _force(model, lo, hi):
+    for _, blk in model.blocks():
+        if blk.masker_channel is not None:
+            blk.forced_channel_mask = blk.full_channel_mask[lo:hi]
+        if blk.masker_spatial is not None:
+            blk.forced_spatial_mask = blk.full_spatial_mask[lo:hi]
+
+
+def _worker(rank, world, port, batch, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
     sys.path.insert(0, ROOT)
+    import laudnet_amd
     from laudnet_amd import distributed as D
     r, w, _ = D.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
-    model, x = _build()
+    model, x = _build(batch)
     lo, hi = D.shard_bounds(x.shape[0], rank, world)
+    _force(model, lo, hi)
     with torch.no_grad():
         local = model(x[lo:hi], 1.0)
-    full = D.gather_outputs(local)
+    # the FLOPs table comes from the PRODUCT model class (shape-only, no HIP call): what bench.py passes on the GPU box
+    product = laudnet_amd.uni_resnet50(**KW).eval()
+    pending = D.gather_outputs_async(local, recompute=D.recompute_for(product, x[lo:hi].shape))
+    full = pending.wait()
     if rank == 0:
         torch.save(full, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world,batch", [(2, 4), (8, 8)])
+def test_gather_equals_single_process(tmp_path, world, batch):
     out_path = str(tmp_path / "gathered.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), batch, out_path), nprocs=world, join=True)
     got = torch.load(out_path, weights_only=False)
-    model, x = _build()
+    model, x = _build(batch)
+    _force(model, 0, batch)
     with torch.no_grad():
         want = model(x, 1.0)
     assert torch.allclose(got[0], want[0], atol=1e-5), "gathered logits must equal the full-batch logits"
     for g_list, w_list in zip(got[1:5], want[1:5]):
         for g, w in zip(g_list, w_list):
             assert torch.allclose(g, w, atol=1e-6), "per-stage sparsities must be global-batch means"
-    # flops_perc / flops contain channel_sparsity**2 (laud_resnet.py:129): the mean over ranks of a per-rank square is
-    # not the square of the global mean.  The reference averages per-rank values the same way (train/main.py:673-683).
-    assert torch.allclose(got[5], want[5], atol=2e-3)
-    assert torch.allclose(got[6], want[6], rtol=2e-3)
+    # sanity of the test itself: the shards' channel sparsities really differ
+    assert float(want[4][0].min()) < 0.9
+    assert torch.allclose(got[5], want[5], atol=1e-6, rtol=1e-6), "flops_perc must equal the global-batch value"
+    assert torch.allclose(got[6], want[6], rtol=1e-6, atol=0), "flops must equal the global-batch value"
+
+
+def test_mean_of_rank_flops_is_not_the_global_value():
+    """Why the recompute exists: with uneven shards the average of per-rank flops differs from the global-batch flops."""
+    model, x = _build(4)
+    with torch.no_grad():
+        _force(model, 0, 4)
+        want = model(x, 1.0)
+        parts = []
+        for lo in (0, 2):
+            _force(model, lo, lo + 2)
+            parts.append(model(x[lo:lo + 2], 1.0)[6])
+    assert abs(float((parts[0] + parts[1]) / 2 - want[6])) / float(want[6]) > 1e-4
 
 
 def test_shard_bounds():

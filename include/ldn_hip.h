@@ -142,12 +142,33 @@ size_t ldn_channel_masker_workspace_bytes(int B, int HW, int C);
  *                with k_idx,    w is k-major  [ksize*ksize][cin][cout]  (rows gathered through k_idx, columns
  *                through n_idx) -- every fetch then stays inside one row of the weight matrix.
  * kgran: the channel granularity of the index lists (channel_dyn_granularity): every run of `kgran` consecutive
- * list entries is a run of consecutive channels; must divide every count. */
+ * list entries is a run of consecutive channels; must divide every count.
+ * out_format: 0 = fp32 rows.  1 = rows PRE-SPLIT for ldn_bottleneck_tail (bf16x3 arithmetic only, no residual / colsum,
+ *   ldo % 32 == 0): every octet of 8 packed output columns is stored as [8 hi bf16 | 8 lo bf16] (hi = bf16(v), lo =
+ *   bf16(v - hi), the same 4 bytes per element), columns Nb .. roundup32(Nb)-1 zero-filled. */
 int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, int stride, int Ho, int Wo,
                    const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt, int kgran,
                    const int32_t* n_idx, const int32_t* n_cnt, const float* scale, const float* shift,
                    int shift_classes, const float* post_sub, int relu, const float* residual, int ldr,
-                   float* out, int ldo, float* colsum, int math_mode, void* stream);
+                   float* out, int ldo, float* colsum, int out_format, int math_mode, void* stream);
+
+/* ---- a7 (channel mode, bf16x3): FUSED TAIL of the bottleneck -- conv2 (3x3) -> bn2 + ReLU -> conv3 (1x1) -> bn3 + residual
+ * + ReLU in one launch (laud_resnet.py:123-144 on the active channels; stride 1; channel_dyn_granularity % 2 == 0;
+ * width in {64, 128, 256}; map width <= 256).  h2 never exists in memory and the 3x3 reads each K slice of h1 once for all
+ * nine taps.  Per image b with channel list ch_idx[b, 0 .. Kb-1] (ascending, aligned pairs), Kb = ch_cnt[b]:
+ *   h1_split [B*H*Wd][ldh]   conv1's output in ldn_conv_image's out_format 1 (left-packed columns = list positions)
+ *   w2_pairs [9][width/2][width/2][16 B]  piece (tap, kp, np) = for n in {2np, 2np+1}: bf16 {hi(w[n][2kp]), hi(w[n][2kp+1]),
+ *            lo(w[n][2kp]), lo(w[n][2kp+1])} with w[n][k] = conv2.weight[n, k, tap]            (k = input, n = output channel)
+ *   w3_pairs [width/2][cout][8 B]  entry (kp, c) = bf16 {hi(w3[c][2kp]), hi(w3[c][2kp+1]), lo(..), lo(..)}, w3 = bn3.scale * conv3.weight
+ *   u   = relu(scale2[n] * conv2 + shift2_tab[class(pixel)][n]) - post_sub2[n]      (16 border classes as in ldn_conv_image)
+ *   out = relu(w3 . u + shift3 + residual)          out/residual [B*H*Wd][ldo/ldr] fp32, may alias (in-place residual stream)
+ *   colsum (optional) [B][ldn_bottleneck_tail_splits(H, Wd)][cout]: partial sums of out over disjoint pixel sets covering
+ *   the image (the next block's channel masker takes them as gap_partial). */
+int ldn_bottleneck_tail_splits(int H, int Wd);
+int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int width, const void* w2_pairs,
+                        const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale2,
+                        const float* shift2_tab, const float* post_sub2, const float* shift3, const float* residual,
+                        int ldr, float* out, int ldo, float* colsum, void* stream);
 
 /* ---- a7 (spatial / layer / both): the same kernel over PACKED PIXEL LISTS ---------------------
  * Image b owns the packed rows [row_prefix[b], row_prefix[b+1]) (B == 1, row_prefix == NULL: rows [0, *m_count),

@@ -35,7 +35,9 @@ SIGNATURES = {
     "ldn_se_packed": ([_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P], _I),
     "ldn_se_packed_workspace_bytes": ([_I, _I, _I], C.c_size_t),
     "ldn_conv_image": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I,
-                        _P, _I, _P, _I, _P, _I, _P], _I),
+                        _P, _I, _P, _I, _P, _I, _I, _P], _I),
+    "ldn_bottleneck_tail_splits": ([_I, _I], _I),
+    "ldn_bottleneck_tail": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
 }
 
 _lib = None

@@ -67,6 +67,8 @@ struct ImgArgs {
     int bn;     // columns per N block (multiple of 32, <= NS*32)
     int bm;     // pixels per M block (multiple of 32, <= MS*32; balanced over the image)
     int math;   // 0 = fp32 MFMA, 1 = bf16x3 (resolved by the entry point, never read from a global)
+    int out_split;   // 1: out rows are written PRE-SPLIT for ldn_bottleneck_tail -- per octet of 8 channels [8 hi bf16 | 8 lo bf16]
+                     //    (same 4 bytes per element), zero-filled up to the next multiple of 32 channels (bf16x3 kernel only)
 };
 
 constexpr int BK = 32;   // K chunk = one 128-byte LDS row
@@ -170,7 +172,7 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
     if (p.k_idx && tid < p.cin) raw_k = p.k_idx[(size_t)b * p.cin + tid];
     const int Kb = p.k_idx ? p.k_cnt[b] : p.cin;
     const int Nb = p.n_idx ? p.n_cnt[b] : p.cout;
-    const int Nb4 = min(round_up(Nb, 4), p.cout);
+    const int Nb4 = min(round_up(Nb, p.out_split ? 32 : 4), p.cout);
     if (n0 >= Nb4 || m0 >= HWo) return false;
     const int T = p.packed ? p.ksize : p.ksize * p.ksize;   // packed mode: ksize carries the tap count (1 or 9)
     const int pad = p.packed ? (T == 9 ? 1 : 0) : p.ksize >> 1;
@@ -416,6 +418,19 @@ __device__ __forceinline__ void tile_store_rows(const ImgArgs& p, const Tile& t,
 #if LDN_ABLATE & 16
                 if (x[0] == 12345.678f)
 #endif
+                if (p.out_split) {
+                    // this lane's 4 channels are half an octet: hi halves -> bytes [0,16) of the octet's 32, lo halves -> [16,32)
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = (__bf16)x[e];
+                        lo[e] = (__bf16)(x[e] - (float)hi[e]);
+                    }
+                    float* oct = p.out + (size_t)ri.orow[it] * p.ldo + t.n0 + (ccol & ~7) + ((ccol & 4) >> 1);
+                    *reinterpret_cast<bf16x4*>(oct) = hi;
+                    *reinterpret_cast<bf16x4*>(oct + 4) = lo;
+                } else
                 *reinterpret_cast<f32x4*>(p.out + (size_t)ri.orow[it] * p.ldo + t.n0 + ccol) = x;
                 csum += x;
             }
@@ -1816,8 +1831,8 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
                               const float* w, int cin, int cout, const int32_t* k_idx, const int32_t* k_cnt,
                               int kgran, const int32_t* n_idx, const int32_t* n_cnt, const float* scale,
                               const float* shift, int shift_classes, const float* post_sub, int relu,
-                              const float* residual, int ldr, float* out, int ldo, float* colsum, int math_mode,
-                              void* stream) {
+                              const float* residual, int ldr, float* out, int ldo, float* colsum, int out_format,
+                              int math_mode, void* stream) {
     LDN_REQUIRE(a && w && shift && out, "ldn_conv_image: null pointer");
     int math;
     if (int rc = resolve_math(math_mode, &math)) return rc;
@@ -1840,7 +1855,9 @@ extern "C" int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, in
     LDN_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "ldn_conv_image: a/w must be 16-byte aligned");
     ImgArgs p{a, lda, B, Hi, Wi, ksize, stride, Ho, Wo, w, cin, cout, k_idx, k_cnt, n_idx, n_cnt,
               scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo, colsum,
-              0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, math};
+              0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, math, out_format};
+    LDN_REQUIRE(out_format == 0 || (out_format == 1 && math == 1 && !residual && !colsum && ldo % 32 == 0 && ldo >= round_up(cout, 32)),
+                "ldn_conv_image: out_format 1 (pre-split bf16 pairs) needs math_mode bf16x3, no residual / colsum and ldo %% 32 == 0");
     return dispatch_mode(p, kgran, static_cast<hipStream_t>(stream));
 }
 
@@ -1873,7 +1890,7 @@ extern "C" int ldn_conv_packed(const float* a, int lda, int B, const int32_t* ro
     if (m_cap <= 0) return LDN_OK;
     ImgArgs p{a, lda, B, Hi > 0 ? Hi : 1, Wi > 0 ? Wi : 1, taps, stride >= 1 ? stride : 1, Ho > 0 ? Ho : 1, Wo > 0 ? Wo : 1,
               w, cin, cout, k_idx, k_cnt, n_idx, n_cnt, scale, shift, shift_classes, post_sub, relu, residual, ldr, out, ldo,
-              nullptr, 1, row_prefix, m_count, m_cap, a_map, out_map, pix_map, relu_if_neg, 0, 0, 0, 0, math};
+              nullptr, 1, row_prefix, m_count, m_cap, a_map, out_map, pix_map, relu_if_neg, 0, 0, 0, 0, math, 0};
     return dispatch_mode(p, kgran, static_cast<hipStream_t>(stream));
 }
 

@@ -1,0 +1,490 @@
+// k_tail -- the fused tail of a channel-mode bottleneck (gfx950 / CDNA4, bf16x3 arithmetic):
+//
+//     conv2 (3x3, per-image input AND output channel subsets) -> bn2 + ReLU (+ the pre-BN mask constants of the channel
+//     algebra) -> conv3 (1x1, per-image input subset, all output channels) -> bn3 + residual + ReLU [+ fused GAP partials]
+//
+// in ONE launch (reference: imagenet_classification/models/laud_resnet.py:123-144 restricted to the active channels).
+// What it removes relative to the two launches it replaces (ldn_conv_image 3x3 + 1x1):
+//   * the 3x3 no longer re-stages its input map once per tap: a K slice of h1 (32 packed channels of every pixel of the
+//     block's halo'd input region) is DMA'd into LDS ONCE and stays there for all nine taps -- the tap shift is a per-lane LDS
+//     row address, out-of-image taps read a zero row;
+//   * h2 never exists in memory: the 3x3's accumulators are turned into the next GEMM's operand IN REGISTERS.  Everything is
+//     computed TRANSPOSED (out^T[channel][pixel] = W^T x act^T: MFMA A operand = weights, B operand = activations, lane =
+//     pixel), so the C layout of conv2 (lane = pixel, registers = channels) IS the B layout of conv3 up to a fixed permutation
+//     of the K order, which is applied to the weight side for free (the K order of a gathered GEMM is a list);
+//   * no operand is split in the K loops: h1 arrives pre-split from conv1's epilogue ([pixel][octet][8 hi | 8 lo] bf16), the
+//     weights are pre-split once per module into "pair-interleaved" k-major layouts whose gather unit (an aligned channel
+//     PAIR, channel_dyn_granularity % 2 == 0) is one 16-byte DMA piece, so that a weight fragment is four ds_read_b64 and no VALU.
+// One 512-thread workgroup = 8 waves, wave w owns the 32 output pixels [32w, 32w+32) of the block (<= 256 pixels: whole
+// 14x14 images, 7 rows of a 28x28 map, 4 rows of a 56x56 map) for ALL channels; there are no producer waves: every wave
+// issues its share of the LDS-DMA (inline asm, counted s_waitcnt vmcnt(N): the DMA of chunk c+2 and of the next h1 slice fly
+// across the barriers of chunks c and c+1).
+#include "ldn_common.h"
+
+namespace ldn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct TailArgs {
+    const unsigned char* h1; long h1_row_bytes;       // pre-split h1: row of pixel q at h1 + q * h1_row_bytes
+    int B, Hi, Wi, Ho, Wo, W, cout;                   // stride 1: Hi == Ho, Wi == Wo
+    const unsigned char* w2p;                         // [9][W/2][W/2] pieces of 16 B (see ldn_hip.h)
+    const unsigned char* w3p;                         // [W/2][cout] entries of 8 B
+    const int32_t* k_idx; const int32_t* k_cnt;       // [B][W], [B]
+    const float* sc2; const float* sh2; const float* ps2;   // [W], [16][W], [W]
+    const float* sh3;                                 // [cout]
+    const float* residual; int ldr; float* out; int ldo;
+    float* colsum;                                    // optional [B][mblocks*8][cout]
+    int rows_per_blk, mblocks;                        // output rows per workgroup, workgroups per image
+    int slice_bytes;                                  // bytes of one h1 slice slot (multiple of 1024)
+};
+
+__device__ __attribute__((aligned(16))) float g_tail_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+// LDS-DMA of 16 bytes per lane: LDS destination = lds_base (wave-uniform byte address) + lane * 16, source per lane.
+// Inline asm: the compiler neither counts it nor waits for it (cdna_hip_programming.md 5.7) -- every wait is explicit below.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N == 0 || N == 1 || N == 2 || N == 4, "add the immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+}
+__device__ __forceinline__ void lds_barrier() {   // LDS traffic of this wave retired, then the workgroup barrier (no vmcnt)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ unsigned lds_off(const void* ptr) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)ptr;
+}
+
+__device__ __forceinline__ void split2(float v, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+}
+
+constexpr int T_KIDX_BYTES = 1280;        // int[W + 32] channel list (W <= 256)
+constexpr int T_W2_SLOTS = 3;
+
+// NS = W / 32 (maximum n-subtiles / K slices of an image): 2, 4 or 8
+template <int NS>
+__global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
+    constexpr int W = NS * 32;
+    constexpr int W2_ROW = NS * 256;                  // bytes of one k-pair row of the staged W2 tile: W entries of 8 B
+    constexpr int W2_SLOT = 16 * W2_ROW;              // 16 k-pairs = one K slice of 32
+    constexpr int CW = NS == 8 ? 32 : 64;             // output channels per conv3 chunk
+    constexpr int NCS = CW / 32;
+    constexpr int W3_ROW = CW * 8;                    // bytes of one k-pair row of the staged W3 chunk
+    constexpr int RPI = 1024 / W3_ROW;                // rows per DMA instruction
+    constexpr int W3_SLOT = (W / 2) * W3_ROW;
+    constexpr int NP = W;                             // table width
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* const s_kidx = reinterpret_cast<int*>(smem);
+    unsigned char* const s_h1 = smem + T_KIDX_BYTES;                      // 2 slice slots (conv2 phase)
+    unsigned char* const s_w2 = s_h1 + 2 * p.slice_bytes;                 // 3 W2 slots   (conv2 phase)
+    unsigned char* const s_w3 = smem + T_KIDX_BYTES;                      // 2 W3 slots   (conv3 phase, over the above)
+    float* const s_tab = reinterpret_cast<float*>(s_w3 + 2 * W3_SLOT);    // sc2[NP], ps2[NP], sh2[16][NP] (conversion)
+    unsigned char* const s_scr = reinterpret_cast<unsigned char*>(s_tab + 18 * NP);   // 8 x 4 KiB transpose scratch
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x % p.B, mb = blockIdx.x / p.B;     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
+
+    // ---- geometry of this workgroup's block of output rows and of its halo'd input region (stride 1, pad 1)
+    const int y0 = mb * p.rows_per_blk;
+    const int rows = min(p.rows_per_blk, p.Ho - y0);
+    const int npix = rows * p.Wo;                              // <= 256
+    const int yin0 = max(y0 - 1, 0), yin1 = min(y0 + rows, p.Hi - 1);
+    const int NR = (yin1 - yin0 + 1) * p.Wi;                   // input pixels resident per slice
+    const int NRp = round_up(NR, 8);
+    const int ZR = NRp;                                        // index of the all-zero row of each slice slot
+    const long in_row0 = (long)b * p.Hi * p.Wi + (long)yin0 * p.Wi;     // first input pixel (flat) of the region
+    const long out_row0 = (long)b * p.Ho * p.Wo + (long)y0 * p.Wo;      // first output pixel (flat) of the block
+
+    const int Kb = min(p.k_cnt[b], W);
+    const int nsub = ceil_div(Kb, 32);                         // n-subtiles == K slices (conv2 is square: same list)
+    const int Kp = nsub * 32;
+    if (tid < W + 32) s_kidx[tid] = tid < Kb ? p.k_idx[(size_t)b * W + tid] : -1;
+    // the zero rows of the two slice slots (never touched by the DMA, which covers rows 0 .. NRp-1)
+    if (tid < 64) reinterpret_cast<float*>(s_h1 + (tid >> 5) * p.slice_bytes + ZR * 128)[tid & 31] = 0.f;
+    __syncthreads();
+
+    // ---- this lane's output pixel and its nine tap rows in the slice (ZR = zero row)
+    const int pm = wave * 32 + l31;
+    const bool pvalid = pm < npix;
+    const int oy = y0 + pm / p.Wo, ox = pm % p.Wo;
+    int trow[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+        const bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        trow[t] = ok ? (iy - yin0) * p.Wi + ix : ZR;
+    }
+    // border class of the pixel for the shift table of the channel algebra: (top | bottom << 1) * 4 + (left | right << 1)
+    const int cls = (((oy - 1 < 0) | ((oy + 1 >= p.Hi) << 1)) * 4 + ((ox - 1 < 0) | ((ox + 1 >= p.Wi) << 1)));
+
+    // ---- DMA helpers -------------------------------------------------------------------------------------------------------
+    const unsigned lds_h1 = lds_off(s_h1), lds_w2 = lds_off(s_w2), lds_w3 = lds_off(s_w3);
+    // h1 slice piece q (rows 8q .. 8q+7 of the region, 128 B each): lane = (row 8q + (lane >> 3), physical slot lane & 7);
+    // the XOR swizzle (slot ^ ((row >> 1) & 7)) is applied to the SOURCE address (the LDS image of a DMA is lane-linear)
+    auto dma_h1 = [&](int slice, int q) {
+        const int r = q * 8 + (lane >> 3);
+        const int lslot = (lane & 7) ^ ((r >> 1) & 7);
+        const unsigned char* src = r < NR ? p.h1 + (in_row0 + r) * p.h1_row_bytes + slice * 128 + lslot * 16
+                                          : reinterpret_cast<const unsigned char*>(g_tail_zero);
+        dma16(src, lds_h1 + (slice & 1) * p.slice_bytes + q * 1024);
+    };
+    // W2 chunk (slice s, tap t): 16 k-pair rows x (Kp / 2) n-pair pieces of 16 B.  Wave w stages rows 2w and 2w + 1.
+    //   NS == 2: one instruction covers both rows (lanes 0-31 / 32-63); NS == 4: one instruction per row;
+    //   NS == 8: two per row (n-pairs 0-63 / 64-127), the second only when the image has more than 128 active channels.
+    const int n_w2 = NS == 2 ? 1 : (NS == 4 ? 2 : (Kp > 128 ? 4 : 2));       // DMA instructions per wave and chunk
+    // per-lane n-pair source offsets (fixed for the whole kernel)
+    long npo[NS == 8 ? 2 : 1];
+#pragma unroll
+    for (int e = 0; e < (NS == 8 ? 2 : 1); ++e) {
+        const int v = (NS == 2 ? (lane & 31) : lane) + 64 * e;               // packed n-pair
+        const int ch = 2 * v < Kb ? s_kidx[2 * v] : -1;
+        npo[e] = ch >= 0 ? (long)(ch >> 1) * 16 : -1;
+    }
+    auto dma_w2 = [&](int c) {
+        const int s = c / 9, t = c - 9 * s;
+        const unsigned slot = lds_w2 + (c % T_W2_SLOTS) * W2_SLOT;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int u = 2 * wave + (NS == 2 ? (lane >> 5) : e);            // k-pair row of the slice
+            const int kch = s_kidx[32 * s + 2 * u];                          // -1 beyond the image's list
+            const long rowoff = ((long)t * (W / 2) + (kch >> 1)) * (W / 2) * 16;
+            if (NS == 2) {
+                if (e == 1) break;
+                const unsigned char* src = (kch >= 0 && npo[0] >= 0) ? p.w2p + rowoff + npo[0] : reinterpret_cast<const unsigned char*>(g_tail_zero);
+                dma16(src, slot + 2 * wave * W2_ROW);
+            } else if (NS == 4) {
+                const unsigned char* src = (kch >= 0 && npo[0] >= 0) ? p.w2p + rowoff + npo[0] : reinterpret_cast<const unsigned char*>(g_tail_zero);
+                dma16(src, slot + u * W2_ROW);
+            } else {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    if (f == 1 && Kp <= 128) break;
+                    const unsigned char* src = (kch >= 0 && npo[f] >= 0) ? p.w2p + rowoff + npo[f] : reinterpret_cast<const unsigned char*>(g_tail_zero);
+                    dma16(src, slot + u * W2_ROW + f * 1024);
+                }
+            }
+        }
+    };
+    auto wait_chunk = [&]() {   // everything but this wave's last n_w2 DMA instructions (= the W2 pieces of the NEXT chunk) has landed
+        if (n_w2 == 1) wait_vm<1>();
+        else if (n_w2 == 2) wait_vm<2>();
+        else wait_vm<4>();
+    };
+
+    // ======================================================================================================== conv2 (3x3)
+    f32x16 acc[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int nchunks = nsub * 9;
+    const int nq = NRp / 8;                                     // DMA pieces per h1 slice (<= 72)
+    const bool active = wave * 32 < npix;                       // waves beyond the block's pixels only stage and synchronise
+    if (nchunks > 0) {
+        for (int q = wave; q < nq; q += 8) dma_h1(0, q);        // slice 0
+        dma_w2(0);
+        dma_w2(1);                                              // nchunks >= 9
+    }
+    // fragment addressing
+    const unsigned a_lane = (unsigned)(4 * h * W2_ROW + l31 * 8);          // A (weights): k-pair rows 4h .. 4h+3 of a K16 step
+    for (int s = 0; s < nsub; ++s) {
+        const unsigned char* hs = s_h1 + (s & 1) * p.slice_bytes;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {                           // chunk c = 9 s + t lives in W2 slot c % 3 == t % 3
+            const int c = 9 * s + t;
+            wait_chunk();
+            lds_barrier();     // chunk c (and, when t == 0, slice s) is in LDS for every wave; every wave has left chunk c - 1
+            // issue: next slice's share first, then the W2 tile of chunk c + 2 (issue order matters for the counted wait)
+            if (s + 1 < nsub) { const int q = t * 8 + wave; if (q < nq) dma_h1(s + 1, q); }
+            if (c + 2 < nchunks) dma_w2(c + 2);
+            else { for (int e = 0; e < n_w2; ++e) dma16(g_tail_zero, lds_w2 + ((t + 2) % T_W2_SLOTS) * W2_SLOT + (2 * wave) * W2_ROW); }   // keeps the count
+            if (!active) continue;
+            // compute chunk c: tap t of K slice s.  B fragment = h1 row of the tap (per-lane LDS address), A = staged W2 rows.
+            const unsigned char* ws = s_w2 + (t % T_W2_SLOTS) * W2_SLOT;
+            const unsigned rbase = (unsigned)trow[t] * 128u, rx = ((unsigned)trow[t] >> 1) & 7u;
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const unsigned sl = 2u * (2u * half + h);       // logical 16-byte slot of this lane's octet (hi); lo = sl + 1
+                bh[half] = *reinterpret_cast<const bf16x8*>(hs + rbase + ((sl ^ rx) << 4));
+                bl[half] = *reinterpret_cast<const bf16x8*>(hs + rbase + (((sl + 1) ^ rx) << 4));
+            }
+            // per n-subtile: two K16 steps; the weight fragment of the second is requested before the MFMAs of the first
+            // (the schedule is pinned: left alone, hipcc hoists every fragment read of the chunk and spills)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                if (j < nsub) {
+                    u32x2 e0[4], e1[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) e0[q] = *reinterpret_cast<const u32x2*>(ws + a_lane + q * W2_ROW + j * 256);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) e1[q] = *reinterpret_cast<const u32x2*>(ws + a_lane + (8 + q) * W2_ROW + j * 256);
+                    {
+                        const u32x4 ahu = {e0[0][0], e0[1][0], e0[2][0], e0[3][0]};
+                        const u32x4 alu = {e0[0][1], e0[1][1], e0[2][1], e0[3][1]};
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[j], 0, 0, 0);
+                    }
+                    {
+                        const u32x4 ahu = {e1[0][0], e1[1][0], e1[2][0], e1[3][0]};
+                        const u32x4 alu = {e1[0][1], e1[1][1], e1[2][1], e1[3][1]};
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                }
+            }
+        }
+    }
+    wait_vm<0>();
+    lds_barrier();         // every wave is out of the conv2 loop: the slice / W2 regions are free
+
+    // ======================================================================================================== conv3 (1x1)
+    // Output channels are walked in chunks of CW (64; 32 for the widest layer, whose h2 operand alone takes 128 registers and
+    // whose staged weight chunk would otherwise not leave room for the transpose scratch), NCS sub-passes of 32 channels each.
+    const int nchunk3 = p.cout / CW;
+    // W3 chunk cc: (Kp / 2) k-pair rows x CW output channels x 8 B; one DMA instruction = RPI rows of CW * 8 bytes
+    auto dma_w3 = [&](int cc) {
+        const unsigned slot = lds_w3 + (cc & 1) * W3_SLOT;
+        constexpr int LPR = 64 / RPI;                            // lanes (16-byte pieces = channel pairs) per row
+        for (int i = wave; i < Kp / (2 * RPI); i += 8) {
+            const int u = RPI * i + lane / LPR;
+            const int kch = s_kidx[2 * u];
+            const unsigned char* src = kch >= 0 ? p.w3p + ((long)(kch >> 1) * p.cout + cc * CW + 2 * (lane % LPR)) * 8
+                                                : reinterpret_cast<const unsigned char*>(g_tail_zero);
+            dma16(src, slot + i * 1024);
+        }
+    };
+    if (nchunk3 > 0) dma_w3(0);
+
+    // ---- conversion tables (gathered through the channel list), then acc -> h2 operand fragments in registers
+    for (int i = tid; i < NP; i += 512) {
+        const int ch = i < Kb ? s_kidx[i] : -1;
+        s_tab[i] = ch >= 0 ? p.sc2[ch] : 0.f;
+        s_tab[NP + i] = ch >= 0 ? p.ps2[ch] : 0.f;
+    }
+    for (int i = tid; i < 16 * NP; i += 512) {
+        const int k = i / NP, n = i - k * NP;
+        const int ch = n < Kb ? s_kidx[n] : -1;
+        s_tab[2 * NP + i] = ch >= 0 ? p.sh2[k * W + ch] : 0.f;
+    }
+    lds_barrier();
+    // In place: the 16 fp32 accumulators of n-subtile j become 16 dwords of bf16 pairs -- for each K16 step t of conv3
+    // [8t .. 8t+3] = the 8 hi halves, [8t+4 .. 8t+7] = the 8 lo halves of the lane's h2 values (k-slot e = 4 qq + i <->
+    // accumulator register 8t + 4 qq + i).  No second register array: h2 of the widest layer alone takes 128 registers.
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        float v[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int n0 = 32 * j + 8 * q4 + 4 * h;             // register quad q4: rows n = 32 j + 8 q4 + 4 h + {0..3}
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_tab + n0);
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(s_tab + NP + n0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(s_tab + 2 * NP + cls * NP + n0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[4 * q4 + e] = fmaxf(acc[j][4 * q4 + e] * sc[e] + sh[e], 0.f) - ps[e];   // columns without a channel: 0 * 0 + 0
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {                       // dword d of the step = k-slots 2d, 2d + 1 = registers 8t + 2d, 8t + 2d + 1
+                const float x0 = v[8 * t + 2 * d], x1 = v[8 * t + 2 * d + 1];
+                const bf16x2 hi = {(__bf16)x0, (__bf16)x1};
+                const bf16x2 lo = {(__bf16)(x0 - (float)hi[0]), (__bf16)(x1 - (float)hi[1])};
+                acc[j][8 * t + d] = __builtin_bit_cast(float, hi);
+                acc[j][8 * t + 4 + d] = __builtin_bit_cast(float, lo);
+            }
+        // compiler memory barrier + scheduling barrier: left alone, hipcc hoists the table reads of ALL subtiles to the top
+        // (96 ds_read_b128 = 384 registers) and spills them
+        asm volatile("" : "+v"(acc[j]) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto frag_hi = [&](int j, int t) -> bf16x8 {
+        const f32x4 x = {acc[j][8 * t], acc[j][8 * t + 1], acc[j][8 * t + 2], acc[j][8 * t + 3]};
+        return __builtin_bit_cast(bf16x8, x);
+    };
+    auto frag_lo = [&](int j, int t) -> bf16x8 {
+        const f32x4 x = {acc[j][8 * t + 4], acc[j][8 * t + 5], acc[j][8 * t + 6], acc[j][8 * t + 7]};
+        return __builtin_bit_cast(bf16x8, x);
+    };
+
+    const int trw = lane >> 3, tc = lane & 7;                  // epilogue layout: lane = (row trw + 8 it, 4 channels at 4 tc)
+    const unsigned a3_lane = (unsigned)(2 * h * W3_ROW + l31 * 8);
+    float* const scr = reinterpret_cast<float*>(s_scr + wave * 4096);   // this wave's 32 x 32 transpose scratch
+    for (int cc = 0; cc < nchunk3; ++cc) {
+        if (cc == 0) { wait_vm<0>(); lds_barrier(); }           // W3(0) is in LDS for every wave
+        if (cc + 1 < nchunk3) dma_w3(cc + 1);                   // slot (cc + 1) & 1: every wave left it before the last barrier
+        const unsigned char* ws = s_w3 + (cc & 1) * W3_SLOT;
+#pragma unroll
+        for (int cs = 0; cs < NCS; ++cs) {
+            const int c0 = cc * CW + cs * 32;
+            // residual tile in the layout the epilogue stores in, requested before the K loop that hides its latency
+            f32x4 res[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int prow = wave * 32 + trw + 8 * it;
+                const float* src = (p.residual && prow < npix) ? p.residual + (size_t)(out_row0 + prow) * p.ldr + c0 + tc * 4 : g_tail_zero;
+                res[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            }
+            f32x16 acc3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                if (j < nsub && active) {
+                    // k-pair rows P0 + {0, 1, 4, 5}, P0 = 16 j + 8 t + 2 h: the K order in which lane (pixel, h) holds h2
+                    u32x2 e[2][4];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            e[t][q] = *reinterpret_cast<const u32x2*>(ws + a3_lane + (16 * j + 8 * t + (q & 1) + 4 * (q >> 1)) * W3_ROW + cs * 256);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const u32x4 ahu = {e[t][0][0], e[t][1][0], e[t][2][0], e[t][3][0]};
+                        const u32x4 alu = {e[t][0][1], e[t][1][1], e[t][2][1], e[t][3][1]};
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
+                        const bf16x8 hb = frag_hi(j, t), lb = frag_lo(j, t);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, hb, acc3, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, lb, acc3, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, hb, acc3, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                }
+            }
+            if (cs == NCS - 1) wait_vm<0>();   // this wave's share of W3(cc + 1) has landed (its earlier stores and the residual too);
+                                               // placed BEFORE this sub-pass's stores, which then fly through the next chunk
+            // C layout (lane = pixel l31, register r = channel (r & 3) + 8 (r >> 2) + 4 h) -> rows of 32 channels per pixel,
+            // 16-byte slots XOR-swizzled with the pixel so that both the writes and the row reads are conflict-free
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = {acc3[4 * q4], acc3[4 * q4 + 1], acc3[4 * q4 + 2], acc3[4 * q4 + 3]};
+                *reinterpret_cast<f32x4*>(scr + l31 * 32 + (((2 * q4 + h) ^ (l31 & 7)) << 2)) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.sh3 + c0 + tc * 4);
+            f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = trw + 8 * it, prow = wave * 32 + row;
+                f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
+                x = x + sh + res[it];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+                if (prow < npix) {
+                    __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p.out + (size_t)(out_row0 + prow) * p.ldo + c0 + tc * 4));
+                    csum += x;
+                }
+            }
+            if (p.colsum) {   // fused global-average-pool partials (the next block's channel masker): one slot per (block, wave)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = csum[e];
+                    x += __shfl_xor(x, 8, 64);
+                    x += __shfl_xor(x, 16, 64);
+                    x += __shfl_xor(x, 32, 64);
+                    csum[e] = x;
+                }
+                if (trw == 0)
+                    *reinterpret_cast<f32x4*>(p.colsum + ((size_t)b * (p.mblocks * 8) + mb * 8 + wave) * p.cout + c0 + tc * 4) = csum;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        lds_barrier();     // every wave has left slot cc & 1 (refilled by the DMA of chunk cc + 2 in the next iteration)
+    }
+}
+
+static int tail_rows_per_block(int Ho, int Wo, int* mblocks) {
+    int R = 256 / Wo;
+    if (R < 1) R = 1;
+    if (R > Ho) R = Ho;
+    const int mbk = ceil_div(Ho, R);
+    *mblocks = mbk;
+    return ceil_div(Ho, mbk);
+}
+
+template <int NS>
+static int launch_tail(TailArgs& a, hipStream_t st) {
+    constexpr int W = NS * 32;
+    const int R = a.rows_per_blk;
+    const int nr = min(R + 2, a.Hi) * a.Wi;
+    a.slice_bytes = round_up((round_up(nr, 8) + 1) * 128, 1024);
+    const size_t lds2 = (size_t)T_KIDX_BYTES + 2 * (size_t)a.slice_bytes + (size_t)T_W2_SLOTS * 16 * NS * 256;
+    const size_t lds3 = (size_t)T_KIDX_BYTES + 2 * (size_t)(W / 2) * (NS == 8 ? 32 : 64) * 8 + (size_t)18 * W * 4 + 8 * 4096;
+    const size_t lds = lds2 > lds3 ? lds2 : lds3;
+    LDN_REQUIRE(lds <= 160 * 1024, "ldn_bottleneck_tail: %zu B of LDS exceed 160 KiB (map %dx%d, width %d)", lds, a.Ho, a.Wo, W);
+    LDN_REQUIRE(round_up(nr, 8) / 8 <= 72, "ldn_bottleneck_tail: input region of %d pixels too large for the slice pipeline", nr);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_tail<NS>), lds), "k_tail: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((k_tail<NS>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
+    LDN_CHECK_LAUNCH("k_tail");
+    return LDN_OK;
+}
+
+}  // namespace ldn
+
+using namespace ldn;
+
+extern "C" int ldn_bottleneck_tail_splits(int Ho, int Wo) {
+    int mbk = 0;
+    if (Ho < 1 || Wo < 1 || Wo > 256) return 0;
+    (void)tail_rows_per_block(Ho, Wo, &mbk);
+    return mbk * 8;
+}
+
+extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int width, const void* w2_pairs,
+                                   const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
+                                   const float* scale2, const float* shift2_tab, const float* post_sub2,
+                                   const float* shift3, const float* residual, int ldr, float* out, int ldo,
+                                   float* colsum, void* stream) {
+    LDN_REQUIRE(h1_split && w2_pairs && w3_pairs && ch_idx && ch_cnt && scale2 && shift2_tab && post_sub2 && shift3 && out,
+                "ldn_bottleneck_tail: null pointer");
+    LDN_REQUIRE(width == 64 || width == 128 || width == 256, "ldn_bottleneck_tail: width must be 64, 128 or 256 (got %d)", width);
+    LDN_REQUIRE(B > 0 && H > 0 && Wd > 0 && Wd <= 256, "ldn_bottleneck_tail: bad geometry (map width must be <= 256)");
+    LDN_REQUIRE(cout > 0 && cout % 64 == 0, "ldn_bottleneck_tail: cout must be a multiple of 64 (got %d)", cout);
+    LDN_REQUIRE(ldh >= width && ldh % 8 == 0, "ldn_bottleneck_tail: ldh must be a multiple of 8 and >= width");
+    LDN_REQUIRE(ldo >= cout && ldo % 4 == 0 && (!residual || (ldr >= cout && ldr % 4 == 0)), "ldn_bottleneck_tail: bad ldo / ldr");
+    LDN_REQUIRE((uintptr_t)h1_split % 16 == 0 && (uintptr_t)w2_pairs % 16 == 0 && (uintptr_t)w3_pairs % 16 == 0 &&
+                (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)shift3 % 16 == 0 && (uintptr_t)colsum % 16 == 0,
+                "ldn_bottleneck_tail: pointers must be 16-byte aligned");
+    LDN_REQUIRE((long)9 * (width / 2) * (width / 2) * 16 < (1L << 31), "ldn_bottleneck_tail: weights too large");
+    TailArgs a{};
+    a.h1 = static_cast<const unsigned char*>(h1_split);
+    a.h1_row_bytes = (long)ldh * 4;
+    a.B = B; a.Hi = H; a.Wi = Wd; a.Ho = H; a.Wo = Wd; a.W = width; a.cout = cout;
+    a.w2p = static_cast<const unsigned char*>(w2_pairs);
+    a.w3p = static_cast<const unsigned char*>(w3_pairs);
+    a.k_idx = ch_idx; a.k_cnt = ch_cnt;
+    a.sc2 = scale2; a.sh2 = shift2_tab; a.ps2 = post_sub2; a.sh3 = shift3;
+    a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo; a.colsum = colsum;
+    a.rows_per_blk = tail_rows_per_block(H, Wd, &a.mblocks);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (width == 64) return launch_tail<2>(a, st);
+    if (width == 128) return launch_tail<4>(a, st);
+    return launch_tail<8>(a, st);
+}

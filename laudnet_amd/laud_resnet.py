@@ -428,6 +428,27 @@ class Bottleneck(_PrepCache):
         self.last_channel_cnt = cnt
         return ops.from_nhwc(out), mask
 
+    use_fused_tail = True    # class-level switch (A/B measurements): False keeps the three-launch gathered execution
+
+    def _tail_eligible(self, Hi, Wi, Ho, Wo, cout):
+        """The fused conv2 -> conv3 launch (ldn_bottleneck_tail) covers: bf16x3 arithmetic, stride 1, an even channel
+        granularity, widths 64 / 128 / 256, maps at most 256 wide.  Everything else keeps the three-launch execution."""
+        return (self.use_fused_tail and self.channel_exec in ("auto", "fused") and ops.get_math_mode() == "bf16x3"
+                and self.stride == 1 and (Hi, Wi) == (Ho, Wo) and self.channel_dyn_granularity % 2 == 0
+                and self.width in (64, 128, 256) and Wo <= 256 and cout % 64 == 0
+                and (min(Ho, 256 // Wo) + 2) * Wo <= 576)
+
+    def tail_weights(self, p):
+        """conv2 / conv3 weights in the pre-split pair-interleaved layouts of ldn_bottleneck_tail (built once, cached with the
+        other folded parameters)."""
+        if "w2p" not in p:
+            with torch.no_grad():
+                dev = p["s3"].device
+                p["w2p"] = ops.pack_w2_pairs(self.conv2.weight.detach().float().to(dev))
+                w3 = self.conv3.weight.detach().float().reshape(-1, self.width).to(dev) * p["s3"].view(-1, 1)
+                p["w3p"] = ops.pack_w3_pairs(w3)
+        return p["w2p"], p["w3p"]
+
     def _shortcut(self, xn, p, identity):
         """Projection shortcut (laud_resnet.py:138-141).  Maps of fewer than 96 pixels run as ONE list of strided pixel rows that
         spans the batch (M tiles then hold rows of several images) instead of per-image tiles that would be mostly empty."""
@@ -473,6 +494,21 @@ class Bottleneck(_PrepCache):
             identity = xn
             out = xn if self._inplace else torch.empty_like(xn)
         h1 = torch.empty(B, Hi, Wi, W, device=dev, dtype=torch.float32)
+        if self._tail_eligible(Hi, Wi, Ho, Wo, cout):
+            # bf16x3 arithmetic, stride 1, even granularity: conv1 writes h1 pre-split, then ONE launch runs conv2 -> conv3
+            # (h2 never exists in memory, every K slice of h1 is staged once for all nine taps)
+            ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1, out_split=True)
+            w2p, w3p = self.tail_weights(p)
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+            gap_out = (torch.empty(B, ops.bottleneck_tail_splits(Ho, Wo), cout, device=dev, dtype=torch.float32)
+                       if want_gap else None)
+            ops.bottleneck_tail(h1, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], out, residual=identity,
+                                colsum=gap_out)
+            self.last_channel_mask = mask
+            self.last_gap = gap_out
+            self.last_channel_cnt = cnt
+            return ops.from_nhwc(out), mask
         ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1)
         h2 = torch.empty(B, Ho, Wo, W, device=dev, dtype=torch.float32)
         ops.conv_image(h1, p["w2"], p["s2"], p["t2_tab"], h2, ksize=3, stride=self.stride, k_idx=idx, k_cnt=cnt,

@@ -212,7 +212,7 @@ def channel_masker(x_nhwc, w1, b1, w2, b2, groups, gran, mask_in=None, want_logi
 
 # ---------------------------------------------------------------------------------------- a7 image
 def conv_image(a_nhwc, w, scale, shift, out_nhwc, *, ksize=1, stride=1, k_idx=None, k_cnt=None, kgran=1, n_idx=None,
-               n_cnt=None, post_sub=None, relu=1, residual=None, colsum=None, math=None):
+               n_cnt=None, post_sub=None, relu=1, residual=None, colsum=None, math=None, out_split=False):
     """Per-image channel-subset convolution (see ldn_conv_image).
     a_nhwc [B,Hi,Wi,lda]; w [cout,ksize*ksize,cin] without k_idx, [ksize*ksize,cin,cout] (k-major) with k_idx;
     shift [cout] or [16,cout]; out_nhwc [B,Ho,Wo,ldo]."""
@@ -232,7 +232,8 @@ def conv_image(a_nhwc, w, scale, shift, out_nhwc, *, ksize=1, stride=1, k_idx=No
                                L.ptr(_i32c(n_idx, "n_idx")), L.ptr(_i32c(n_cnt, "n_cnt")),
                                L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), classes, L.ptr(post_sub),
                                relu, L.ptr(residual), residual.shape[-1] if residual is not None else 0,
-                               L.ptr(_f32c(out_nhwc, "out")), ldo, L.ptr(colsum), _mm(math), L.stream_ptr(out_nhwc)),
+                               L.ptr(_f32c(out_nhwc, "out")), ldo, L.ptr(colsum), 1 if out_split else 0, _mm(math),
+                               L.stream_ptr(out_nhwc)),
             "ldn_conv_image")
     return out_nhwc
 
@@ -291,3 +292,52 @@ def se_packed(a2d, row_prefix, w1, b1, w2, b2, max_rows_per_image):
                               L.ptr(_f32c(w1, "w1")), L.ptr(_f32c(b1, "b1")), L.ptr(_f32c(w2, "w2")), L.ptr(_f32c(b2, "b2")),
                               max_rows_per_image, L.ptr(work), L.stream_ptr()), "ldn_se_packed")
     return a2d
+
+
+# ---------------------------------------------------------------------------------------- a7 fused tail (channel mode, bf16x3)
+def _hi_lo(w):
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def pack_w2_pairs(conv2_weight):
+    """conv2.weight [W(out n), W(in k), 3, 3] fp32 -> the pair-interleaved, pre-split layout of ldn_bottleneck_tail:
+    [9][W/2 kp][W/2 np][2 n][hi k0, hi k1, lo k0, lo k1] bf16 (one-time module preparation, include/ldn_hip.h)."""
+    W = conv2_weight.shape[0]
+    w = conv2_weight.detach().float().permute(2, 3, 1, 0).reshape(9, W // 2, 2, W // 2, 2)   # [tap][kp][kk][np][nn]
+    w = w.permute(0, 1, 3, 4, 2).contiguous()                                                 # [tap][kp][np][nn][kk]
+    hi, lo = _hi_lo(w)
+    return torch.stack((hi, lo), dim=-2).contiguous()                                         # [...][nn][hi/lo][kk]
+
+
+def pack_w3_pairs(w3_scaled):
+    """bn3.scale * conv3.weight as [cout, W] fp32 -> [W/2 kp][cout][hi k0, hi k1, lo k0, lo k1] bf16."""
+    cout, W = w3_scaled.shape
+    w = w3_scaled.detach().float().t().reshape(W // 2, 2, cout).permute(0, 2, 1).contiguous()   # [kp][c][kk]
+    hi, lo = _hi_lo(w)
+    return torch.stack((hi, lo), dim=-2).contiguous()
+
+
+def bottleneck_tail_splits(H, W):
+    return L.load().ldn_bottleneck_tail_splits(H, W)
+
+
+def bottleneck_tail(h1_split, w2_pairs, w3_pairs, ch_idx, ch_cnt, scale2, shift2_tab, post_sub2, shift3, out_nhwc, *,
+                    residual=None, colsum=None):
+    """Fused conv2 -> conv3 tail of a channel-mode bottleneck (see ldn_bottleneck_tail).  h1_split [B,H,Wd,ldh] as written by
+    conv_image(..., out_split=True); out_nhwc [B,H,Wd,cout]."""
+    L.require_device(h1_split, w2_pairs, w3_pairs, out_nhwc)
+    lib = L.load()
+    B, H, Wd, ldh = h1_split.shape
+    width = ch_idx.shape[1]
+    cout = out_nhwc.shape[-1]
+    if w2_pairs.dtype != torch.bfloat16 or w3_pairs.dtype != torch.bfloat16 or not (w2_pairs.is_contiguous() and w3_pairs.is_contiguous()):
+        raise L.LdnError("bottleneck_tail: w2_pairs / w3_pairs must be the contiguous bf16 tensors of pack_w2_pairs / pack_w3_pairs")
+    L.check(lib.ldn_bottleneck_tail(L.ptr(_f32c(h1_split, "h1")), ldh, B, H, Wd, width, L.ptr(w2_pairs), L.ptr(w3_pairs), cout,
+                                    L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")), L.ptr(_f32c(scale2, "scale2")),
+                                    L.ptr(_f32c(shift2_tab, "shift2_tab")), L.ptr(_f32c(post_sub2, "post_sub2")),
+                                    L.ptr(_f32c(shift3, "shift3")), L.ptr(residual),
+                                    residual.shape[-1] if residual is not None else 0, L.ptr(_f32c(out_nhwc, "out")), cout,
+                                    L.ptr(colsum), L.stream_ptr(out_nhwc)), "ldn_bottleneck_tail")
+    return out_nhwc

@@ -1,0 +1,83 @@
+"""GPU parity of the fused bottleneck tail (ldn_bottleneck_tail: conv2 3x3 -> bn2/ReLU -> conv3 1x1 -> bn3 + residual + ReLU
+in one launch, bf16x3 arithmetic) and of conv1's pre-split output format, against the dense-emulation algebra of the
+reference (laud_resnet.py:115-144, channel mask applied before BN).  Tolerance 2e-4 + 1e-4 relative on O(1) activations
+(north star: 1e-3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fill import seeded_bernoulli, seeded_randn
+from oracle import torch_ref as TR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from laudnet_amd import ops as _ops, load_library
+    load_library()
+    return _ops
+
+
+def _decode_split(h1s):
+    """[B,H,W,ld] fp32-typed storage of [octet][8 hi | 8 lo] bf16 -> fp32 values hi + lo, [B,H,W,ld]."""
+    B, H, W, ld = h1s.shape
+    raw = h1s.contiguous().view(torch.bfloat16).reshape(B, H, W, ld // 8, 2, 8).float()
+    return (raw[..., 0, :] + raw[..., 1, :]).reshape(B, H, W, ld)
+
+
+@pytest.mark.parametrize("B,H,cin,W,gran,down", [(4, 14, 1024, 256, 2, False), (3, 28, 512, 128, 2, False), (2, 56, 256, 64, 2, False),
+                                                 (3, 56, 64, 64, 2, True), (3, 14, 64, 256, 4, False), (2, 9, 32, 64, 2, False),
+                                                 (9, 14, 128, 256, 2, False)])
+def test_tail_vs_reference_algebra(ops, B, H, cin, W, gran, down):
+    G = W // gran
+    gm = seeded_bernoulli((B, G), 0.62, 31 + H)
+    gm[0] = 0.0          # an image with no active channel
+    gm[1] = 1.0          # an image with all channels
+    cout = 4 * W
+    blk = TR.BottleneckRef(cin, W, stride=1, downsample=None, dyn_mode="channel", channel_dyn_granularity=gran,
+                           channel_masker="MLP", output_size=H).eval()
+    TR.randomize_bn_(blk, 5)
+    with torch.no_grad():
+        for m in (blk.conv1, blk.conv2, blk.conv3):
+            m.weight.normal_(0, (2.0 / (m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3])) ** 0.5)
+    x = F.relu(seeded_randn((B, cin, H, H), 32))
+    ident = F.relu(seeded_randn((B, cout, H, H), 33))    # the residual (x itself when cin == cout, else a projection's output)
+    cm = TR.broadcast_channel_mask(gm, W)
+    with torch.no_grad():
+        h1 = F.relu(blk.bn1(blk.conv1(x) * cm))
+        h2 = F.relu(blk.bn2(blk.conv2(h1) * cm))
+        want = F.relu(blk.bn3(blk.conv3(h2)) + ident).permute(0, 2, 3, 1)
+    from laudnet_amd.laud_resnet import Bottleneck
+    hb = Bottleneck(cin, W, stride=1, downsample=None, dyn_mode="channel", channel_dyn_granularity=gran,
+                    channel_masker="MLP", output_size=H).eval()
+    hb.load_state_dict(blk.state_dict())
+    hb = hb.to(DEV)
+    p = hb._prepare(torch.device(DEV))
+    _, idx, cnt, _ = ops.channel_masker(None, None, None, None, None, G, gran, mask_in=gm.to(DEV))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    h1s = torch.full((B, H, H, W), float("nan"), device=DEV)
+    ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1s, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1, math="bf16x3", out_split=True)
+    dec = _decode_split(h1s).cpu()
+    c1 = p["c1"].cpu()
+    for b in range(B):
+        n = int(cnt[b])
+        ch = idx[b, :n].cpu().long()
+        want1 = h1[b, ch].permute(1, 2, 0) - c1[ch]
+        assert torch.allclose(dec[b, :, :, :n], want1, atol=1e-4, rtol=1e-4), f"conv1 split output, image {b}"
+        pad = (n + 31) // 32 * 32
+        assert bool((dec[b, :, :, n:pad] == 0).all()), "columns up to the next multiple of 32 must be zero"
+    w2p, w3p = hb.tail_weights(p)
+    idn = ident.permute(0, 2, 3, 1).contiguous().to(DEV)
+    splits = ops.bottleneck_tail_splits(H, H)
+    colsum = torch.full((B, splits, cout), float("nan"), device=DEV)
+    out = torch.full((B, H, H, cout), float("nan"), device=DEV)
+    ops.bottleneck_tail(h1s, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], out, residual=idn, colsum=colsum)
+    torch.cuda.synchronize()
+    err = (out.cpu() - want).abs()
+    assert torch.allclose(out.cpu(), want, atol=2e-4, rtol=1e-4), f"max err {err.max().item():.3e} at {tuple(torch.nonzero(err == err.max())[0].tolist())}"
+    assert torch.allclose(colsum.sum(dim=1).cpu().double(), out.cpu().double().sum(dim=(1, 2)), atol=1e-2, rtol=1e-5)
+    # in-place residual stream (out aliases residual): same result
+    ops.bottleneck_tail(h1s, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], idn, residual=idn)
+    assert torch.equal(idn, out)

@@ -43,6 +43,15 @@ struct TailArgs {
 
 __device__ __attribute__((aligned(16))) float g_tail_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifdef LDN_TRACE   // tuning only: per-workgroup phase timestamps of every wave (tools/trace_tail.py)
+__device__ unsigned long long* g_tail_trace = nullptr;
+#define TT(x) x = __builtin_amdgcn_s_memtime();
+#define TT_ADD(acc, a, b) acc += (b) - (a);
+#else
+#define TT(x)
+#define TT_ADD(acc, a, b)
+#endif
+
 // LDS-DMA of 16 bytes per lane: LDS destination = lds_base (wave-uniform byte address) + lane * 16, source per lane.
 // Inline asm: the compiler neither counts it nor waits for it (cdna_hip_programming.md 5.7) -- every wait is explicit below.
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
@@ -97,6 +106,10 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
+#ifdef LDN_TRACE
+    unsigned long long tr0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, ta = 0, tb = 0, w2wait = 0, w3wait = 0, w3bar = 0, w3epi = 0, w3k = 0;
+    TT(tr0)
+#endif
     const int b = blockIdx.x % p.B, mb = blockIdx.x / p.B;     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
 
     // ---- geometry of this workgroup's block of output rows and of its halo'd input region (stride 1, pad 1)
@@ -203,14 +216,18 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
     }
     // fragment addressing
     const unsigned a_lane = (unsigned)(4 * h * W2_ROW + l31 * 8);          // A (weights): k-pair rows 4h .. 4h+3 of a K16 step
+    TT(tr1)
     for (int s = 0; s < nsub; ++s) {
         const unsigned char* hs = s_h1 + (s & 1) * p.slice_bytes;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {                           // chunk c = 9 s + t lives in W2 slot c % 3 == t % 3
             const int c = 9 * s + t;
+            TT(ta)
             wait_chunk();
             lds_barrier();     // chunk c (and, when t == 0, slice s) is in LDS for every wave; every wave has left chunk c - 1
             // issue: next slice's share first, then the W2 tile of chunk c + 2 (issue order matters for the counted wait)
+            TT(tb)
+            TT_ADD(w2wait, ta, tb)
             if (s + 1 < nsub) { const int q = t * 8 + wave; if (q < nq) dma_h1(s + 1, q); }
             if (c + 2 < nchunks) dma_w2(c + 2);
             else { for (int e = 0; e < n_w2; ++e) dma16(g_tail_zero, lds_w2 + ((t + 2) % T_W2_SLOTS) * W2_SLOT + (2 * wave) * W2_ROW); }   // keeps the count
@@ -259,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
     }
     wait_vm<0>();
     lds_barrier();         // every wave is out of the conv2 loop: the slice / W2 regions are free
+    TT(tr2)
 
     // ======================================================================================================== conv3 (1x1)
     // Output channels are walked in chunks of CW (64; 32 for the widest layer, whose h2 operand alone takes 128 registers and
@@ -331,6 +349,7 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
         return __builtin_bit_cast(bf16x8, x);
     };
 
+    TT(tr3)
     const int trw = lane >> 3, tc = lane & 7;                  // epilogue layout: lane = (row trw + 8 it, 4 channels at 4 tc)
     const unsigned a3_lane = (unsigned)(2 * h * W3_ROW + l31 * 8);
     float* const scr = reinterpret_cast<float*>(s_scr + wave * 4096);   // this wave's 32 x 32 transpose scratch
@@ -349,7 +368,9 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
                 const float* src = (p.residual && prow < npix) ? p.residual + (size_t)(out_row0 + prow) * p.ldr + c0 + tc * 4 : g_tail_zero;
                 res[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
             }
+            f32x4 sh = *reinterpret_cast<const f32x4*>(p.sh3 + c0 + tc * 4);   // bn3 shift: requested with the residual
             f32x16 acc3;
+            TT(ta)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
 #pragma unroll
@@ -376,8 +397,16 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                 }
             }
+            TT(tb)
+            TT_ADD(w3k, ta, tb)
             if (cs == NCS - 1) wait_vm<0>();   // this wave's share of W3(cc + 1) has landed (its earlier stores and the residual too);
                                                // placed BEFORE this sub-pass's stores, which then fly through the next chunk
+            // gfx9 counts loads and stores in ONE vmcnt and lets them complete out of order with each other: a residual register first
+            // touched after a store has been issued makes hipcc wait vmcnt(0), i.e. for that store's acknowledgement -- four
+            // serialised store latencies per tile.  Touch all of them here, before the first store.
+            asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sh));
+            TT(ta)
+            TT_ADD(w3wait, tb, ta)
             // C layout (lane = pixel l31, register r = channel (r & 3) + 8 (r >> 2) + 4 h) -> rows of 32 channels per pixel,
             // 16-byte slots XOR-swizzled with the pixel so that both the writes and the row reads are conflict-free
 #pragma unroll
@@ -387,7 +416,6 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.sh3 + c0 + tc * 4);
             f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -415,9 +443,22 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            TT(tb)
+            TT_ADD(w3epi, ta, tb)
         }
+        TT(ta)
         lds_barrier();     // every wave has left slot cc & 1 (refilled by the DMA of chunk cc + 2 in the next iteration)
+        TT(tb)
+        TT_ADD(w3bar, ta, tb)
     }
+#ifdef LDN_TRACE
+    TT(tr4)
+    if (g_tail_trace && lane == 0) {
+        unsigned long long* r = g_tail_trace + ((size_t)blockIdx.x * 8 + wave) * 12;
+        r[0] = tr0; r[1] = tr1; r[2] = tr2; r[3] = tr3; r[4] = tr4; r[5] = w2wait; r[6] = w3k; r[7] = w3wait; r[8] = w3epi; r[9] = w3bar;
+        r[10] = nsub; r[11] = 0;
+    }
+#endif
 }
 
 static int tail_rows_per_block(int Ho, int Wo, int* mblocks) {
@@ -449,6 +490,13 @@ static int launch_tail(TailArgs& a, hipStream_t st) {
 }  // namespace ldn
 
 using namespace ldn;
+
+#ifdef LDN_TRACE
+extern "C" int ldn_debug_set_tail_trace(void* buf) {
+    unsigned long long* q = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tail_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int ldn_bottleneck_tail_splits(int Ho, int Wo) {
     int mbk = 0;

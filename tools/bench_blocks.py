@@ -24,7 +24,7 @@ with torch.no_grad():
         G = blk.masker_channel.channel_dyn_group
         blk.forced_channel_mask = (torch.rand(B, G, generator=g) < 0.62).float().to(dev)
         blk.inplace_residual = False
-        for mode in ("gather", "dense"):
+        for mode in ("auto", "gather", "dense"):
             blk.channel_exec = mode
             for _ in range(3): blk.run_dynamic(x)
             torch.cuda.synchronize()

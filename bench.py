@@ -145,12 +145,13 @@ class KernelTimer:
     def __init__(self):
         self.records = []
         self.rows = []
+        self.tails = []
         self.step = 0          # index of the timed step in flight (set by the timed loop)
         self.steps_of = {}     # kind -> set of steps in which its launches were bracketed
 
     # Two event records per launch cost ~4 us of stream time each (0.48 ms of a 19.7 ms step when every conv2 and conv3
     # launch is bracketed): each kind is bracketed in every OTHER timed step, which still samples the whole timed region.
-    PHASE = {"conv2_3x3": 0, "conv3_1x1": 1, "rows_3x3": 0}
+    PHASE = {"conv2_3x3": 0, "conv3_1x1": 1, "rows_3x3": 0, "tail_fused": 1}
 
     def sampled(self, kind):
         if (self.step + self.PHASE[kind]) % 2:
@@ -173,6 +174,19 @@ class KernelTimer:
             e1.record()
             self.records.append((kind, e0, e1, kw.get("k_cnt"), kw.get("n_cnt"), tuple(a[4].shape), tuple(a[1].shape),
                                  kw.get("residual") is not None))
+            return out
+        return timed
+
+    def wrap_tail(self, fn):
+        """ops.bottleneck_tail: the fused conv2 -> conv3 launch of a channel-mode block (k_tail)."""
+        def timed(*a, **kw):
+            if not self.sampled("tail_fused"):
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.tails.append((e0, e1, a[4], tuple(a[0].shape), tuple(a[9].shape), kw.get("residual") is not None))
             return out
         return timed
 
@@ -203,6 +217,16 @@ class KernelTimer:
             nbytes = 4.0 * (Ho * Wo * float(kb.sum()) + taps * cin * cout + Ho * Wo * float(nb.sum()) * (2 if has_res else 1))
             n, ms, f, by = agg.get(kind, (0, 0.0, 0.0, 0.0))
             agg[kind] = (n + 1, ms + e0.elapsed_time(e1), f + flops, by + nbytes)
+        for e0, e1, kc, hshape, oshape, has_res in self.tails:
+            # algorithmic work of the fused tail per launch: conv2 on the active subsets + conv3; bytes = h1 read once (left-packed,
+            # 4 B per element), residual read + output written once, both weight tensors once
+            B, H, Wd, width = hshape
+            cout = oshape[-1]
+            kb = kc.double().cpu()
+            flops = float((2.0 * H * Wd * (9.0 * kb * kb + kb * cout)).sum())
+            nbytes = 4.0 * (H * Wd * float(kb.sum()) + 9 * width * width + width * cout + B * H * Wd * cout * (2 if has_res else 1))
+            n, ms, f, by = agg.get("tail_fused", (0, 0.0, 0.0, 0.0))
+            agg["tail_fused"] = (n + 1, ms + e0.elapsed_time(e1), f + flops, by + nbytes)
         for e0, e1, mc, cap, wshape in self.rows:          # w [cout][9][cin]; rows = active output pixels of the batch
             cout, taps, cin = wshape
             m = float(mc.item()) if mc is not None else float(cap)
@@ -296,9 +320,11 @@ def main():
     timer = KernelTimer()
     orig_conv_image = ops.conv_image
     orig_conv_rows = ops.conv_rows
+    orig_tail = ops.bottleneck_tail
     if not os.environ.get("LDN_BENCH_NO_EVENTS"):   # tuning only: what the per-launch HIP events cost
         ops.conv_image = timer.wrap(orig_conv_image)
         ops.conv_rows = timer.wrap_rows(orig_conv_rows)
+        ops.bottleneck_tail = timer.wrap_tail(orig_tail)
 
     if world > 1:
         torch.distributed.barrier()
@@ -320,6 +346,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.conv_image = orig_conv_image
     ops.conv_rows = orig_conv_rows
+    ops.bottleneck_tail = orig_tail
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -348,7 +375,7 @@ def main():
     agg = timer.summary()
     if agg:
         # per-launch HBM traffic of the stage-3 instance of each kernel from the committed PMC passes (profiles/)
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
         traffic = json.load(open(tj)) if (args.workload == "channel" and args.batch == 256 and os.path.exists(tj)) else {}
         mode = args.math
 
@@ -374,7 +401,20 @@ def main():
                     "traffic_scope": "stage-3 launch (443 MB algorithmic)", "launches": n, "avg_launch_us": 1e3 * ms / n,
                     "algorithmic_mbytes_per_launch": nbytes / n / 1e6, "algorithmic_tflops": flops / (ms * 1e-3) / 1e12}
 
-        objs = {k: (hbm_roofline if k == "conv3_1x1" else mfma_roofline)(*v) for k, v in agg.items()}
+        def tail_roofline(n, ms, flops, nbytes):
+            # the fused tail is bounded by HBM (h1 + residual in, output out: 442 MB per stage-3 launch = 55 us at 8 TB/s) slightly
+            # before the matrix pipe (3 bf16 MFMA products per algorithmic product: 118 GFLOP executed = 47 us at 2.5 PFLOP/s)
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            tf = flops / (ms * 1e-3) / 1e12
+            return {"kernel": "k_tail (fused conv2 3x3 -> bn2/ReLU -> conv3 1x1 -> bn3 + residual + ReLU of a channel-mode block, bf16x3)",
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic.get("tail_fused_bf16x3", {}).get("traffic_bytes_per_launch"),
+                    "traffic_scope": traffic.get("tail_fused_bf16x3", {}).get("scope"),
+                    "launches": n, "avg_launch_us": 1e3 * ms / n, "algorithmic_mbytes_per_launch": nbytes / n / 1e6,
+                    "algorithmic_tflops": tf, "executed_mfma_tflops": 3 * tf, "frac_of_bf16_mfma_peak_executed": 3 * tf / BF16_MFMA_PEAK_TFLOPS}
+
+        pick = {"conv3_1x1": hbm_roofline, "tail_fused": tail_roofline}
+        objs = {k: pick.get(k, mfma_roofline)(*v) for k, v in agg.items()}
         if "rows_3x3" in objs:
             objs["rows_3x3"]["kernel"] = objs["rows_3x3"]["kernel"].replace("3x3 per-image channel-subset conv", "3x3 conv over packed active rows, shared weights")
             objs["rows_3x3"]["traffic_scope"] = objs["rows_3x3"]["traffic"] = None

@@ -193,11 +193,20 @@ int ldn_conv_packed(const float* a, int lda, int B, const int32_t* row_prefix, c
 int ldn_grouped_conv3x3_rows(const float* a, int lda, const int32_t* nbr, const int32_t* m_count, int m_cap,
                              const float* w, int C, int group_width, const float* scale, const float* shift, int relu,
                              float* out, int ldo, void* stream);
+/* b in CHANNEL mode (laud_regnet.py:160-189: the mask is applied AFTER conv+BN+ReLU, so masked channels are exact zeros and the
+ *    subset execution is exact): dense image whose columns are left-packed per image (column j of image b = channel
+ *    ch_idx[b,j], ascending, j < ch_cnt[b]); output column j sums over the ACTIVE input channels of its group only.
+ *    a [B,Hi,Wi,lda], out [B,Ho,Wo,ldo] (columns >= ch_cnt[b] written as zeros), w [C][9][gw], pad 1. */
+int ldn_grouped_conv3x3_image(const float* a, int lda, int B, int Hi, int Wi, int stride, int Ho, int Wo, const float* w,
+                              int C, int group_width, const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale,
+                              const float* shift, int relu, float* out, int ldo, void* stream);
 /* se: torchvision SqueezeExcitation (laud_regnet.py:119-123,194) applied IN PLACE to the packed rows of every kept
  *    image: gate[b,:] = sigmoid(W2 relu(W1 mean_rows(a_b) + b1) + b2), a[r,:] *= gate[image(r),:].
- *    w1 [S][C], w2 [C][S].  work: B*(ldn_channel_masker_splits(max_rows_per_image)+1)*C floats. */
+ *    w1 [S][C], w2 [C][S].  ch_idx / ch_cnt (optional, [B][C] / [B]): the columns of image b are its active channels
+ *    (channel mode); the weights are gathered through the list.  work: ldn_se_packed_workspace_bytes. */
 int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B, int C, int S, const float* w1, const float* b1,
-                  const float* w2, const float* b2, int max_rows_per_image, float* work, void* stream);
+                  const float* w2, const float* b2, const int32_t* ch_idx, const int32_t* ch_cnt, int max_rows_per_image,
+                  float* work, void* stream);
 size_t ldn_se_packed_workspace_bytes(int B, int C, int max_rows_per_image);
 
 #ifdef __cplusplus

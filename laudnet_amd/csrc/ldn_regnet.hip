@@ -110,35 +110,96 @@ __global__ __launch_bounds__(256) void k_rows_gap(const float* __restrict__ a, i
 }
 
 // squeeze-excitation head per image: mean -> fc1 + ReLU -> fc2 -> sigmoid  (torchvision SqueezeExcitation)
+// With a channel list (channel mode: column j of image b is channel ch_idx[b, j], j < ch_cnt[b]) the weights are gathered
+// through it; masked channels are exact zeros in the reference (post-activation mask) and contribute nothing to fc1.
 __global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ partial, const int32_t* __restrict__ prefix,
                                                   int C, int S, int splits, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
-                                                  const float* __restrict__ b2, float* __restrict__ gate) {
+                                                  const float* __restrict__ b2, const int32_t* __restrict__ ch_idx,
+                                                  const int32_t* __restrict__ ch_cnt, float* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) float s_f[];
     float* s_mean = s_f;        // [C]
     float* s_hid = s_f + C;     // [S]
+    int* s_ch = reinterpret_cast<int*>(s_f + C + S);   // [C] channel of column j
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = prefix[b + 1] - prefix[b];
     if (n == 0) return;         // skipped image: its gate is never read
+    const int Cb = ch_idx ? ch_cnt[b] : C;
     const float inv = 1.f / (float)n;
     for (int c = tid; c < C; c += 256) {
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
+        if (c < Cb)
+            for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
         s_mean[c] = s * inv;
+        s_ch[c] = c < Cb ? (ch_idx ? ch_idx[(size_t)b * C + c] : c) : 0;
     }
     __syncthreads();
     for (int o = wave; o < S; o += 4) {
         float acc = 0.f;
-        for (int c = lane; c < C; c += 64) acc += w1[(size_t)o * C + c] * s_mean[c];
+        for (int c = lane; c < Cb; c += 64) acc += w1[(size_t)o * C + s_ch[c]] * s_mean[c];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if (lane == 0) s_hid[o] = fmaxf(acc + b1[o], 0.f);
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
-        float acc = b2[c];
-        for (int j = 0; j < S; ++j) acc += w2[(size_t)c * S + j] * s_hid[j];
-        gate[(size_t)b * C + c] = 1.f / (1.f + __expf(-acc));
+        float g = 0.f;
+        if (c < Cb) {
+            const int ch = s_ch[c];
+            float acc = b2[ch];
+            for (int j = 0; j < S; ++j) acc += w2[(size_t)ch * S + j] * s_hid[j];
+            g = 1.f / (1.f + __expf(-acc));
+        }
+        gate[(size_t)b * C + c] = g;
+    }
+}
+
+// ---- channel mode (laud_regnet.py:160-189): grouped 3x3 conv + BN + ReLU over a dense image whose channels are LEFT-PACKED per
+// image (column j of image b = channel ch_idx[b, j], ascending, j < ch_cnt[b]).  Output column j (channel c, group g = c / gw)
+// sums over the ACTIVE input channels of its group only -- they occupy a contiguous run of packed columns -- so skipped
+// channels cost nothing: out[b,p,j] = act(scale[c] * sum_t sum_{q in run(g)} a[b, pix(p,t), q] * w[c, t, ch(q) - g*gw] + shift[c]).
+// Columns j >= ch_cnt[b] are written as zeros.  One workgroup = one image x a run of output pixels; thread = (pixel, column).
+__global__ __launch_bounds__(256) void k_grouped3x3_chan(const float* __restrict__ a, int lda, int Hi, int Wi, int stride,
+                                                          int Ho, int Wo, const float* __restrict__ w, int C, int gw,
+                                                          const int32_t* __restrict__ ch_idx, const int32_t* __restrict__ ch_cnt,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          int relu, float* __restrict__ out, int ldo) {
+    extern __shared__ int s_i[];
+    int* s_ch = s_i;                 // [C] channel of packed column j
+    int* s_lo = s_i + C;             // [C / gw] first packed column of group g
+    int* s_hi = s_lo + C / gw;       // [C / gw] one past its last packed column
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int Cb = min(ch_cnt[b], C), G = C / gw;
+    for (int g = tid; g < G; g += 256) { s_lo[g] = 0; s_hi[g] = 0; }
+    for (int j = tid; j < Cb; j += 256) s_ch[j] = ch_idx[(size_t)b * C + j];
+    __syncthreads();
+    for (int j = tid; j < Cb; j += 256) {
+        const int g = s_ch[j] / gw;
+        if (j == 0 || s_ch[j - 1] / gw != g) s_lo[g] = j;
+        if (j == Cb - 1 || s_ch[j + 1] / gw != g) s_hi[g] = j + 1;
+    }
+    __syncthreads();
+    const int HWo = Ho * Wo;
+    const long total = (long)HWo * C;
+    for (long i = (long)blockIdx.x * 256 + tid; i < total; i += (long)gridDim.x * 256) {
+        const int p = (int)(i / C), j = (int)(i - (long)p * C);
+        float v = 0.f;
+        if (j < Cb) {
+            const int c = s_ch[j], g = c / gw, g0 = g * gw, lo = s_lo[g], hi = s_hi[g];
+            const int oy = p / Wo, ox = p - oy * Wo;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy * stride + t / 3 - 1, ix = ox * stride + t % 3 - 1;
+                if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+                const float* ap = a + ((size_t)(b * Hi + iy) * Wi + ix) * lda;
+                const float* wp = w + ((size_t)c * 9 + t) * gw - g0;
+                for (int q = lo; q < hi; ++q) acc += ap[q] * wp[s_ch[q]];
+            }
+            v = acc * scale[c] + shift[c];
+            if (relu) v = fmaxf(v, 0.f);
+        }
+        out[((size_t)b * HWo + p) * ldo + j] = v;
     }
 }
 
@@ -199,9 +260,27 @@ extern "C" size_t ldn_se_packed_workspace_bytes(int B, int C, int max_rows_per_i
     return (size_t)B * (ldn_channel_masker_splits(max_rows_per_image) + 1) * C * sizeof(float);
 }
 
+extern "C" int ldn_grouped_conv3x3_image(const float* a, int lda, int B, int Hi, int Wi, int stride, int Ho, int Wo,
+                                         const float* w, int C, int group_width, const int32_t* ch_idx, const int32_t* ch_cnt,
+                                         const float* scale, const float* shift, int relu, float* out, int ldo, void* stream) {
+    LDN_REQUIRE(a && w && ch_idx && ch_cnt && scale && shift && out, "ldn_grouped_conv3x3_image: null pointer");
+    LDN_REQUIRE(C > 0 && group_width > 0 && C % group_width == 0, "ldn_grouped_conv3x3_image: channels must be a multiple of the group width");
+    LDN_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && (Ho - 1) * stride < Hi && (Wo - 1) * stride < Wi,
+                "ldn_grouped_conv3x3_image: bad geometry");
+    LDN_REQUIRE(lda >= 1 && ldo >= C, "ldn_grouped_conv3x3_image: bad strides");
+    long bx = ((long)Ho * Wo * C + 255) / 256;
+    if (bx > 64) bx = 64;
+    const size_t lds = (size_t)(C + 2 * (C / group_width)) * sizeof(int);
+    hipLaunchKernelGGL(k_grouped3x3_chan, dim3((unsigned)bx, B), dim3(256), lds, static_cast<hipStream_t>(stream), a, lda, Hi, Wi,
+                       stride, Ho, Wo, w, C, group_width, ch_idx, ch_cnt, scale, shift, relu, out, ldo);
+    LDN_CHECK_LAUNCH("k_grouped3x3_chan");
+    return LDN_OK;
+}
+
 extern "C" int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B, int C, int S, const float* w1,
-                             const float* b1, const float* w2, const float* b2, int max_rows_per_image, float* work,
-                             void* stream) {
+                             const float* b1, const float* w2, const float* b2, const int32_t* ch_idx, const int32_t* ch_cnt,
+                             int max_rows_per_image, float* work, void* stream) {
+    LDN_REQUIRE((ch_idx == nullptr) == (ch_cnt == nullptr), "ldn_se_packed: channel list and count must be given together");
     LDN_REQUIRE(a && row_prefix && w1 && b1 && w2 && b2 && work, "ldn_se_packed: null pointer");
     LDN_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && S > 0 && lda % 4 == 0, "ldn_se_packed: bad shape");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -210,8 +289,8 @@ extern "C" int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B
     float* gate = work + (size_t)B * splits * C;     // [B][C]
     hipLaunchKernelGGL(k_rows_gap, dim3(splits, B), dim3(256), 0, st, a, lda, row_prefix, C, splits, partial);
     LDN_CHECK_LAUNCH("k_rows_gap");
-    hipLaunchKernelGGL(k_se_head, dim3(B), dim3(256), (size_t)(C + S) * sizeof(float), st, partial, row_prefix, C, S, splits,
-                       w1, b1, w2, b2, gate);
+    hipLaunchKernelGGL(k_se_head, dim3(B), dim3(256), (size_t)(2 * C + S) * sizeof(float), st, partial, row_prefix, C, S, splits,
+                       w1, b1, w2, b2, ch_idx, ch_cnt, gate);
     LDN_CHECK_LAUNCH("k_se_head");
     int chunks = (max_rows_per_image * (C / 4) + 255) / 256;
     if (chunks > 64) chunks = 64;

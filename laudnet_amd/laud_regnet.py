@@ -127,6 +127,7 @@ class BottleneckTransform(_PrepCache):
             p["wb"] = self.b[0].weight.detach().permute(0, 2, 3, 1).reshape(w_b, 9, gw).float().contiguous()
             p["sb"], p["tb"] = _fold_bn(self.b[1])
             p["wc"] = self.c[0].weight.detach().reshape(-1, 1, w_b).float().contiguous()
+            p["wc_k"] = self.c[0].weight.detach().reshape(-1, w_b).float().t().reshape(1, w_b, -1).contiguous()   # k-major (channel mode)
             p["sc"], p["tc"] = _fold_bn(self.c[1])
             s = self.se.fc1.out_channels
             p["se_w1"] = self.se.fc1.weight.detach().reshape(s, w_b).float().contiguous()
@@ -201,10 +202,13 @@ class ResBottleneckBlock(_PrepCache):
         _eval_only(self, x)
         inplace = bool(self.inplace_residual if inplace is None else inplace) and self.proj is None
         f = self.f
+        if f.dyn_mode == "channel":
+            return self._run_channel(x, inplace)
         if f.dyn_mode != "spatial" or f.mask_size != 1 or f.masker_spatial.mask_channel_group != 1:
-            raise LdnError("HIP path (round 1): LAD-RegNet runs layer skip only -- dyn_mode='spatial' with "
-                           "mask_spatial_granularity equal to the stage's output size (BASELINE config 4); other RegNet "
-                           "modes are covered by the oracle only")
+            raise LdnError("HIP path: LAD-RegNet runs channel mode and layer skip (dyn_mode='spatial' with "
+                           "mask_spatial_granularity equal to the stage's output size, BASELINE config 4); general spatial / "
+                           "both modes are not exactly sparsifiable (the SE squeeze pools the dense conv-b output before the "
+                           "mask is applied, SURVEY 0.9) and are covered by the oracle only")
         p = f.prepared(x.device)
         B, Cin, Hi, Wi = x.shape
         Ho = Wo = f.output_size
@@ -241,6 +245,51 @@ class ResBottleneckBlock(_PrepCache):
         f.last_spatial_mask = patch
         stats = torch.cat((ix.stats, torch.ones(1, device=dev)))
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), stats
+
+    def _run_channel(self, x, inplace):
+        """dyn_mode 'channel' (laud_regnet.py:160-170,182-189): the mask multiplies the outputs of a and b AFTER conv+BN+ReLU, so
+        masked channels are exact zeros and computing only the active subsets is exact: a = 1x1 with an output-channel list,
+        b = grouped 3x3 over the active channels of each group, SE on the kept channels, c = 1x1 with an input-channel list
+        (+ residual + ReLU fused)."""
+        f = self.f
+        p = f.prepared(x.device)
+        B, Cin, Hi, Wi = x.shape
+        s = self.stride
+        Ho, Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
+        dev = x.device
+        xn = ops.as_nhwc(x)
+        w_b = f.w_b
+        gran = w_b // f.masker_channel.channel_dyn_group
+        if w_b % 8 != 0:
+            raise LdnError("HIP path: LAD-RegNet channel mode needs a bottleneck width that is a multiple of 8")
+        mask, idx, cnt, _ = f.masker_channel.lists(x, gran, mask_in=f.forced_channel_mask)
+        h_a = torch.empty(B, Hi, Wi, w_b, device=dev, dtype=torch.float32)
+        ops.conv_image(xn, p["wa"], p["sa"], p["ta"], h_a, n_idx=idx, n_cnt=cnt, relu=1)
+        h_b = torch.empty(B, Ho, Wo, w_b, device=dev, dtype=torch.float32)
+        ops.grouped_conv3x3_image(h_a, p["wb"], f.group_width, idx, cnt, p["sb"], p["tb"], h_b, stride=s, relu=1)
+        ops.se_packed(h_b.view(B * Ho * Wo, w_b), self._img_prefix(B, Ho * Wo, dev), p["se_w1"], p["se_b1"], p["se_w2"],
+                      p["se_b2"], Ho * Wo, ch_idx=idx, ch_cnt=cnt)
+        cout = p["wc"].shape[0]
+        if self.proj is not None:
+            wp, sp, tp = self._proj(dev)
+            identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
+            ops.conv_image(xn, wp, sp, tp, identity, stride=s, relu=0)
+            out = identity
+        else:
+            identity = xn
+            out = xn if inplace else torch.empty_like(xn)
+        ops.conv_image(h_b, p["wc_k"], p["sc"], p["tc"], out, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual=identity)
+        f.last_channel_mask = mask
+        stats = torch.ones(4, device=dev)
+        stats[3] = mask.mean()
+        return ops.from_nhwc(out), stats
+
+    def _img_prefix(self, B, rows, dev):
+        key = (B, rows, str(dev))
+        cache = self.__dict__.setdefault("_prefix_cache", {})
+        if key not in cache:
+            cache[key] = (torch.arange(B + 1, device=dev, dtype=torch.int32) * rows).contiguous()
+        return cache[key]
 
     def forward(self, x, temperature):
         x, s3_list, s2_list, s1_list, cs_list, perc_list, flops = x

@@ -281,7 +281,21 @@ def grouped_conv3x3_rows(a2d, nbr, w, group_width, scale, shift, out2d, *, m_cou
     return out2d
 
 
-def se_packed(a2d, row_prefix, w1, b1, w2, b2, max_rows_per_image):
+def grouped_conv3x3_image(a_nhwc, w, group_width, ch_idx, ch_cnt, scale, shift, out_nhwc, *, stride=1, relu=1):
+    """Grouped 3x3 conv + BN (+ReLU) on left-packed per-image channel subsets (see ldn_grouped_conv3x3_image).  w [C,9,gw]."""
+    L.require_device(a_nhwc, w, out_nhwc, ch_idx)
+    lib = L.load()
+    B, Hi, Wi, lda = a_nhwc.shape
+    _, Ho, Wo, ldo = out_nhwc.shape
+    C = w.shape[0]
+    L.check(lib.ldn_grouped_conv3x3_image(L.ptr(_f32c(a_nhwc, "a")), lda, B, Hi, Wi, stride, Ho, Wo, L.ptr(_f32c(w, "w")), C,
+                                          group_width, L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")),
+                                          L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,
+                                          L.ptr(_f32c(out_nhwc, "out")), ldo, L.stream_ptr(out_nhwc)), "ldn_grouped_conv3x3_image")
+    return out_nhwc
+
+
+def se_packed(a2d, row_prefix, w1, b1, w2, b2, max_rows_per_image, ch_idx=None, ch_cnt=None):
     """In-place squeeze-excitation over the packed rows of every kept image (see ldn_se_packed)."""
     L.require_device(a2d, row_prefix)
     lib = L.load()
@@ -290,7 +304,8 @@ def se_packed(a2d, row_prefix, w1, b1, w2, b2, max_rows_per_image):
     work = _work(lib.ldn_se_packed_workspace_bytes(B, C, max_rows_per_image), a2d.device)
     L.check(lib.ldn_se_packed(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(row_prefix, "row_prefix")), B, C, S,
                               L.ptr(_f32c(w1, "w1")), L.ptr(_f32c(b1, "b1")), L.ptr(_f32c(w2, "w2")), L.ptr(_f32c(b2, "b2")),
-                              max_rows_per_image, L.ptr(work), L.stream_ptr()), "ldn_se_packed")
+                              L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")), max_rows_per_image, L.ptr(work),
+                              L.stream_ptr()), "ldn_se_packed")
     return a2d
 
 

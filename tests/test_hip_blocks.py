@@ -243,9 +243,38 @@ def test_regnet_layerskip_own_maskers(math_mode):
                        what="regnet logits")
 
 
-def test_regnet_other_modes_raise():
-    from laudnet_amd import LdnError
+def test_regnet_channel_injected(math_mode):
+    """LAD-RegNet channel mode (laud_regnet.py:160-189): per-image subsets of a / grouped b / SE / c against the fixture the
+    reference generated with the same injected group masks."""
+    from fill import seeded_bernoulli
     fx = REGNET["cases"]["channel_g2"]
+    model, x = _hip_regnet(fx)
+    for i, blk in enumerate(model.blocks()):
+        m = seeded_bernoulli((fx["batch"], blk.f.masker_channel.channel_dyn_group), 0.62, fx["mask_seed"] + 2 * i + 1)
+        blk.f.forced_channel_mask = m.to(DEV)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=logit_atol(math_mode, fx["injected_run"]), rtol=LOGIT_RTOL[math_mode],
+                       what="regnet channel logits")
+    assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what="regnet channel stats")
+    assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what="regnet channel flops")
+
+
+def test_regnet_channel_own_maskers(math_mode):
+    fx = REGNET["cases"]["channel_g2"]
+    model, x = _hip_regnet(fx)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got[1:6], fx["masker_run"][1:6], atol=1e-6, what="regnet channel stats (same masker decisions)")
+    assert_tuple_close(got[:1], fx["masker_run"][:1], atol=logit_atol(math_mode, fx["masker_run"]), rtol=LOGIT_RTOL[math_mode],
+                       what="regnet channel logits")
+
+
+def test_regnet_general_spatial_raises():
+    """General spatial masks on RegNet-Y are not exactly sparsifiable (SE pools the dense conv-b output before the mask is
+    applied): the HIP path refuses them instead of approximating."""
+    from laudnet_amd import LdnError
+    fx = REGNET["cases"]["spatial_g2"]
     model, x = _hip_regnet(fx)
     with pytest.raises(LdnError):
         model(x, 1.0)

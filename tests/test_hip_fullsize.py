@@ -38,6 +38,9 @@ CONFIGS = {
     "r50_both": dict(factory="uni_resnet50", batch=32, kw=dict(
         dyn_mode=["both"] * 4, channel_dyn_granularity=[2, 2, 2, 2], channel_masker=["MLP"] * 4,
         channel_masker_layers=[2, 2, 2, 2], mask_spatial_granularity=[4, 4, 2, 1])),
+    "regnety800_channel": dict(factory="lad_regnet_y_800mf", batch=32, kw=dict(
+        dyn_mode=["channel"] * 4, channel_dyn_granularity=[2, 2, 2, 2], channel_masker=["MLP"] * 4,
+        channel_masker_layers=[2, 2, 2, 2])),
     "regnety800_layerskip": dict(factory="lad_regnet_y_800mf", batch=64, kw=dict(
         dyn_mode=["spatial"] * 4, mask_spatial_granularity=[56, 28, 14, 7])),
 }

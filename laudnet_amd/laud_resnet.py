@@ -151,13 +151,15 @@ class ExpandMask(nn.Module):
         self.stride, self.padding, self.mask_channel_group = stride, padding, mask_channel_group
 
     def forward(self, x):
-        if x.shape[1] != 1 or self.padding not in (0, 1) or (self.padding == 0 and self.stride != 1):
-            raise LdnError("ExpandMask on the HIP path supports one mask group and (stride,1)/(1,0) dilation")
+        if self.padding not in (0, 1) or (self.padding == 0 and self.stride != 1):
+            raise LdnError("ExpandMask on the HIP path supports the (stride,1) and (1,0) dilations the blocks use")
+        b, g, h, w = x.shape
+        # utils.py:81: the dilation kernel is [g,g,k,k] ones -> every output group is the OR of all input groups
+        u = x[:, 0] if g == 1 else x.amax(dim=1)
         if self.padding == 0:
-            return x > 0.5
-        b, _, h, w = x.shape
-        ix = ops.mask_to_index(x[:, 0].float().contiguous(), h, w, self.stride)
-        return (ix.pos1 >= 0).view(b, 1, h * self.stride, w * self.stride)
+            return (u > 0.5).unsqueeze(1).expand(b, g, h, w)
+        ix = ops.mask_to_index(u.float().contiguous(), h, w, self.stride)
+        return (ix.pos1 >= 0).view(b, 1, h * self.stride, w * self.stride).expand(b, g, h * self.stride, w * self.stride)
 
 
 class Masker_channel_MLP(_PrepCache):
@@ -530,33 +532,53 @@ class Bottleneck(_PrepCache):
         if Hi != Ho * self.stride or Wi != Wo * self.stride:
             raise LdnError(f"Bottleneck: input {Hi}x{Wi} does not match output_size {Ho} * stride {self.stride}")
         ms = self.masker_spatial
-        if ms.mask_channel_group != 1:
-            raise LdnError("HIP path: spatial_mask_channel_group > 1 is not built (all shipped configs use 1)")
+        G = ms.mask_channel_group
         xn = ops.as_nhwc(x)
         if self.forced_spatial_mask is not None:
             patch = self.forced_spatial_mask.to(device=x.device, dtype=torch.float32).contiguous()
         else:
             patch = ms(x, 1.0)[0]
-        ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, self.stride)
         dev = x.device
+        # spatial_mask_channel_group > 1 (models/utils.py:27-33,74-89): group g of the OUTPUT channels has its own pixel mask.
+        # ExpandMask ORs the groups (its dilation kernel is [g,g,k,k] ones), so conv1 / conv2 -- and the sparsities the
+        # reference reports for them -- live on the UNION of the groups; only conv3's scatter is per group.
+        union = patch[:, 0] if G == 1 else patch.amax(dim=1)
+        ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride)
         x2d = xn.reshape(B * Hi * Wi, Cin)
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
         ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
         h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
         ops.conv_rows(h1, p["w2"], p["s2"], p["t2"], h2, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3)
         cout = p["w3"].shape[0]
+        if G == 1:
+            groups = [(ix, None, slice(0, cout))]
+        else:
+            if cout % (4 * G) != 0:
+                raise LdnError("HIP path: spatial_mask_channel_group must divide the output channels into multiples of 4")
+            groups = []
+            ar = torch.arange(ix.cap3, device=dev, dtype=torch.int32)
+            for g in range(G):
+                ig = ops.mask_to_index(patch[:, g].contiguous(), Ho, Wo, self.stride)
+                # packed h2 row (union list) of every pixel of this group's list; entries past the device-side count are unused
+                rows = torch.where(ar < ig.cnt[0], ix.pos3[ig.idx3.clamp(0, ix.cap3 - 1).long()], torch.full_like(ar, -1))
+                groups.append((ig, rows.contiguous(), slice(g * (cout // G), (g + 1) * (cout // G))))
         if self.downsample is not None:
             out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
-            ops.conv_rows(x2d, p["wd"], p["sd"], p["td"], out2d, a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev),
-                          taps=1, m_cap=ix.cap3, relu=2, relu_if_neg=ix.pos3)
+            ds_rows = self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev)
+            for ig, _, cs in groups:   # ReLU directly where the (pixel, group) is inactive: no branch output is added there
+                ops.conv_rows(x2d, p["wd"][cs], p["sd"][cs], p["td"][cs], out2d[:, cs], a_rows=ds_rows, taps=1, m_cap=ix.cap3,
+                              relu=2, relu_if_neg=ig.pos3)
             resid = out2d
         elif self._inplace:
             resid = out2d = x2d          # x >= 0 (post-ReLU) inside the network: inactive pixels pass through
         else:
             resid, out2d = x2d, torch.relu(x2d)
-        ops.conv_rows(h2, p["w3"], None, p["t3"], out2d, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
-                      out_rows=ix.idx3, residual2d=resid)
+        for ig, rows, cs in groups:
+            ops.conv_rows(h2, p["w3"][cs], None, p["t3"][cs], out2d[:, cs], a_rows=rows, taps=1, m_count=ig.cnt[0:1],
+                          m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs])
         self.last_spatial_mask = patch
+        if G > 1:   # sparsity of conv3 = mean over ALL group masks (Masker_spatial, utils.py:61); conv2 / conv1 = the union's
+            ix.stats = torch.cat((patch.mean().reshape(1), ix.stats[1:]))
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), patch, ix
 
     def _run_both(self, x, p):

@@ -18,6 +18,15 @@ def _f32c(t, what):
     return t
 
 
+def _f32rows(t, what):
+    """2-D fp32 tensor whose rows are contiguous (a column slice of a wider matrix is fine: the row stride is passed on)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.data_ptr() % 16 != 0:
+        raise L.LdnError(f"{what}: expected a 16-byte aligned float32 matrix with contiguous rows, got {t.dtype} strides {t.stride()}")
+    return t
+
+
 def _i32c(t, what):
     if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
         raise L.LdnError(f"{what}: expected a contiguous int32 tensor")
@@ -167,8 +176,8 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
                               L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(_f32c(w, "w")), cin, cout,
                               L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,
                               L.ptr(_i32c(relu_if_neg, "relu_if_neg")), L.ptr(_i32c(out_rows, "out_rows")),
-                              L.ptr(residual2d), residual2d.stride(0) if residual2d is not None else 0,
-                              L.ptr(_f32c(out2d, "out")), out2d.stride(0), _mm(math), L.stream_ptr(out2d)), "ldn_conv_rows")
+                              L.ptr(_f32rows(residual2d, "residual")), residual2d.stride(0) if residual2d is not None else 0,
+                              L.ptr(_f32rows(out2d, "out")), out2d.stride(0), _mm(math), L.stream_ptr(out2d)), "ldn_conv_rows")
     return out2d
 
 

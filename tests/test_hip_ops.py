@@ -378,3 +378,17 @@ def test_wide_1x1_image_gathered_inputs(ops, B, H, W, cout, gran, p):
     pad = (-flat.shape[1]) % 32
     flat = torch.cat([flat, flat.new_zeros(B, pad, cout)], dim=1).reshape(B, -1, 32, cout).sum(dim=2)
     assert torch.allclose(colsum.cpu().double(), flat, atol=1e-3, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ ExpandMask module surface (models/utils.py:67-89)
+def test_expand_mask_module_vs_reference_fixtures(ops):
+    """The HIP-side ExpandMask (dilation folded into ldn_mask_to_index; with several mask groups every output group is the OR
+    of all input groups, utils.py:81) against the outputs of the reference's ExpandMask stored in l1_ops.pt."""
+    from helpers import load_golden
+    from laudnet_amd.laud_resnet import ExpandMask
+    for case in load_golden("l1_ops.pt")["expand"]:
+        m = case["mask"]
+        if case["padding"] == 0 and case["stride"] != 1:
+            continue    # pure zero-insertion: never instantiated by a block (expander2 is (1,0), expander1 is (stride,1))
+        got = ExpandMask(stride=case["stride"], padding=case["padding"], mask_channel_group=m.shape[1])(m.to(DEV))
+        assert torch.equal(got.cpu(), case["y"].bool()), (case["stride"], case["padding"], tuple(m.shape))

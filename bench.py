@@ -546,12 +546,25 @@ def main():
     pj = os.path.join(ROOT, "profiles", "predicted_speedup_mi355x.json")
     if os.path.exists(pj):
         key = {"channel": "channel-2222", "spatial": "spatial S=4-4-2-1", "layer": "ResNet101 layer skip", "regnet": "RegNetY-800MF"}[args.workload]
-        rows = [r for r in json.load(open(pj))["rows"] if key in r["workload"] and r["mem_bandwidth"].startswith("8.0")]
-        if rows:
-            result["predicted_speedup"] = {"value": rows[0]["predicted_speedup"], "source": "reference DyNetSimulator, MI355X parameters "
-                                           "(256 CUs x 128 fp32 lanes, 2.4 GHz, 8 TB/s), bs256; uncalibrated NVIDIA-fitted knobs"}
+        pd = json.load(open(pj))
+        rows = [r for r in pd["rows"] if key in r["workload"]]
+        unc = [r for r in rows if r["mem_bandwidth"].startswith("8.0 TB/s (spec)")]
+        cal = [r for r in rows if "calibrated" in r["mem_bandwidth"]]
+        if unc:
+            result["predicted_speedup"] = {"value": unc[0]["predicted_speedup"], "source": "reference DyNetSimulator (harness pinned to its V100 "
+                                           "numbers by tests/test_predictor.py), MI355X parameters (256 CUs x 128 fp32 lanes, 2.4 GHz, "
+                                           "8 TB/s), bs256; reference-default (NVIDIA-fitted) knobs"}
+            if cal:
+                result["predicted_speedup"]["calibrated"] = {
+                    "value": cal[0]["predicted_speedup"], "knobs": pd.get("calibration", {}).get("knobs"),
+                    "fitted_to": "9 dense fp32 convs measured on MI355X (profiles/r02_dense_convs.json)",
+                    "predicted_static_ms_per_batch": 1e3 * cal[0]["static_latency_s"]}
+            best = (cal or unc)[0]["predicted_speedup"]
             if "realised_speedup_vs_dense_emulation" in result:
-                result["realised_over_predicted"] = result["realised_speedup_vs_dense_emulation"] / rows[0]["predicted_speedup"]
+                result["realised_over_predicted"] = {"math_" + args.math: result["realised_speedup_vs_dense_emulation"] / best}
+                if "realised_speedup_fp32_mode" in result:   # the predictor models fp32 FMA lanes: the like-for-like comparison
+                    result["realised_over_predicted"]["math_fp32"] = result["realised_speedup_fp32_mode"] / best
+                result["realised_over_predicted"]["predicted"] = best
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

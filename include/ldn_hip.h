@@ -32,6 +32,13 @@ extern "C" {
 
 const char* ldn_last_error(void);
 int ldn_version(void);
+/* Index-bounds audit ("race detection / sanitizers").  In the LDN_DEBUG build of the library (python -m
+ * laudnet_amd.build --debug -> libldn_hip_debug.so) every kernel checks the index lists it consumes or produces on the device
+ * (entries inside their tensor, counts inside the list capacity, channel pairs aligned and ascending, every in-bounds 3x3 tap
+ * of an active pixel present in the dilated list); violations are counted, never trapped.  *count = violations since the last
+ * reset (synchronises the device), *first_code = code of the first one (1xx conv, 2xx index build, 3xx fused tail, 4xx RegNet);
+ * the release build reports *count = -1 (checks compiled away).  Debug-only tooling: not on the hot path. */
+int ldn_debug_violations(int* count, int* first_code, int reset);
 /* number of compute units of the current device (used by callers to size persistent grids) */
 int ldn_device_cus(int* cus);
 /* Arithmetic of the MFMA convolutions -- the `math_mode` ARGUMENT of ldn_conv_image / ldn_conv_packed / ldn_conv_rows /

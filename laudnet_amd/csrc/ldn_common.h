@@ -28,6 +28,38 @@ bool allow_dynamic_lds(const void* kernel, size_t bytes);
         }                                                                               \
     } while (0)
 
+// ---- LDN_DEBUG build (python -m laudnet_amd.build --debug -> libldn_hip_debug.so): device-side checks of every index list a
+// kernel consumes (bounds, alignment of channel pairs, counts).  A violation never traps: it is COUNTED (per translation unit)
+// and the first one's code is kept; ldn_debug_violations() sums the counters.  Release builds compile the checks away.
+#ifdef LDN_DEBUG
+static __device__ unsigned g_ldn_viol[2] = {0u, 0u};   // {count, code of the first violation}
+#define LDN_DCHECK(cond, code)                                                   \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            if (atomicAdd(&g_ldn_viol[0], 1u) == 0u) g_ldn_viol[1] = (code);     \
+        }                                                                        \
+    } while (0)
+#define LDN_DEFINE_TU_VIOLATIONS(fn)                                                                  \
+    int fn(unsigned* count, unsigned* code, int reset) {                                              \
+        unsigned v[2] = {0u, 0u};                                                                     \
+        if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_ldn_viol), sizeof(v)) != hipSuccess) return LDN_EHIP; \
+        *count += v[0];                                                                               \
+        if (v[0] && !*code) *code = v[1];                                                             \
+        if (reset) {                                                                                  \
+            unsigned z[2] = {0u, 0u};                                                                 \
+            if (hipMemcpyToSymbol(HIP_SYMBOL(g_ldn_viol), z, sizeof(z)) != hipSuccess) return LDN_EHIP; \
+        }                                                                                             \
+        return LDN_OK;                                                                                \
+    }
+#else
+#define LDN_DCHECK(cond, code) do { } while (0)
+#define LDN_DEFINE_TU_VIOLATIONS(fn) int fn(unsigned*, unsigned*, int) { return LDN_OK; }
+#endif
+int tu_violations_conv(unsigned* count, unsigned* code, int reset);
+int tu_violations_index(unsigned* count, unsigned* code, int reset);
+int tu_violations_regnet(unsigned* count, unsigned* code, int reset);
+int tu_violations_tail(unsigned* count, unsigned* code, int reset);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -172,6 +172,10 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
     if (p.k_idx && tid < p.cin) raw_k = p.k_idx[(size_t)b * p.cin + tid];
     const int Kb = p.k_idx ? p.k_cnt[b] : p.cin;
     const int Nb = p.n_idx ? p.n_cnt[b] : p.cout;
+    LDN_DCHECK(Kb >= 0 && Kb <= p.cin, 101);                                   // channel counts within the list capacity
+    LDN_DCHECK(Nb >= 0 && Nb <= p.cout, 102);
+    LDN_DCHECK(!p.n_idx || !(tid < BNX && n0 + tid < Nb) || (raw_n >= 0 && raw_n < p.cout), 103);   // output-channel list entries
+    LDN_DCHECK(!p.k_idx || !(tid < Kb) || (raw_k >= 0 && raw_k < p.cin), 104);                     // input-channel list entries
     const int Nb4 = min(round_up(Nb, p.out_split ? 32 : 4), p.cout);
     if (n0 >= Nb4 || m0 >= HWo) return false;
     const int T = p.packed ? p.ksize : p.ksize * p.ksize;   // packed mode: ksize carries the tap count (1 or 9)
@@ -203,6 +207,7 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
             int orow = -1;
             if (valid) {
                 orow = p.out_map ? p.out_map[rbase + m] : rbase + m;
+                LDN_DCHECK(orow >= 0 && orow < 0x40000000, 105);               // destination rows are non-negative
                 if (p.relu == 2 && p.relu_if_neg[rbase + m] < 0) orow |= 0x40000000;   // bit 30: apply ReLU to this row
             }
             s_orow[i] = orow;
@@ -212,6 +217,7 @@ __device__ __forceinline__ bool tile_setup(const ImgArgs& p, float* smem, Tile& 
         for (int i = tid; i < BM * T; i += 512) {
             const int r = i / T, m = m0 + r;
             s_arow[i] = (m < HWo && r < p.bm) ? (p.a_map ? p.a_map[(size_t)(rbase + m) * T + (i - r * T)] : rbase + m) : -1;
+            LDN_DCHECK(s_arow[i] >= -1, 106);                                  // gather rows: -1 (zero row) or a row index
         }
     static_assert(BNX <= 512, "one thread per tile column");
     if (tid < BNX) {
@@ -1807,6 +1813,8 @@ static int dispatch_mode(const ImgArgs& p, int kgran, hipStream_t st) {
     if (g % 2 == 0) return launch_shape<B_KN2>(p, st);
     return launch_shape<B_KN1>(p, st);
 }
+
+LDN_DEFINE_TU_VIOLATIONS(tu_violations_conv)
 
 }  // namespace ldn
 

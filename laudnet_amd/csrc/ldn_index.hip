@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ pa
             const int p = f ? base3 + running + r : -1;
             s_pos3[i] = p;
             pos3[(size_t)b * HWo + i] = p;
+            LDN_DCHECK(!f || (p >= 0 && p < g.B * HWo), 201);                  // packed position inside the list capacity
             if (f) idx3[p] = b * HWo + i;
         }
         running += tot;
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ pa
             const int p = f ? base1 + running + r : -1;
             s_pos1[i] = p;
             pos1[(size_t)b * HWi + i] = p;
+            LDN_DCHECK(!f || (p >= 0 && p < g.B * HWi), 202);
             if (f) idx1[p] = b * HWi + i;
         }
         running += tot;
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ pa
         for (int t = 0; t < 9; ++t) {
             const int iy = oy * g.stride - 1 + t / 3, ix = ox * g.stride - 1 + t % 3;
             const bool inb = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+            LDN_DCHECK(!inb || s_pos1[iy * g.Wi + ix] >= 0, 203);              // every in-bounds tap of an active pixel is in the dilated list
             nbr[(size_t)p * 9 + t] = inb ? s_pos1[iy * g.Wi + ix] : -1;
         }
     }
@@ -516,12 +519,35 @@ __global__ __launch_bounds__(256) void k_spatial_head(const float* __restrict__ 
     }
 }
 
+LDN_DEFINE_TU_VIOLATIONS(tu_violations_index)
+
 }  // namespace ldn
 
 using namespace ldn;
 
 extern "C" const char* ldn_last_error(void) { return g_err; }
 extern "C" int ldn_version(void) { return 100; }
+extern "C" int ldn_debug_violations(int* count, int* first_code, int reset) {
+    LDN_REQUIRE(count != nullptr, "ldn_debug_violations: null pointer");
+#ifndef LDN_DEBUG
+    *count = -1;   // not a debug build: the checks are compiled away
+    if (first_code) *first_code = 0;
+    (void)reset;
+    return LDN_OK;
+#else
+    if (hipDeviceSynchronize() != hipSuccess) { set_error("ldn_debug_violations: device error"); return LDN_EHIP; }
+    unsigned c = 0, code = 0;
+    int rc = tu_violations_conv(&c, &code, reset);
+    if (!rc) rc = tu_violations_index(&c, &code, reset);
+    if (!rc) rc = tu_violations_regnet(&c, &code, reset);
+    if (!rc) rc = tu_violations_tail(&c, &code, reset);
+    if (rc) { set_error("ldn_debug_violations: cannot read the counters"); return rc; }
+    *count = (int)c;
+    if (first_code) *first_code = (int)code;
+    return LDN_OK;
+#endif
+}
+
 extern "C" int ldn_device_cus(int* cus) {
     int dev = 0;
     hipDeviceProp_t prop;

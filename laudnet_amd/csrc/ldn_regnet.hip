@@ -171,7 +171,12 @@ __global__ __launch_bounds__(256) void k_grouped3x3_chan(const float* __restrict
     const int b = blockIdx.y, tid = threadIdx.x;
     const int Cb = min(ch_cnt[b], C), G = C / gw;
     for (int g = tid; g < G; g += 256) { s_lo[g] = 0; s_hi[g] = 0; }
-    for (int j = tid; j < Cb; j += 256) s_ch[j] = ch_idx[(size_t)b * C + j];
+    for (int j = tid; j < Cb; j += 256) {
+        s_ch[j] = ch_idx[(size_t)b * C + j];
+        LDN_DCHECK(s_ch[j] >= 0 && s_ch[j] < C, 401);                              // channel list entries
+        LDN_DCHECK(j == 0 || s_ch[j] > ch_idx[(size_t)b * C + j - 1], 402);        // ascending (active runs per group are contiguous)
+    }
+    LDN_DCHECK(ch_cnt[b] >= 0 && ch_cnt[b] <= C, 403);
     __syncthreads();
     for (int j = tid; j < Cb; j += 256) {
         const int g = s_ch[j] / gw;
@@ -216,6 +221,8 @@ __global__ __launch_bounds__(256) void k_rows_scale(float* __restrict__ a, int l
         *p = *p * *reinterpret_cast<const f32x4*>(gate + (size_t)b * C + c);
     }
 }
+
+LDN_DEFINE_TU_VIOLATIONS(tu_violations_regnet)
 
 }  // namespace ldn
 

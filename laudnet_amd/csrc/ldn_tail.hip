@@ -127,6 +127,13 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
     const int nsub = ceil_div(Kb, 32);                         // n-subtiles == K slices (conv2 is square: same list)
     const int Kp = nsub * 32;
     if (tid < W + 32) s_kidx[tid] = tid < Kb ? p.k_idx[(size_t)b * W + tid] : -1;
+    LDN_DCHECK(p.k_cnt[b] >= 0 && p.k_cnt[b] <= W && (p.k_cnt[b] & 1) == 0, 301);   // count within the list, whole channel pairs
+    if (tid < Kb) {
+        const int ch = p.k_idx[(size_t)b * W + tid];
+        LDN_DCHECK(ch >= 0 && ch < W, 302);                                        // list entries are channels of this layer
+        LDN_DCHECK((tid & 1) ? (ch == p.k_idx[(size_t)b * W + tid - 1] + 1) : ((ch & 1) == 0), 303);   // aligned pairs (gran % 2 == 0)
+        LDN_DCHECK(tid == 0 || ch > p.k_idx[(size_t)b * W + tid - 1], 304);        // ascending
+    }
     // the zero rows of the two slice slots (never touched by the DMA, which covers rows 0 .. NRp-1)
     if (tid < 64) reinterpret_cast<float*>(s_h1 + (tid >> 5) * p.slice_bytes + ZR * 128)[tid & 31] = 0.f;
     __syncthreads();
@@ -460,6 +467,8 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
     }
 #endif
 }
+
+LDN_DEFINE_TU_VIOLATIONS(tu_violations_tail)
 
 static int tail_rows_per_block(int Ho, int Wo, int* mblocks) {
     int R = 256 / Wo;

@@ -1,0 +1,83 @@
+"""LDN_DEBUG build: the same forward passes through libldn_hip_debug.so, whose kernels audit every index list on the
+device.  A clean run must report zero violations with results identical to the release build's; a deliberately corrupted
+channel list must be counted (and must not trap).  Runs in a subprocess because the library path is fixed at import time."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import ctypes, json, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests/golden")
+import torch
+import laudnet_amd
+from laudnet_amd import _lib, ops
+from fill import fill_state_dict, seeded_randn, seeded_bernoulli
+lib = _lib.load()
+def violations(reset=1):
+    c, code = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.ldn_debug_violations(ctypes.byref(c), ctypes.byref(code), reset) == 0
+    return c.value, code.value
+res = {"initial": violations()}
+logits = {}
+for math in ("fp32", "bf16x3"):
+    ops.set_math_mode(math)
+    for mode, extra in (("channel", dict(channel_dyn_granularity=[2] * 4, channel_masker_layers=[2] * 4)),
+                        ("spatial", dict(mask_spatial_granularity=[4, 4, 2, 1])),
+                        ("both", dict(channel_dyn_granularity=[2] * 4, channel_masker_layers=[2] * 4, mask_spatial_granularity=[4, 4, 2, 1]))):
+        kw = dict(dyn_mode=[mode] * 4, width_mult=0.5, input_size=128, num_classes=10, **extra)
+        m = laudnet_amd.uni_resnet50(**kw).eval()
+        m.load_state_dict(fill_state_dict(m.state_dict(), 5))
+        m = m.cuda()
+        blocks = [b for s in (1, 2, 3, 4) for b in getattr(m, "layer%%d" %% s)]
+        for i, b in enumerate(blocks):
+            if b.masker_spatial is not None:
+                b.forced_spatial_mask = seeded_bernoulli((4, 1, b.masker_spatial.mask_size, b.masker_spatial.mask_size), 0.5, 100 + i)
+            if b.masker_channel is not None:
+                b.forced_channel_mask = seeded_bernoulli((4, b.masker_channel.channel_dyn_group), 0.62, 200 + i).cuda()
+        with torch.no_grad():
+            y = m(seeded_randn((4, 3, 128, 128), 9).cuda(), 1.0)[0]
+        logits[mode + "/" + math] = y.double().abs().sum().item()
+    rg = laudnet_amd.lad_regnet_y_400mf(dyn_mode=["channel"] * 4, channel_dyn_granularity=[2] * 4, channel_masker=["MLP"] * 4,
+                                        channel_masker_layers=[2] * 4, num_classes=10, input_size=64).eval().cuda()
+    with torch.no_grad():
+        logits["regnet/" + math] = rg(seeded_randn((2, 3, 64, 64), 3).cuda(), 1.0)[0].double().abs().sum().item()
+res["clean"] = violations()
+res["logits"] = logits
+# a corrupted channel list: an odd first entry breaks the aligned-pair invariant of the fused tail (reads stay inside the tensors)
+ops.set_math_mode("bf16x3")
+B, H, W = 2, 14, 64
+idx = torch.arange(W, dtype=torch.int32).repeat(B, 1).cuda()
+cnt = torch.full((B,), 32, dtype=torch.int32).cuda()
+idx[0, 0] = 1
+h1 = torch.zeros(B, H, H, W).cuda()
+out = torch.zeros(B, H, H, 256).cuda()
+ops.bottleneck_tail(h1, ops.pack_w2_pairs(torch.zeros(W, W, 3, 3).cuda()), ops.pack_w3_pairs(torch.zeros(256, W).cuda()), idx, cnt,
+                    torch.ones(W).cuda(), torch.zeros(16, W).cuda(), torch.zeros(W).cuda(), torch.zeros(256).cuda(), out)
+res["corrupted"] = violations()
+print("RESULT " + json.dumps(res))
+"""
+
+
+def _run(lib):
+    env = dict(os.environ, LDN_LIB_PATH=os.path.join(ROOT, "laudnet_amd", lib))
+    p = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+def test_debug_build_audits_index_lists():
+    assert os.path.exists(os.path.join(ROOT, "laudnet_amd", "libldn_hip_debug.so")), "build it: python -m laudnet_amd.build --debug"
+    dbg = _run("libldn_hip_debug.so")
+    rel = _run("libldn_hip.so")
+    assert rel["clean"][0] == -1, "the release build must say that its checks are compiled away"
+    assert dbg["initial"][0] == 0 and dbg["clean"] == [0, 0], f"index-bounds violations in a clean run: {dbg['clean']}"
+    assert dbg["logits"] == rel["logits"], "debug and release builds must compute identical results"
+    n, code = dbg["corrupted"]
+    assert n > 0 and 300 <= code < 400, f"the corrupted channel list was not flagged by the fused tail's checks: {dbg['corrupted']}"

@@ -44,7 +44,9 @@ for math in ("fp32", "bf16x3"):
             y = m(seeded_randn((4, 3, 128, 128), 9).cuda(), 1.0)[0]
         logits[mode + "/" + math] = y.double().abs().sum().item()
     rg = laudnet_amd.lad_regnet_y_400mf(dyn_mode=["channel"] * 4, channel_dyn_granularity=[2] * 4, channel_masker=["MLP"] * 4,
-                                        channel_masker_layers=[2] * 4, num_classes=10, input_size=64).eval().cuda()
+                                        channel_masker_layers=[2] * 4, num_classes=10, input_size=64).eval()
+    rg.load_state_dict(fill_state_dict(rg.state_dict(), 6))
+    rg = rg.cuda()
     with torch.no_grad():
         logits["regnet/" + math] = rg(seeded_randn((2, 3, 64, 64), 3).cuda(), 1.0)[0].double().abs().sum().item()
 res["clean"] = violations()

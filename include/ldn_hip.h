@@ -171,6 +171,13 @@ int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, in
  *   out = relu(w3 . u + shift3 + residual)          out/residual [B*H*Wd][ldo/ldr] fp32, may alias (in-place residual stream)
  *   colsum (optional) [B][ldn_bottleneck_tail_splits(H, Wd)][cout]: partial sums of out over disjoint pixel sets covering
  *   the image (the next block's channel masker takes them as gap_partial). */
+/* conv1 of the same block in the same style (k_head): h1 = relu(scale1 * conv1x1(x)[active channels] + shift1) - post_sub1, written
+ * in out_format 1 for ldn_bottleneck_tail (laud_resnet.py:115-118).  x [B*HW][ldx] fp32, cin % 32 == 0;
+ * w1_split [width][cin/8][32 B]: row n, octet o = bf16 {8 hi | 8 lo} of conv1.weight[n, 8o .. 8o+7] (n-major: the per-image
+ * OUTPUT-channel gather is a row gather). */
+int ldn_bottleneck_head(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
+                        const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
+                        const float* post_sub1, void* h1_split, int ldh, void* stream);
 int ldn_bottleneck_tail_splits(int H, int Wd);
 int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int width, const void* w2_pairs,
                         const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale2,

@@ -545,3 +545,226 @@ extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, 
     if (width == 128) return launch_tail<4>(a, st);
     return launch_tail<8>(a, st);
 }
+
+namespace ldn {
+
+// ================================================================================================================ k_head
+// conv1 of a channel-mode bottleneck in the same style as k_tail (transposed MFMA formulation, lane = pixel, bf16x3):
+//     h1 = relu(bn1(conv1x1(x)[active output channels])) - c1          (laud_resnet.py:115-118 on the image's channel list)
+// written PRE-SPLIT for k_tail ([pixel][octet][8 hi | 8 lo] bf16, zero-filled to a multiple of 32 columns).
+// Why a second kernel for it (the general k_conv_bf3 did this launch in round 1): measured on the stage-3 launch, a third of
+// k_conv_bf3's 180-196 k cycles per image were prologue + epilogue, and its two-deep staging kept only one K chunk in flight
+// per CU (producers 112 k cycles in issue).  Here:
+//   * the weights are pre-split once per module (n-major rows [n][octet][8 hi | 8 lo]): a weight fragment is two
+//     ds_read_b128 and NO VALU, the row gather through the channel list is a pointer;
+//   * x lands as raw fp32 through LDS-DMA and is split by the one wave that owns the pixels (24 VALU per K16 step, shared by
+//     all of the wave's n-subtiles);
+//   * a ring of D = 2..4 slots (as many as the image's subset leaves room for in 160 KiB) with counted vmcnt: D - 1 chunks of
+//     52 KB are in flight per CU -- the launch is bounded by the CU's memory pipe (x + the gathered weight rows), not by latency;
+//   * the epilogue pairs the two half-waves of a pixel with v_permlane32_swap so that every lane stores 16 contiguous bytes.
+struct HeadArgs {
+    const float* x; int ldx;
+    int B, HW, cin, W;
+    const unsigned char* w1s;                         // [W][cin / 8][32 B]
+    const int32_t* n_idx; const int32_t* n_cnt;       // [B][W], [B]
+    const float* sc1; const float* sh1; const float* ps1;   // [W]
+    unsigned char* h1; long h1_row_bytes;
+    int pix_per_blk, mblocks;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm_n() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vm_rt(int n) {   // counted wait with a run-time (wave-uniform) count, 0..16
+    switch (n) {
+        case 0: wait_vm_n<0>(); break;   case 1: wait_vm_n<1>(); break;   case 2: wait_vm_n<2>(); break;
+        case 3: wait_vm_n<3>(); break;   case 4: wait_vm_n<4>(); break;   case 5: wait_vm_n<5>(); break;
+        case 6: wait_vm_n<6>(); break;   case 7: wait_vm_n<7>(); break;   case 8: wait_vm_n<8>(); break;
+        case 9: wait_vm_n<9>(); break;   case 10: wait_vm_n<10>(); break; case 11: wait_vm_n<11>(); break;
+        case 12: wait_vm_n<12>(); break; case 13: wait_vm_n<13>(); break; case 14: wait_vm_n<14>(); break;
+        case 15: wait_vm_n<15>(); break; default: wait_vm_n<16>(); break;
+    }
+}
+
+constexpr int H_XROWS = 256;                          // rows of the x tile of a ring slot (pixels of the block, padded)
+
+template <int NS>
+__global__ __launch_bounds__(512, 2) void k_head(const HeadArgs p) {
+    constexpr int W = NS * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* const s_nidx = reinterpret_cast<int*>(smem);                    // [W + 32]
+    float* const s_tab = reinterpret_cast<float*>(smem + T_KIDX_BYTES);  // sc1 | sh1 | ps1 of the packed columns, 3 x W
+    unsigned char* const s_ring = smem + T_KIDX_BYTES + 3 * W * 4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x % p.B, mb = blockIdx.x / p.B;
+    const int m0 = mb * p.pix_per_blk;
+    const int npix = min(p.pix_per_blk, p.HW - m0);
+    const long row0 = (long)b * p.HW + m0;
+
+    const int Nb = min(p.n_cnt[b], W);
+    const int nsub = ceil_div(Nb, 32);
+    const int wrows = round_up(max(Nb, 1), 64);                          // weight rows staged per chunk (DMA instructions cover 8 rows)
+    if (tid < W + 32) s_nidx[tid] = tid < Nb ? p.n_idx[(size_t)b * W + tid] : -1;
+    __syncthreads();
+    for (int i = tid; i < 3 * W; i += 512) {
+        const int k = i / W, n = i - k * W;
+        const int ch = s_nidx[n];
+        const float* src = k == 0 ? p.sc1 : (k == 1 ? p.sh1 : p.ps1);
+        s_tab[i] = ch >= 0 ? src[ch] : 0.f;
+    }
+    // ring geometry: slot = [256 x rows | wrows weight rows] x 128 B; as many slots as fit (2..4)
+    const int xrows = round_up(npix, 32);                                // x rows staged per chunk: whole 32-pixel subtiles of busy waves
+    const int slot_bytes = (xrows + wrows) * 128;
+    const int avail = 160 * 1024 - (T_KIDX_BYTES + 3 * W * 4);
+    const int D = min(4, avail / slot_bytes);                            // >= 2 for W <= 256
+    const int nchunks = p.cin / 32;
+    const unsigned lds_ring = lds_off(s_ring);
+    const int nw = wrows / 64;                                           // weight DMA instructions per wave and chunk (1..4)
+    const bool active = wave * 32 < npix;
+    const int per_chunk = (active ? 4 : 0) + nw;                         // this wave's DMA instructions per chunk (4 = its 32 x rows)
+
+    // DMA of chunk c into slot c % D.  Wave w moves x rows [32 w, 32 w + 32) and weight rows {64 i + 8 w .. + 7}.
+    // one instruction = 8 rows x 128 B: lane = (row r0 + (lane >> 3), physical slot lane & 7); XOR swizzle on the SOURCE address
+    auto dma_chunk = [&](int c) {
+        const unsigned slot = lds_ring + (c % D) * slot_bytes;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave * 32 + i * 8 + (lane >> 3);
+                const int ls = (lane & 7) ^ ((r >> 1) & 7);
+                const float* src = r < npix ? p.x + (row0 + r) * p.ldx + c * 32 + ls * 4 : g_tail_zero;
+                dma16(src, slot + (wave * 32 + i * 8) * 128);
+            }
+        }
+        for (int i = 0; i < nw; ++i) {
+            const int r = i * 64 + wave * 8 + (lane >> 3);
+            const int ls = (lane & 7) ^ ((r >> 1) & 7);
+            const int ch = s_nidx[min(r, W + 31)];
+            const unsigned char* src = ch >= 0 ? p.w1s + ((long)ch * (p.cin / 8) + c * 4) * 32 + ls * 16
+                                               : reinterpret_cast<const unsigned char*>(g_tail_zero);
+            dma16(src, slot + (xrows + i * 64 + wave * 8) * 128);
+        }
+    };
+    auto dma_dummy = [&](int c) {   // keeps the per-iteration DMA count constant at the end of the K loop
+        const unsigned slot = lds_ring + (c % D) * slot_bytes;
+        for (int i = 0; i < per_chunk; ++i) dma16(g_tail_zero, slot + (xrows + (i % nw) * 64 + wave * 8) * 128);
+    };
+
+    f32x16 acc[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    for (int c = 0; c < D - 1; ++c) { if (c < nchunks) dma_chunk(c); else dma_dummy(c); }
+    const unsigned xrow = (unsigned)(wave * 32 + l31), xsw = (xrow >> 1) & 7u;
+    const unsigned wsw = ((unsigned)l31 >> 1) & 7u;      // weight row 32 j + l31: (row >> 1) & 7 == (l31 >> 1) & 7
+    for (int c = 0; c < nchunks; ++c) {
+        wait_vm_rt(per_chunk * (D - 2));     // chunk c has landed; the D - 2 chunks issued after it may still fly
+        lds_barrier();                       // ... for every wave; every wave has left chunk c - 1
+        if (c + D - 1 < nchunks) dma_chunk(c + D - 1); else dma_dummy(c + D - 1);
+        if (!active) continue;
+        const unsigned char* xs = s_ring + (c % D) * slot_bytes;
+        const unsigned char* ws = xs + xrows * 128;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned sl = 4u * half + 2u * h;          // logical 16-byte slot of this lane's 8 k values (x: fp32 k .. k+3, k+4 .. k+7)
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = e < 4 ? x0[e] : x1[e - 4];
+                const __bf16 hb = (__bf16)v;
+                bh[e] = hb;
+                bl[e] = (__bf16)(v - (float)hb);
+            }
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                if (j < nsub) {
+                    // weight row 32 j + l31, octet 2 half + h: [8 hi] at logical slot sl, [8 lo] at sl + 1 -- no VALU
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl ^ wsw) << 4));
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl + 1) ^ wsw) << 4));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    wait_vm_n<0>();      // no LDS-DMA may be in flight when the workgroup's LDS is released
+
+    // ---- epilogue: bn1 + ReLU - c1, split, pair the half-waves, 16-byte stores of [8 hi] (lanes 0-31) / [8 lo] (lanes 32-63)
+    const int pm = wave * 32 + l31;
+    if (!active) return;
+    unsigned char* orow = p.h1 + (row0 + min(pm, npix - 1)) * p.h1_row_bytes;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        if (j >= nsub) continue;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int n0 = 32 * j + 8 * q4 + 4 * h;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_tab + n0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(s_tab + W + n0);
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(s_tab + 2 * W + n0);
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            unsigned hi2[2], lo2[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float v0 = fmaxf(acc[j][4 * q4 + 2 * d] * sc[2 * d] + sh[2 * d], 0.f) - ps[2 * d];
+                const float v1 = fmaxf(acc[j][4 * q4 + 2 * d + 1] * sc[2 * d + 1] + sh[2 * d + 1], 0.f) - ps[2 * d + 1];
+                const bf16x2 hh = {(__bf16)v0, (__bf16)v1};
+                const bf16x2 ll = {(__bf16)(v0 - (float)hh[0]), (__bf16)(v1 - (float)hh[1])};
+                hi2[d] = __builtin_bit_cast(unsigned, hh);
+                lo2[d] = __builtin_bit_cast(unsigned, ll);
+            }
+            // lanes (pixel, 0) hold channels 0-3 of the octet, lanes (pixel, 1) channels 4-7.  After the swaps the lower lane holds
+            // the octet's 8 hi halves {own hi, partner's hi} and the upper lane its 8 lo halves {partner's lo, own lo}.
+            u32x4 outv;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const auto r = __builtin_amdgcn_permlane32_swap(hi2[d], lo2[d], false, false);   // vdst = hi, src = lo
+                const unsigned a = r[0], bq = r[1];   // lower lanes: a = own hi, bq = partner's hi; upper lanes: a = partner's lo, bq = own lo
+                outv[d] = a;
+                outv[2 + d] = bq;
+            }
+            if (pm < npix) *reinterpret_cast<u32x4*>(orow + (4 * j + q4) * 32 + h * 16) = outv;
+        }
+    }
+}
+
+template <int NS>
+static int launch_head(HeadArgs& a, hipStream_t st) {
+    const size_t lds = 160 * 1024;
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_head<NS>), lds), "k_head: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((k_head<NS>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
+    LDN_CHECK_LAUNCH("k_head");
+    return LDN_OK;
+}
+
+}  // namespace ldn
+
+extern "C" int ldn_bottleneck_head(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
+                                   const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
+                                   const float* post_sub1, void* h1_split, int ldh, void* stream) {
+    using namespace ldn;
+    LDN_REQUIRE(x && w1_split && ch_idx && ch_cnt && scale1 && shift1 && post_sub1 && h1_split, "ldn_bottleneck_head: null pointer");
+    LDN_REQUIRE(width == 64 || width == 128 || width == 256, "ldn_bottleneck_head: width must be 64, 128 or 256 (got %d)", width);
+    LDN_REQUIRE(B > 0 && HW > 0 && cin > 0 && cin % 32 == 0, "ldn_bottleneck_head: cin must be a multiple of 32 (got %d)", cin);
+    LDN_REQUIRE(ldx >= cin && ldx % 4 == 0 && ldh >= width && ldh % 8 == 0, "ldn_bottleneck_head: bad ldx / ldh");
+    LDN_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w1_split % 16 == 0 && (uintptr_t)h1_split % 16 == 0, "ldn_bottleneck_head: pointers must be 16-byte aligned");
+    HeadArgs a{};
+    a.x = x; a.ldx = ldx; a.B = B; a.HW = HW; a.cin = cin; a.W = width;
+    a.w1s = static_cast<const unsigned char*>(w1_split);
+    a.n_idx = ch_idx; a.n_cnt = ch_cnt; a.sc1 = scale1; a.sh1 = shift1; a.ps1 = post_sub1;
+    a.h1 = static_cast<unsigned char*>(h1_split); a.h1_row_bytes = (long)ldh * 4;
+    a.mblocks = ceil_div(HW, 256);
+    a.pix_per_blk = ceil_div(HW, a.mblocks);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (width == 64) return launch_head<2>(a, st);
+    if (width == 128) return launch_head<4>(a, st);
+    return launch_head<8>(a, st);
+}

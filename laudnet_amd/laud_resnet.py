@@ -430,6 +430,7 @@ class Bottleneck(_PrepCache):
         self.last_channel_cnt = cnt
         return ops.from_nhwc(out), mask
 
+    use_fused_head = True    # conv1 on k_head (False: the general ldn_conv_image with out_format 1)
     use_fused_tail = True    # class-level switch (A/B measurements): False keeps the three-launch gathered execution
 
     def _tail_eligible(self, Hi, Wi, Ho, Wo, cout):
@@ -449,6 +450,7 @@ class Bottleneck(_PrepCache):
                 p["w2p"] = ops.pack_w2_pairs(self.conv2.weight.detach().float().to(dev))
                 w3 = self.conv3.weight.detach().float().reshape(-1, self.width).to(dev) * p["s3"].view(-1, 1)
                 p["w3p"] = ops.pack_w3_pairs(w3)
+                p["w1s"] = ops.pack_w1_split(self.conv1.weight.detach().float().reshape(self.width, -1).to(dev))
         return p["w2p"], p["w3p"]
 
     def _shortcut(self, xn, p, identity):
@@ -499,8 +501,13 @@ class Bottleneck(_PrepCache):
         if self._tail_eligible(Hi, Wi, Ho, Wo, cout):
             # bf16x3 arithmetic, stride 1, even granularity: conv1 writes h1 pre-split, then ONE launch runs conv2 -> conv3
             # (h2 never exists in memory, every K slice of h1 is staged once for all nine taps)
-            ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1, out_split=True)
             w2p, w3p = self.tail_weights(p)
+            # k_head (deep staging ring, one workgroup per CU) pays where an image fills a workgroup and K is long (stage 3);
+            # the early stages stream many short blocks and stay on the general kernel, two workgroups per CU (measured)
+            if self.use_fused_head and Cin % 32 == 0 and self.width == 256:
+                ops.bottleneck_head(xn, p["w1s"], idx, cnt, p["s1"], p["t1"], p["c1"], h1)
+            else:
+                ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1, out_split=True)
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)
             gap_out = (torch.empty(B, ops.bottleneck_tail_splits(Ho, Wo), cout, device=dev, dtype=torch.float32)

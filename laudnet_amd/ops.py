@@ -343,6 +343,29 @@ def pack_w3_pairs(w3_scaled):
     return torch.stack((hi, lo), dim=-2).contiguous()
 
 
+def pack_w1_split(conv1_weight_2d):
+    """conv1.weight as [W, cin] fp32 -> [W][cin/8][hi 8 | lo 8] bf16 (n-major rows, pre-split; ldn_bottleneck_head)."""
+    W, cin = conv1_weight_2d.shape
+    w = conv1_weight_2d.detach().float().reshape(W, cin // 8, 8)
+    hi, lo = _hi_lo(w)
+    return torch.stack((hi, lo), dim=-2).contiguous()
+
+
+def bottleneck_head(x_nhwc, w1_split, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1_split):
+    """conv1 of a channel-mode block on the image's active output channels, written pre-split (see ldn_bottleneck_head)."""
+    L.require_device(x_nhwc, w1_split, h1_split)
+    lib = L.load()
+    B, H, Wd, cin = x_nhwc.shape
+    width = ch_idx.shape[1]
+    if w1_split.dtype != torch.bfloat16 or not w1_split.is_contiguous():
+        raise L.LdnError("bottleneck_head: w1_split must be the contiguous bf16 tensor of pack_w1_split")
+    L.check(lib.ldn_bottleneck_head(L.ptr(_f32c(x_nhwc, "x")), cin, B, H * Wd, cin, L.ptr(w1_split), width,
+                                    L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")), L.ptr(_f32c(scale1, "scale1")),
+                                    L.ptr(_f32c(shift1, "shift1")), L.ptr(_f32c(post_sub1, "post_sub1")),
+                                    L.ptr(_f32c(h1_split, "h1")), h1_split.shape[-1], L.stream_ptr(h1_split)), "ldn_bottleneck_head")
+    return h1_split
+
+
 def bottleneck_tail_splits(H, W):
     return L.load().ldn_bottleneck_tail_splits(H, W)
 

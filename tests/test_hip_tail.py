@@ -69,6 +69,19 @@ def test_tail_vs_reference_algebra(ops, B, H, cin, W, gran, down):
         pad = (n + 31) // 32 * 32
         assert bool((dec[b, :, :, n:pad] == 0).all()), "columns up to the next multiple of 32 must be zero"
     w2p, w3p = hb.tail_weights(p)
+    # conv1 on k_head: same pre-split output (identical arithmetic up to the order of the K sum)
+    if cin % 32 == 0:
+        h1h = torch.full((B, H, H, W), float("nan"), device=DEV)
+        ops.bottleneck_head(xn, p["w1s"], idx, cnt, p["s1"], p["t1"], p["c1"], h1h)
+        dech = _decode_split(h1h).cpu()
+        for b in range(B):
+            n = int(cnt[b])
+            ch = idx[b, :n].cpu().long()
+            want1 = h1[b, ch].permute(1, 2, 0) - c1[ch]
+            assert torch.allclose(dech[b, :, :, :n], want1, atol=1e-4, rtol=1e-4), f"k_head output, image {b}"
+            pad = (n + 31) // 32 * 32
+            assert bool((dech[b, :, :, n:pad] == 0).all()), "k_head: columns up to the next multiple of 32 must be zero"
+        h1s = h1h     # the tail below consumes k_head's output
     idn = ident.permute(0, 2, 3, 1).contiguous().to(DEV)
     splits = ops.bottleneck_tail_splits(H, H)
     colsum = torch.full((B, splits, cout), float("nan"), device=DEV)

@@ -43,6 +43,9 @@ struct TailArgs {
 
 __device__ __attribute__((aligned(16))) float g_tail_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifndef LDN_TAIL_PRIO
+#define LDN_TAIL_PRIO 0     // tuning: 1 = s_setprio(1) around the MFMA section of a conv2 chunk, 2 = s_setprio(2) around its DMA issue
+#endif
 #ifdef LDN_TRACE   // tuning only: per-workgroup phase timestamps of every wave (tools/trace_tail.py)
 __device__ unsigned long long* g_tail_trace = nullptr;
 #define TT(x) x = __builtin_amdgcn_s_memtime();
@@ -235,10 +238,19 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
             // issue: next slice's share first, then the W2 tile of chunk c + 2 (issue order matters for the counted wait)
             TT(tb)
             TT_ADD(w2wait, ta, tb)
+#if LDN_TAIL_PRIO == 2
+            __builtin_amdgcn_s_setprio(2);
+#endif
             if (s + 1 < nsub) { const int q = t * 8 + wave; if (q < nq) dma_h1(s + 1, q); }
             if (c + 2 < nchunks) dma_w2(c + 2);
             else { for (int e = 0; e < n_w2; ++e) dma16(g_tail_zero, lds_w2 + ((t + 2) % T_W2_SLOTS) * W2_SLOT + (2 * wave) * W2_ROW); }   // keeps the count
+#if LDN_TAIL_PRIO == 2
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (!active) continue;
+#if LDN_TAIL_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);
+#endif
             // compute chunk c: tap t of K slice s.  B fragment = h1 row of the tap (per-lane LDS address), A = staged W2 rows.
             const unsigned char* ws = s_w2 + (t % T_W2_SLOTS) * W2_SLOT;
             const unsigned rbase = (unsigned)trow[t] * 128u, rx = ((unsigned)trow[t] >> 1) & 7u;
@@ -279,6 +291,9 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                 }
             }
+#if LDN_TAIL_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     }
     wait_vm<0>();

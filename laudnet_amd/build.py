@@ -52,5 +52,5 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
-    if "--debug" in sys.argv:
+    if "--debug" in sys.argv or os.path.exists(DEBUG_LIB):     # an existing audit build is kept in step with the sources
         build_debug(force="--force" in sys.argv)

@@ -53,6 +53,9 @@ def _eval_only(module: nn.Module, x: torch.Tensor):
 
 
 _SIDE_STREAMS = {}
+# Projection shortcuts on a side stream next to conv1 / conv2?  Round 1: yes (the main chain's launches left CUs idle).  With the
+# one-workgroup-per-CU kernels of round 2 the overlap only steals their CUs: inline is 1.3 % faster end to end (16.05 vs 16.27 ms).
+_USE_SIDE_STREAM = __import__("os").environ.get("LDN_SIDE_STREAM", "0") == "1"
 
 
 def _side_stream(dev):
@@ -488,10 +491,13 @@ class Bottleneck(_PrepCache):
             # the projection shortcut only depends on x: it runs on a side stream next to conv1 / conv2 and is joined
             # before conv3 (a fork/join that hipGraph capture records as such)
             identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
-            cur = torch.cuda.current_stream(dev)
-            side = _side_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            if _USE_SIDE_STREAM:
+                cur = torch.cuda.current_stream(dev)
+                side = _side_stream(dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._shortcut(xn, p, identity)
+            else:
                 self._shortcut(xn, p, identity)
             out = identity
         else:

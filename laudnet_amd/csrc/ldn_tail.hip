@@ -88,8 +88,11 @@ constexpr int T_W2_SLOTS = 3;
 
 // NS = W / 32 (maximum n-subtiles / K slices of an image): 2, 4 or 8
 template <int NS>
-__global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
+__global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_tail(const TailArgs p) {
     constexpr int W = NS * 32;
+    // NS == 2 (stage 1: 14 short blocks per image, all of them bound by the CU's memory pipe in their conv3 phase and idle on it in
+    // their conv2 phase): ONE h1 slice slot and 128 registers, so that TWO workgroups fit a CU and overlap each other's phases.
+    constexpr int SLICE_BUFS = NS == 2 ? 1 : 2;
     constexpr int W2_ROW = NS * 256;                  // bytes of one k-pair row of the staged W2 tile: W entries of 8 B
     constexpr int W2_SLOT = 16 * W2_ROW;              // 16 k-pairs = one K slice of 32
     constexpr int CW = NS == 8 ? 32 : 64;             // output channels per conv3 chunk
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* const s_kidx = reinterpret_cast<int*>(smem);
     unsigned char* const s_h1 = smem + T_KIDX_BYTES;                      // 2 slice slots (conv2 phase)
-    unsigned char* const s_w2 = s_h1 + 2 * p.slice_bytes;                 // 3 W2 slots   (conv2 phase)
+    unsigned char* const s_w2 = s_h1 + SLICE_BUFS * p.slice_bytes;        // 3 W2 slots   (conv2 phase)
     unsigned char* const s_w3 = smem + T_KIDX_BYTES;                      // 2 W3 slots   (conv3 phase, over the above)
     float* const s_tab = reinterpret_cast<float*>(s_w3 + 2 * W3_SLOT);    // sc2[NP], ps2[NP], sh2[16][NP] (conversion)
     unsigned char* const s_scr = reinterpret_cast<unsigned char*>(s_tab + 18 * NP);   // 8 x 4 KiB transpose scratch
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
         LDN_DCHECK(tid == 0 || ch > p.k_idx[(size_t)b * W + tid - 1], 304);        // ascending
     }
     // the zero rows of the two slice slots (never touched by the DMA, which covers rows 0 .. NRp-1)
-    if (tid < 64) reinterpret_cast<float*>(s_h1 + (tid >> 5) * p.slice_bytes + ZR * 128)[tid & 31] = 0.f;
+    if (tid < 32 * SLICE_BUFS) reinterpret_cast<float*>(s_h1 + (tid >> 5) * p.slice_bytes + ZR * 128)[tid & 31] = 0.f;
     __syncthreads();
 
     // ---- this lane's output pixel and its nine tap rows in the slice (ZR = zero row)
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
         const int lslot = (lane & 7) ^ ((r >> 1) & 7);
         const unsigned char* src = r < NR ? p.h1 + (in_row0 + r) * p.h1_row_bytes + slice * 128 + lslot * 16
                                           : reinterpret_cast<const unsigned char*>(g_tail_zero);
-        dma16(src, lds_h1 + (slice & 1) * p.slice_bytes + q * 1024);
+        dma16(src, lds_h1 + (slice % SLICE_BUFS) * p.slice_bytes + q * 1024);
     };
     // W2 chunk (slice s, tap t): 16 k-pair rows x (Kp / 2) n-pair pieces of 16 B.  Wave w stages rows 2w and 2w + 1.
     //   NS == 2: one instruction covers both rows (lanes 0-31 / 32-63); NS == 4: one instruction per row;
@@ -228,20 +231,25 @@ __global__ __launch_bounds__(512, 2) void k_tail(const TailArgs p) {
     const unsigned a_lane = (unsigned)(4 * h * W2_ROW + l31 * 8);          // A (weights): k-pair rows 4h .. 4h+3 of a K16 step
     TT(tr1)
     for (int s = 0; s < nsub; ++s) {
-        const unsigned char* hs = s_h1 + (s & 1) * p.slice_bytes;
+        const unsigned char* hs = s_h1 + (s % SLICE_BUFS) * p.slice_bytes;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {                           // chunk c = 9 s + t lives in W2 slot c % 3 == t % 3
             const int c = 9 * s + t;
             TT(ta)
             wait_chunk();
             lds_barrier();     // chunk c (and, when t == 0, slice s) is in LDS for every wave; every wave has left chunk c - 1
+            if (SLICE_BUFS == 1 && t == 0 && s > 0) {   // single slice slot: every wave has left slice s - 1 -> fetch slice s now (the
+                for (int q = wave; q < nq; q += 8) dma_h1(s, q);   // co-resident workgroup covers the stall)
+                wait_vm<0>();
+                lds_barrier();
+            }
             // issue: next slice's share first, then the W2 tile of chunk c + 2 (issue order matters for the counted wait)
             TT(tb)
             TT_ADD(w2wait, ta, tb)
 #if LDN_TAIL_PRIO == 2
             __builtin_amdgcn_s_setprio(2);
 #endif
-            if (s + 1 < nsub) { const int q = t * 8 + wave; if (q < nq) dma_h1(s + 1, q); }
+            if (SLICE_BUFS == 2 && s + 1 < nsub) { const int q = t * 8 + wave; if (q < nq) dma_h1(s + 1, q); }
             if (c + 2 < nchunks) dma_w2(c + 2);
             else { for (int e = 0; e < n_w2; ++e) dma16(g_tail_zero, lds_w2 + ((t + 2) % T_W2_SLOTS) * W2_SLOT + (2 * wave) * W2_ROW); }   // keeps the count
 #if LDN_TAIL_PRIO == 2
@@ -500,7 +508,7 @@ static int launch_tail(TailArgs& a, hipStream_t st) {
     const int R = a.rows_per_blk;
     const int nr = min(R + 2, a.Hi) * a.Wi;
     a.slice_bytes = round_up((round_up(nr, 8) + 1) * 128, 1024);
-    const size_t lds2 = (size_t)T_KIDX_BYTES + 2 * (size_t)a.slice_bytes + (size_t)T_W2_SLOTS * 16 * NS * 256;
+    const size_t lds2 = (size_t)T_KIDX_BYTES + (NS == 2 ? 1 : 2) * (size_t)a.slice_bytes + (size_t)T_W2_SLOTS * 16 * NS * 256;
     const size_t lds3 = (size_t)T_KIDX_BYTES + 2 * (size_t)(W / 2) * (NS == 8 ? 32 : 64) * 8 + (size_t)18 * W * 4 + 8 * 4096;
     const size_t lds = lds2 > lds3 ? lds2 : lds3;
     LDN_REQUIRE(lds <= 160 * 1024, "ldn_bottleneck_tail: %zu B of LDS exceed 160 KiB (map %dx%d, width %d)", lds, a.Ho, a.Wo, W);

@@ -112,6 +112,19 @@ int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int taps, cons
                   const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
                   float* out, int ldo, int math_mode, void* stream);
 
+/* The same contract on the round-2 kernel k_dense (bf16x3 arithmetic): the weights come PRE-SPLIT, n-major --
+ * w_split [cout][taps*cin/8][32 B], row n, octet o = bf16 {8 hi | 8 lo} of w[n, 8o .. 8o+7] over the K axis (tap, channel)
+ * (one-time module preparation) -- so that a weight fragment needs no conversion in the K loop; cin % 32 == 0, cout % 32 == 0;
+ * taps == 9: a_rows is the [rows][9] neighbour table of ldn_mask_to_index.  shift_classes 16 + pix_map + geometry: the
+ * border-class shift table of the channel algebra, as in ldn_conv_packed.  Two optional epilogue terms of the dense
+ * execution of channel mode: post_sub [cout] is subtracted after the ReLU, chan_mask [B][cout] {0,1} multiplies
+ * row r by the mask of image floor(dst(r) / rows_per_image) (apply_channel_mask, models/utils.py:18-25, fused). */
+int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
+                        const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
+                        const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr, float* out,
+                        int ldo, const float* post_sub, const float* chan_mask, int rows_per_image, int shift_classes,
+                        const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride, void* stream);
+
 /* ---- a2: Masker_channel_MLP.forward, eval branch (models/utils.py:113-131) + index build ----
  * x [B,HW,C] NHWC -> global average pool -> Linear(C,hidden)+ReLU+Linear(hidden,2G) (hidden>0)
  * or Linear(C,2G) (hidden==0: w1=[2G,C], b1=[2G], w2/b2 unused) -> mask[b,j] = l[j] >= l[G+j].

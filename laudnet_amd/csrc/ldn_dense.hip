@@ -1,0 +1,314 @@
+// k_dense -- shared-weight 1x1 convolution over (packed) pixel rows in the round-2 style (gfx950, bf16x3):
+//     out[dst(m), n] = act(scale[n] * sum_k A[src(m), k] * w[n, k] + shift[n] (+ residual[dst(m), n]))
+// (laud_resnet.py:115-144 restricted to the active pixels: conv1 / conv3 / projection shortcut of spatial, layer and `both`
+// blocks; the dense execution of channel-mode stage 4; LAD-RegNet a / c / proj).  Same contract as ldn_conv_rows with taps == 1.
+//
+// Structure (shared with k_head / k_tail, csrc/ldn_tail.hip): transposed MFMA formulation (A operand = weights, B operand =
+// activations, lane = row); the weights are pre-split once per module into n-major rows [n][octet][8 hi | 8 lo] bf16 -- a
+// weight fragment is two ds_read_b128 and no VALU; the activation rows land as raw fp32 through LDS-DMA (row gather = per-lane
+// source address) and are split by the one wave that owns the 32 rows; no producer waves -- every wave issues its share of the
+// DMA (inline asm) with counted vmcnt over a ring of 2-3 slots.  One workgroup = 256 rows x NT columns (NT = 64 / 128 / 256).
+#include "ldn_common.h"
+
+namespace ldn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct DenseArgs {
+    const float* a; int lda;
+    const int32_t* a_rows; const int32_t* m_count; int m_cap;
+    const unsigned char* ws;                          // [cout][cin / 8][32 B]
+    int cin, cout;
+    const float* scale; const float* shift; int relu;
+    const int32_t* relu_if_neg; const int32_t* out_rows;
+    const float* residual; int ldr; float* out; int ldo;
+    int taps;                                         // 1, or 9: a_rows is then [rows][9] (-1 = zero row) and w_split rows hold 9 * cin inputs (tap-major)
+    int shift_classes; const int32_t* pix_map;        // 16: shift is [16][cout], selected by the border class of the row's output pixel
+    int Hi, Wi, Ho, Wo, stride;                       //     (pix_map[row] = flat output pixel; geometry of the 3x3 layer)
+    const float* post_sub;                            // optional [cout]: subtracted after the ReLU (channel algebra)
+    const float* chmask; int rows_per_img;            // optional [B][cout] {0,1}: out *= chmask[dst / rows_per_img][n] (dense channel exec)
+    int mtn, ntn;                                     // M tiles (of 256 rows), N tiles (of NT columns)
+};
+
+__device__ __attribute__((aligned(16))) float g_dense_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void d_dma16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+template <int N> __device__ __forceinline__ void d_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void d_wait_vm_rt(int n) {
+    switch (n) {
+        case 1: d_wait_vm<1>(); break;   case 2: d_wait_vm<2>(); break;   case 3: d_wait_vm<3>(); break;
+        case 4: d_wait_vm<4>(); break;   case 5: d_wait_vm<5>(); break;   case 6: d_wait_vm<6>(); break;
+        case 7: d_wait_vm<7>(); break;   case 8: d_wait_vm<8>(); break;
+        default: d_wait_vm<0>(); break;   // 0, and anything unexpected: wait for everything (always safe)
+    }
+}
+__device__ __forceinline__ void d_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ unsigned d_lds_off(const void* ptr) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)ptr;
+}
+
+constexpr int D_ROWS = 256;
+constexpr int D_ROW_RELU = 1 << 30;
+
+// NSUB = n-subtiles of 32 columns per workgroup (2, 4, 8); D = ring depth (2 for NSUB 8, 3 otherwise)
+template <int NSUB>
+__global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
+    constexpr int NT = NSUB * 32;
+    constexpr int D = NSUB == 8 ? 2 : 3;
+    constexpr int SLOT = (D_ROWS + NT) * 128;
+    constexpr int NWI = NT / 64 > 0 ? NT / 64 : 1;    // weight DMA instructions per wave and chunk (8 rows each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* const s_arow = reinterpret_cast<int*>(smem);            // [256] source row or -1
+    int* const s_orow = s_arow + D_ROWS;                         // [256] destination row | D_ROW_RELU, or -1
+    int* const s_cls = s_orow + D_ROWS;                          // [256] border class * cout (16-class shift table) or 0
+    int* const s_atap = s_cls + D_ROWS;                          // [256][9] source rows per tap (taps == 9)
+    unsigned char* const s_ring = smem + (3 + 9) * D_ROWS * 4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    // XCD-aware order: the N tiles of one M tile get consecutive slots of ONE XCD (block b runs on XCD b % 8), so the A rows of
+    // the tile come from HBM once and from that XCD's L2 for the other N tiles
+    const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+    const int nt = slot_i % p.ntn, mt = (slot_i / p.ntn) * 8 + xcd;
+    if (mt >= p.mtn) return;
+    const int M = p.m_count ? min(p.m_count[0], p.m_cap) : p.m_cap;
+    const int m0 = mt * D_ROWS;
+    if (m0 >= M) return;
+    const int rows = min(D_ROWS, M - m0);
+    const int n0 = nt * NT;
+    const int nsub = min(NSUB, (p.cout - n0) / 32);
+
+    if (tid < D_ROWS) {
+        int ar = -1, orw = -1;
+        if (tid < rows) {
+            ar = (p.a_rows && p.taps == 1) ? p.a_rows[m0 + tid] : m0 + tid;
+            orw = p.out_rows ? p.out_rows[m0 + tid] : m0 + tid;
+            if (p.relu == 1 || (p.relu == 2 && p.relu_if_neg[m0 + tid] < 0)) orw |= D_ROW_RELU;
+        }
+        int cls = 0;
+        if (tid < rows && p.shift_classes > 1) {
+            const int q = p.pix_map[m0 + tid] % (p.Ho * p.Wo);
+            const int oy = q / p.Wo, ox = q - oy * p.Wo;
+            const int top = oy * p.stride - 1 < 0, bot = oy * p.stride + 1 >= p.Hi;
+            const int lef = ox * p.stride - 1 < 0, rig = ox * p.stride + 1 >= p.Wi;
+            cls = ((top | (bot << 1)) * 4 + (lef | (rig << 1))) * p.cout;
+        }
+        LDN_DCHECK(tid >= rows || (ar >= -1 && (orw & (D_ROW_RELU - 1)) >= 0), 501);
+        s_arow[tid] = ar;
+        s_orow[tid] = orw;
+        s_cls[tid] = cls;
+    }
+    if (p.taps == 9)
+        for (int i = tid; i < D_ROWS * 9; i += 512) {
+            const int r = i / 9;
+            s_atap[i] = r < rows ? p.a_rows[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
+        }
+    __syncthreads();
+
+    const bool active = wave * 32 < rows;
+    const int cpt = p.cin / 32;                                  // chunks per tap
+    const int nchunks = p.taps * cpt;
+    const unsigned lds_ring = d_lds_off(s_ring);
+    const int per_chunk = (active ? 4 : 0) + NWI;
+    long asrc[4];                                                // this lane's four source rows (element offsets), -1 = zero row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ar = s_arow[wave * 32 + i * 8 + (lane >> 3)];
+        asrc[i] = ar >= 0 ? (long)ar * p.lda : -1;
+    }
+    auto dma_chunk = [&](int c) {
+        const unsigned slot = lds_ring + (c % D) * SLOT;
+        const int tap = c / cpt, ck = c - tap * cpt;             // K position = tap * cin + 32 ck
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave * 32 + i * 8 + (lane >> 3);
+                const int ls = (lane & 7) ^ ((r >> 1) & 7);
+                long off = asrc[i];
+                if (p.taps == 9) {
+                    const int ar = s_atap[r * 9 + tap];
+                    off = ar >= 0 ? (long)ar * p.lda : -1;
+                }
+                const float* src = off >= 0 ? p.a + off + ck * 32 + ls * 4 : g_dense_zero;
+                d_dma16(src, slot + (wave * 32 + i * 8) * 128);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            const int r = i * 64 + wave * 8 + (lane >> 3);
+            const int ls = (lane & 7) ^ ((r >> 1) & 7);
+            const int n = n0 + r;
+            const unsigned char* src = (r < NT && n < p.cout) ? p.ws + ((long)n * (p.taps * p.cin / 8) + c * 4) * 32 + ls * 16
+                                                               : reinterpret_cast<const unsigned char*>(g_dense_zero);
+            d_dma16(src, slot + (D_ROWS + (r < NT ? i * 64 + wave * 8 : 0)) * 128);
+        }
+    };
+    auto dma_dummy = [&](int c) {
+        const unsigned slot = lds_ring + (c % D) * SLOT;
+        for (int i = 0; i < per_chunk; ++i) d_dma16(g_dense_zero, slot + (D_ROWS + wave * 8) * 128);
+    };
+
+    f32x16 acc[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    for (int c = 0; c < D - 1; ++c) { if (c < nchunks) dma_chunk(c); else dma_dummy(c); }
+    const unsigned xrow = (unsigned)(wave * 32 + l31), xsw = (xrow >> 1) & 7u;
+    const unsigned wsw = ((unsigned)l31 >> 1) & 7u;
+    for (int c = 0; c < nchunks; ++c) {
+        d_wait_vm_rt(per_chunk * (D - 2));
+        d_lds_barrier();
+        if (c + D - 1 < nchunks) dma_chunk(c + D - 1); else dma_dummy(c + D - 1);
+        if (!active) continue;
+        const unsigned char* xs = s_ring + (c % D) * SLOT;
+        const unsigned char* ws = xs + D_ROWS * 128;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned sl = 4u * half + 2u * h;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = e < 4 ? x0[e] : x1[e - 4];
+                const __bf16 hb = (__bf16)v;
+                bh[e] = hb;
+                bl[e] = (__bf16)(v - (float)hb);
+            }
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                if (j < nsub) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl ^ wsw) << 4));
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl + 1) ^ wsw) << 4));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    d_wait_vm<0>();
+    d_lds_barrier();       // every wave is out of the ring: it becomes the per-wave 32 x 32 transpose scratch
+    if (!active) return;
+
+    // ---- epilogue: per n-subtile, C layout (lane = row, register = channel) -> rows of 32 channels, 16-byte accesses
+    float* const scr = reinterpret_cast<float*>(s_ring + wave * 4096);
+    const int trw = lane >> 3, tc = lane & 7;
+    int orw[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) orw[it] = s_orow[wave * 32 + trw + 8 * it];
+    auto load_res = [&](int j, f32x4 (&res)[4], f32x4& sc, f32x4& sh, f32x4& ps) {
+        const int cb = n0 + 32 * j + tc * 4;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float* src = (p.residual && orw[it] >= 0) ? p.residual + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldr + cb : g_dense_zero;
+            res[it] = *reinterpret_cast<const f32x4*>(src);
+        }
+        sh = *reinterpret_cast<const f32x4*>(p.shift + cb);      // (one class; the 16-class table is read per row below)
+        sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cb) : f32x4{1.f, 1.f, 1.f, 1.f};
+        ps = p.post_sub ? *reinterpret_cast<const f32x4*>(p.post_sub + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+        if (j >= nsub) continue;
+        f32x4 res[4], sc, sh, ps;
+        load_res(j, res, sc, sh, ps);
+        f32x4 cm[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float* src = (p.chmask && orw[it] >= 0) ? p.chmask + (size_t)((orw[it] & (D_ROW_RELU - 1)) / p.rows_per_img) * p.cout + n0 + 32 * j + tc * 4
+                                                          : nullptr;
+            cm[it] = src ? *reinterpret_cast<const f32x4*>(src) : f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = {acc[j][4 * q4], acc[j][4 * q4 + 1], acc[j][4 * q4 + 2], acc[j][4 * q4 + 3]};
+            *reinterpret_cast<f32x4*>(scr + l31 * 32 + (((2 * q4 + h) ^ (l31 & 7)) << 2)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // residual / scale / shift registers touched before the first store (gfx9: a load first used after a store waits vmcnt(0)
+        // for that store's acknowledgement)
+        asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sc), "+v"(sh), "+v"(ps));
+        asm volatile("" : "+v"(cm[0]), "+v"(cm[1]), "+v"(cm[2]), "+v"(cm[3]));
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = trw + 8 * it;
+            f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
+            const f32x4 shr = p.shift_classes > 1 ? *reinterpret_cast<const f32x4*>(p.shift + s_cls[wave * 32 + row] + n0 + 32 * j + tc * 4) : sh;
+            x = x * sc + shr + res[it];
+            if (orw[it] & D_ROW_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+            }
+            x = (x - ps) * cm[it];
+            if (orw[it] >= 0)
+                *reinterpret_cast<f32x4*>(p.out + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + tc * 4) = x;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+LDN_DEFINE_TU_VIOLATIONS(tu_violations_dense)
+
+template <int NSUB>
+static int launch_dense(DenseArgs& a, hipStream_t st) {
+    constexpr int NT = NSUB * 32;
+    constexpr int D = NSUB == 8 ? 2 : 3;
+    const size_t lds = (size_t)(3 + 9) * D_ROWS * 4 + (size_t)D * (D_ROWS + NT) * 128;
+    a.ntn = ceil_div(a.cout, NT);
+    a.mtn = ceil_div(a.m_cap, D_ROWS);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
+    const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
+    hipLaunchKernelGGL((k_dense<NSUB>), dim3(grid), dim3(512), lds, st, a);
+    LDN_CHECK_LAUNCH("k_dense");
+    return LDN_OK;
+}
+
+}  // namespace ldn
+
+using namespace ldn;
+
+extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
+                                   const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
+                                   const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
+                                   float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
+                                   int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
+                                   void* stream) {
+    LDN_REQUIRE(a && w_split && shift && out, "ldn_conv_rows_split: null pointer");
+    LDN_REQUIRE(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0, "ldn_conv_rows_split: cin and cout must be multiples of 32 (got %d, %d)", cin, cout);
+    LDN_REQUIRE(lda % 4 == 0 && lda >= cin && ldo % 4 == 0 && ldo >= cout && (!residual || (ldr % 4 == 0 && ldr >= cout)),
+                "ldn_conv_rows_split: strides must be multiples of 4 and cover the row");
+    LDN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || relu_if_neg), "ldn_conv_rows_split: bad relu mode");
+    LDN_REQUIRE((uintptr_t)a % 16 == 0 && (uintptr_t)w_split % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 &&
+                (uintptr_t)shift % 16 == 0 && (uintptr_t)scale % 16 == 0, "ldn_conv_rows_split: pointers must be 16-byte aligned");
+    LDN_REQUIRE(taps == 1 || (taps == 9 && a_rows), "ldn_conv_rows_split: taps must be 1, or 9 with a neighbour table");
+    LDN_REQUIRE(shift_classes == 1 || (shift_classes == 16 && pix_map && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0 && stride >= 1),
+                "ldn_conv_rows_split: shift_classes 16 needs pix_map and the layer geometry");
+    LDN_REQUIRE(!chan_mask || rows_per_image > 0, "ldn_conv_rows_split: chan_mask needs rows_per_image");
+    LDN_REQUIRE((uintptr_t)post_sub % 16 == 0 && (uintptr_t)chan_mask % 16 == 0, "ldn_conv_rows_split: post_sub / chan_mask must be 16-byte aligned");
+    if (m_cap <= 0) return LDN_OK;
+    DenseArgs d{a, lda, a_rows, m_count, m_cap, static_cast<const unsigned char*>(w_split), cin, cout, scale, shift, relu,
+                relu_if_neg, out_rows, residual, ldr, out, ldo, taps, shift_classes, pix_map, Hi, Wi, Ho > 0 ? Ho : 1, Wo > 0 ? Wo : 1,
+                stride, post_sub, chan_mask, rows_per_image > 0 ? rows_per_image : 1, 0, 0};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // columns per workgroup: as wide as the layer allows (fewer passes over the activation rows) while the grid still fills the chip
+    const int mt = ceil_div(m_cap, D_ROWS);
+    if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8>(d, st);
+    if (cout % 128 == 0) return launch_dense<4>(d, st);
+    if (cout % 64 == 0 && cout < 128) return launch_dense<2>(d, st);
+    return launch_dense<4>(d, st);
+}

@@ -411,13 +411,23 @@ class Bottleneck(_PrepCache):
                               ).reshape(-1, 1, W).contiguous().to(dev)
         ix = self._dense_ix(B, Ho, Wo, dev)
         x2d = xn.reshape(B * Hi * Wi, Cin)
+        fused_mask = ops.get_math_mode() == "bf16x3" and Cin % 32 == 0 and W % 32 == 0 and ops.USE_DENSE_KERNEL
+        chm2d = chm.reshape(B, W).contiguous()
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
-        ops.conv_packed(x2d, p["w1"], p["s1"], p["t1"], h1, taps=1, m_cap=ix.cap1, post_sub=p["c1"], relu=1)
-        h1.view(B, -1, W).mul_(chm)
+        if fused_mask:   # k_dense: the per-image channel mask and the post-ReLU constant are epilogue terms (no pass over h1)
+            ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, taps=1, m_cap=ix.cap1, relu=1, post_sub=p["c1"], chan_mask=chm2d,
+                          rows_per_image=Hi * Wi)
+        else:
+            ops.conv_packed(x2d, p["w1"], p["s1"], p["t1"], h1, taps=1, m_cap=ix.cap1, post_sub=p["c1"], relu=1)
+            h1.view(B, -1, W).mul_(chm)
         h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
-        ops.conv_packed(h1, p["w2_nk"], p["s2"], p["t2_tab"], h2, a_map=ix.nbr, taps=9, m_cap=ix.cap3, pix_map=ix.idx3,
-                        geom=(Hi, Wi, Ho, Wo, self.stride), post_sub=p["c2"], relu=1)
-        h2.view(B, -1, W).mul_(chm)
+        if fused_mask and 9 in ops.DENSE_TAPS:
+            ops.conv_rows(h1, p["w2_nk"], p["s2"], p["t2_tab"], h2, a_rows=ix.nbr, taps=9, m_cap=ix.cap3, pix_map=ix.idx3,
+                          geom=(Hi, Wi, Ho, Wo, self.stride), post_sub=p["c2"], relu=1, chan_mask=chm2d, rows_per_image=Ho * Wo)
+        else:
+            ops.conv_packed(h1, p["w2_nk"], p["s2"], p["t2_tab"], h2, a_map=ix.nbr, taps=9, m_cap=ix.cap3, pix_map=ix.idx3,
+                            geom=(Hi, Wi, Ho, Wo, self.stride), post_sub=p["c2"], relu=1)
+            h2.view(B, -1, W).mul_(chm)
         cout = p["w3_nk"].shape[0]
         if self.downsample is not None:
             identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
@@ -426,8 +436,8 @@ class Bottleneck(_PrepCache):
         else:
             identity = xn
             out = xn if self._inplace else torch.empty_like(xn)
-        ops.conv_packed(h2, p["w3_nk"], None, p["t3c"], out.view(B * Ho * Wo, cout), taps=1, m_cap=ix.cap3, relu=1,
-                        residual2d=identity.view(B * Ho * Wo, cout))
+        ops.conv_rows(h2, p["w3_nk"], None, p["t3c"], out.view(B * Ho * Wo, cout), taps=1, m_cap=ix.cap3, relu=1,
+                      residual2d=identity.view(B * Ho * Wo, cout))
         self.last_channel_mask = mask
         self.last_gap = None
         self.last_channel_cnt = cnt
@@ -461,9 +471,10 @@ class Bottleneck(_PrepCache):
         spans the batch (M tiles then hold rows of several images) instead of per-image tiles that would be mostly empty."""
         B, Hi, Wi, Cin = xn.shape
         _, Ho, Wo, cout = identity.shape
-        if Ho * Wo < 96:
-            ops.conv_packed(xn.reshape(B * Hi * Wi, Cin), p["wd"], p["sd"], p["td"], identity.view(B * Ho * Wo, cout), taps=1,
-                            m_cap=B * Ho * Wo, a_map=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], xn.device), relu=0)
+        if Ho * Wo < 96 or (ops.get_math_mode() == "bf16x3" and ops.USE_DENSE_KERNEL and Cin % 32 == 0 and cout % 32 == 0):
+            # one list of strided pixel rows over the batch (k_dense in bf16x3 mode: pre-split shared weights, 256-row tiles)
+            ops.conv_rows(xn.reshape(B * Hi * Wi, Cin), p["wd"], p["sd"], p["td"], identity.view(B * Ho * Wo, cout), taps=1,
+                          m_cap=B * Ho * Wo, a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], xn.device), relu=0)
         else:
             ops.conv_image(xn, p["wd"], p["sd"], p["td"], identity, stride=p["ds_stride"], relu=0)
 

@@ -162,9 +162,30 @@ def scatter_add_relu(packed, rows, identity2d, out2d=None, count=None, cap=None)
 
 
 # ---------------------------------------------------------------------------------------- a7 rows
+_SPLIT_CACHE = {}   # (data_ptr, _version, shape) of an fp32 weight -> its pre-split n-major copy (ldn_conv_rows_split)
+DENSE_TAPS = (1,)
+USE_DENSE_KERNEL = True   # tuning switch: False keeps every packed-row 1x1 on the round-1 kernels
+
+
+def split_rows_weight(w):
+    """[cout, 1, cin] (or [cout, cin]) fp32 -> [cout][cin/8][8 hi | 8 lo] bf16, cached until the tensor changes."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device))
+    hit = _SPLIT_CACHE.get(key)
+    if hit is None:
+        if len(_SPLIT_CACHE) > 4096:
+            _SPLIT_CACHE.clear()
+        with torch.no_grad():
+            w2 = w.detach().float().reshape(w.shape[0], -1)
+            hit = _SPLIT_CACHE[key] = (pack_w1_split(w2), w)     # the source tensor is kept alive: its data_ptr stays unique
+    return hit[0]
+
+
 def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None, m_cap=None, relu=1,
-              relu_if_neg=None, out_rows=None, residual2d=None, math=None):
-    """Packed-row convolution (see ldn_conv_rows).  a2d [rows,lda>=cin]; w [cout,taps,cin]; out2d [rows,ldo]."""
+              relu_if_neg=None, out_rows=None, residual2d=None, math=None, post_sub=None, chan_mask=None, rows_per_image=0,
+              pix_map=None, geom=None):
+    """Packed-row convolution (see ldn_conv_rows).  a2d [rows,lda>=cin]; w [cout,taps,cin]; out2d [rows,ldo].
+    In bf16x3 mode the 1x1 form runs on k_dense (ldn_conv_rows_split) with a cached pre-split copy of the weights;
+    post_sub / chan_mask (dense execution of channel mode) exist on that kernel only."""
     L.require_device(a2d, w, out2d)
     lib = L.load()
     cout, t, cin = w.shape
@@ -172,6 +193,25 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
         raise L.LdnError(f"conv_rows: weight has {t} taps, expected {taps}")
     if m_cap is None:
         m_cap = a2d.shape[0] if a_rows is None else a_rows.numel() // taps
+    mode = math if math is not None else get_math_mode()
+    # k_dense also implements the 3x3 over a neighbour table (taps == 9), but re-staging the activation rows once per tap through
+    # the owning wave's split makes it SLOWER than round 1's producer/consumer kernel there (measured: spatial 17.8 -> 19.1 ms,
+    # headline 15.4 -> 15.6 ms): only the 1x1 form is dispatched to it (DENSE_TAPS = (1, 9) re-enables the 3x3 for experiments).
+    dense_ok = (USE_DENSE_KERNEL and mode == "bf16x3" and taps in DENSE_TAPS and cin % 32 == 0 and cout % 32 == 0 and a2d.stride(0) >= cin)
+    classes = 1 if shift.dim() == 1 else shift.shape[0]
+    if (post_sub is not None or chan_mask is not None or classes != 1) and not dense_ok:
+        raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table need the bf16x3 path (cin, cout multiples of 32)")
+    if dense_ok:
+        hi, wi, ho, wo, stride = geom if geom is not None else (0, 0, 0, 0, 1)
+        L.check(lib.ldn_conv_rows_split(L.ptr(_f32rows(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")), taps,
+                                        L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(split_rows_weight(w)), cin, cout,
+                                        L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,
+                                        L.ptr(_i32c(relu_if_neg, "relu_if_neg")), L.ptr(_i32c(out_rows, "out_rows")),
+                                        L.ptr(_f32rows(residual2d, "residual")), residual2d.stride(0) if residual2d is not None else 0,
+                                        L.ptr(_f32rows(out2d, "out")), out2d.stride(0), L.ptr(_f32c(post_sub, "post_sub")),
+                                        L.ptr(_f32c(chan_mask, "chan_mask")), rows_per_image, classes, L.ptr(_i32c(pix_map, "pix_map")),
+                                        hi, wi, ho, wo, stride, L.stream_ptr(out2d)), "ldn_conv_rows_split")
+        return out2d
     L.check(lib.ldn_conv_rows(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")), taps,
                               L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(_f32c(w, "w")), cin, cout,
                               L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,

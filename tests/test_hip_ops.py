@@ -392,3 +392,28 @@ def test_expand_mask_module_vs_reference_fixtures(ops):
             continue    # pure zero-insertion: never instantiated by a block (expander2 is (1,0), expander1 is (stride,1))
         got = ExpandMask(stride=case["stride"], padding=case["padding"], mask_channel_group=m.shape[1])(m.to(DEV))
         assert torch.equal(got.cpu(), case["y"].bool()), (case["stride"], case["padding"], tuple(m.shape))
+
+
+@pytest.mark.parametrize("B,H,C,cout,stride", [(2, 14, 32, 64, 1), (3, 14, 64, 64, 2)])
+def test_dense_kernel_3x3_neighbour_table(ops, B, H, C, cout, stride, math_mode):
+    """k_dense's 3x3 form (ldn_conv_rows_split, taps == 9) is not dispatched by default (slower than the round-1 kernel) but is
+    part of the ABI: same result as the default path on the spatial-mode slice mask -> index -> 3x3 through the neighbour table."""
+    if math_mode != "bf16x3":
+        pytest.skip("k_dense is the bf16x3 kernel")
+    Ho = H // stride if stride > 1 else H
+    patch = seeded_bernoulli((B, Ho, Ho), 0.5, 11)
+    ix = ops.mask_to_index(patch.to(DEV), Ho, Ho, stride)
+    h1 = seeded_randn((ix.cap1, C), 12).to(DEV)
+    w = (seeded_randn((cout, 9, C), 13) * (2.0 / (9 * C)) ** 0.5).to(DEV)
+    sc, sh = _affine(cout, 14)
+    outs = []
+    for taps_set in ((1,), (1, 9)):
+        ops.DENSE_TAPS = taps_set
+        try:
+            out = torch.zeros(ix.cap3, cout, device=DEV)
+            ops.conv_rows(h1, w, sc.to(DEV), sh.to(DEV), out, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1)
+            outs.append(out.cpu())
+        finally:
+            ops.DENSE_TAPS = (1,)
+    n = int(ix.cnt[0])
+    assert torch.allclose(outs[0][:n], outs[1][:n], atol=1e-4, rtol=1e-4)

@@ -60,7 +60,7 @@ constexpr int D_ROWS = 256;
 constexpr int D_ROW_RELU = 1 << 30;
 
 // NSUB = n-subtiles of 32 columns per workgroup (2, 4, 8); D = ring depth (2 for NSUB 8, 3 otherwise)
-template <int NSUB>
+template <int NSUB, bool T9>   // T9: 3x3 over a neighbour table (compiled apart: the 1x1 form carries none of its tables or branches)
 __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     constexpr int NT = NSUB * 32;
     constexpr int D = NSUB == 8 ? 2 : 3;
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* const s_arow = reinterpret_cast<int*>(smem);            // [256] source row or -1
     int* const s_orow = s_arow + D_ROWS;                         // [256] destination row | D_ROW_RELU, or -1
-    int* const s_cls = s_orow + D_ROWS;                          // [256] border class * cout (16-class shift table) or 0
-    int* const s_atap = s_cls + D_ROWS;                          // [256][9] source rows per tap (taps == 9)
-    unsigned char* const s_ring = smem + (3 + 9) * D_ROWS * 4;
+    int* const s_cls = s_orow + D_ROWS;                          // [256] border class * cout (16-class shift table) (T9 only)
+    int* const s_atap = s_cls + D_ROWS;                          // [256][9] source rows per tap (T9 only)
+    unsigned char* const s_ring = smem + (T9 ? 12 : 2) * D_ROWS * 4;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,12 +91,12 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     if (tid < D_ROWS) {
         int ar = -1, orw = -1;
         if (tid < rows) {
-            ar = (p.a_rows && p.taps == 1) ? p.a_rows[m0 + tid] : m0 + tid;
+            ar = (p.a_rows && !T9) ? p.a_rows[m0 + tid] : m0 + tid;
             orw = p.out_rows ? p.out_rows[m0 + tid] : m0 + tid;
             if (p.relu == 1 || (p.relu == 2 && p.relu_if_neg[m0 + tid] < 0)) orw |= D_ROW_RELU;
         }
         int cls = 0;
-        if (tid < rows && p.shift_classes > 1) {
+        if (T9 && tid < rows && p.shift_classes > 1) {
             const int q = p.pix_map[m0 + tid] % (p.Ho * p.Wo);
             const int oy = q / p.Wo, ox = q - oy * p.Wo;
             const int top = oy * p.stride - 1 < 0, bot = oy * p.stride + 1 >= p.Hi;
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         LDN_DCHECK(tid >= rows || (ar >= -1 && (orw & (D_ROW_RELU - 1)) >= 0), 501);
         s_arow[tid] = ar;
         s_orow[tid] = orw;
-        s_cls[tid] = cls;
+        if (T9) s_cls[tid] = cls;
     }
-    if (p.taps == 9)
+    if (T9)
         for (int i = tid; i < D_ROWS * 9; i += 512) {
             const int r = i / 9;
             s_atap[i] = r < rows ? p.a_rows[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
 
     const bool active = wave * 32 < rows;
     const int cpt = p.cin / 32;                                  // chunks per tap
-    const int nchunks = p.taps * cpt;
+    const int nchunks = (T9 ? 9 : 1) * cpt;
     const unsigned lds_ring = d_lds_off(s_ring);
     const int per_chunk = (active ? 4 : 0) + NWI;
     long asrc[4];                                                // this lane's four source rows (element offsets), -1 = zero row
@@ -128,14 +128,14 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     }
     auto dma_chunk = [&](int c) {
         const unsigned slot = lds_ring + (c % D) * SLOT;
-        const int tap = c / cpt, ck = c - tap * cpt;             // K position = tap * cin + 32 ck
+        const int tap = T9 ? c / cpt : 0, ck = c - tap * cpt;    // K position = tap * cin + 32 ck
         if (active) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = wave * 32 + i * 8 + (lane >> 3);
                 const int ls = (lane & 7) ^ ((r >> 1) & 7);
                 long off = asrc[i];
-                if (p.taps == 9) {
+                if (T9) {
                     const int ar = s_atap[r * 9 + tap];
                     off = ar >= 0 ? (long)ar * p.lda : -1;
                 }
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
             const int r = i * 64 + wave * 8 + (lane >> 3);
             const int ls = (lane & 7) ^ ((r >> 1) & 7);
             const int n = n0 + r;
-            const unsigned char* src = (r < NT && n < p.cout) ? p.ws + ((long)n * (p.taps * p.cin / 8) + c * 4) * 32 + ls * 16
+            const unsigned char* src = (r < NT && n < p.cout) ? p.ws + ((long)n * ((T9 ? 9 : 1) * p.cin / 8) + c * 4) * 32 + ls * 16
                                                                : reinterpret_cast<const unsigned char*>(g_dense_zero);
             d_dma16(src, slot + (D_ROWS + (r < NT ? i * 64 + wave * 8 : 0)) * 128);
         }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         for (int it = 0; it < 4; ++it) {
             const int row = trw + 8 * it;
             f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
-            const f32x4 shr = p.shift_classes > 1 ? *reinterpret_cast<const f32x4*>(p.shift + s_cls[wave * 32 + row] + n0 + 32 * j + tc * 4) : sh;
+            const f32x4 shr = (T9 && p.shift_classes > 1) ? *reinterpret_cast<const f32x4*>(p.shift + s_cls[wave * 32 + row] + n0 + 32 * j + tc * 4) : sh;
             x = x * sc + shr + res[it];
             if (orw[it] & D_ROW_RELU) {
 #pragma unroll
@@ -264,16 +264,16 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_dense)
 
-template <int NSUB>
+template <int NSUB, bool T9>
 static int launch_dense(DenseArgs& a, hipStream_t st) {
     constexpr int NT = NSUB * 32;
     constexpr int D = NSUB == 8 ? 2 : 3;
-    const size_t lds = (size_t)(3 + 9) * D_ROWS * 4 + (size_t)D * (D_ROWS + NT) * 128;
+    const size_t lds = (size_t)(T9 ? 12 : 2) * D_ROWS * 4 + (size_t)D * (D_ROWS + NT) * 128;
     a.ntn = ceil_div(a.cout, NT);
     a.mtn = ceil_div(a.m_cap, D_ROWS);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB, T9>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
     const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
-    hipLaunchKernelGGL((k_dense<NSUB>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_dense<NSUB, T9>), dim3(grid), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_dense");
     return LDN_OK;
 }
@@ -296,7 +296,7 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
     LDN_REQUIRE((uintptr_t)a % 16 == 0 && (uintptr_t)w_split % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 &&
                 (uintptr_t)shift % 16 == 0 && (uintptr_t)scale % 16 == 0, "ldn_conv_rows_split: pointers must be 16-byte aligned");
     LDN_REQUIRE(taps == 1 || (taps == 9 && a_rows), "ldn_conv_rows_split: taps must be 1, or 9 with a neighbour table");
-    LDN_REQUIRE(shift_classes == 1 || (shift_classes == 16 && pix_map && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0 && stride >= 1),
+    LDN_REQUIRE(shift_classes == 1 || (shift_classes == 16 && taps == 9 && pix_map && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0 && stride >= 1),
                 "ldn_conv_rows_split: shift_classes 16 needs pix_map and the layer geometry");
     LDN_REQUIRE(!chan_mask || rows_per_image > 0, "ldn_conv_rows_split: chan_mask needs rows_per_image");
     LDN_REQUIRE((uintptr_t)post_sub % 16 == 0 && (uintptr_t)chan_mask % 16 == 0, "ldn_conv_rows_split: post_sub / chan_mask must be 16-byte aligned");
@@ -307,8 +307,9 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
     hipStream_t st = static_cast<hipStream_t>(stream);
     // columns per workgroup: as wide as the layer allows (fewer passes over the activation rows) while the grid still fills the chip
     const int mt = ceil_div(m_cap, D_ROWS);
-    if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8>(d, st);
-    if (cout % 128 == 0) return launch_dense<4>(d, st);
-    if (cout % 64 == 0 && cout < 128) return launch_dense<2>(d, st);
-    return launch_dense<4>(d, st);
+    if (taps == 9) return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true>(d, st) : launch_dense<2, true>(d, st);
+    if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8, false>(d, st);
+    if (cout % 128 == 0) return launch_dense<4, false>(d, st);
+    if (cout % 64 == 0 && cout < 128) return launch_dense<2, false>(d, st);
+    return launch_dense<4, false>(d, st);
 }

@@ -2,6 +2,7 @@
 memory and the current stream; every computation below runs in libldn_hip.so.  No fallbacks."""
 from __future__ import annotations
 
+import os
 import threading
 from dataclasses import dataclass
 
@@ -164,7 +165,7 @@ def scatter_add_relu(packed, rows, identity2d, out2d=None, count=None, cap=None)
 # ---------------------------------------------------------------------------------------- a7 rows
 _SPLIT_CACHE = {}   # (data_ptr, _version, shape) of an fp32 weight -> its pre-split n-major copy (ldn_conv_rows_split)
 DENSE_TAPS = (1,)
-USE_DENSE_KERNEL = True   # tuning switch: False keeps every packed-row 1x1 on the round-1 kernels
+USE_DENSE_KERNEL = os.environ.get("LDN_DENSE_KERNEL", "1") != "0"   # tuning switch: off keeps every packed-row 1x1 on the round-1 kernels
 
 
 def split_rows_weight(w):

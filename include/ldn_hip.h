@@ -197,6 +197,30 @@ int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int
                         const float* shift2_tab, const float* post_sub2, const float* shift3, const float* residual,
                         int ldr, float* out, int ldo, float* colsum, void* stream);
 
+/* ---- a2 + a7 (channel mode, bf16x3): a RUN of consecutive stride-1 channel-mode bottlenecks on maps of at most 256 pixels
+ * (stage 3 of the ResNets: 14x14) as ONE launch -- per block: ldn_channel_masker on the GAP of the block's input, then
+ * ldn_bottleneck_head, then ldn_bottleneck_tail (laud_resnet.py:104-147, block after block; models/utils.py:92-131).
+ * Workgroup b walks image b through the whole run; images never synchronise with each other, so a launch no longer lasts as
+ * long as its heaviest image per phase.  Results are bit-identical to the three stand-alone entry points.
+ *   blocks [nblocks]  DEVICE array of per-block constants (layouts as in ldn_bottleneck_head / _tail / ldn_channel_masker;
+ *                     mw2 / mb2 NULL and hidden == 0 for a one-layer masker); every block has the same shapes
+ *   x_in   [B*H*Wd][ldx]  input of the first block (C channels; also its residual); x_work: the residual stream the run
+ *                     updates (may alias x_in: in place); holds the run's output afterwards
+ *   gap_in [B][gap_splits][C]  partial channel sums of x_in (ldn_bottleneck_tail colsum / ldn_conv_image colsum / any producer)
+ *   colsum [B][8][C]      GAP partials of the run's output (and scratch between blocks)
+ *   masks [nblocks][B][G], ch_idx [nblocks][B][width], ch_cnt [nblocks][B]: the maskers' decisions and channel lists, per block
+ *   h1_split [B*H*Wd][ldh] scratch (conv1's pre-split output). */
+typedef struct ldn_chain_block {
+    const void* w1_split; const float* scale1; const float* shift1; const float* post_sub1;
+    const void* w2_pairs; const void* w3_pairs; const float* scale2; const float* shift2_tab; const float* post_sub2;
+    const float* shift3;
+    const float* mw1; const float* mb1; const float* mw2; const float* mb2;
+} ldn_chain_block;
+int ldn_bottleneck_chain(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
+                         const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran, const float* gap_in,
+                         int gap_splits, float* colsum, float* masks, int32_t* ch_idx, int32_t* ch_cnt, void* h1_split,
+                         int ldh, void* stream);
+
 /* ---- a7 (spatial / layer / both): the same kernel over PACKED PIXEL LISTS ---------------------
  * Image b owns the packed rows [row_prefix[b], row_prefix[b+1]) (B == 1, row_prefix == NULL: rows [0, *m_count),
  * m_count == NULL -> m_cap).  For packed row R:

@@ -1,0 +1,159 @@
+// Device-side pieces shared by the mask / index kernels (csrc/ldn_index.hip) and the chained stage kernel (csrc/ldn_tail.hip).
+#pragma once
+#include "ldn_common.h"
+
+namespace ldn {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// rank of this lane among the set lanes of `flag` in its wave, and the wave total
+__device__ __forceinline__ int wave_rank(bool flag, int& total) {
+    const unsigned long long m = __ballot(flag);
+    total = __popcll(m);
+    const int lane = threadIdx.x & 63;
+    return __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// block_rank for a block of NW waves
+template <int NW>
+__device__ __forceinline__ int block_rank_n(bool flag, int* s_w, int& chunk_total) {
+    int wtot;
+    const int r = wave_rank(flag, wtot);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();  // protect s_w from the previous call
+    if ((threadIdx.x & 63) == 0) s_w[wave] = wtot;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int v = s_w[i];
+        before += i < wave ? v : 0;
+        total += v;
+    }
+    chunk_total = total;
+    return before + r;
+}
+
+// Channel masker of ONE image b (models/utils.py:92-131 in eval mode): GAP from split partials -> MLP -> keep iff
+// logit_keep >= logit_drop -> ordered list of the active channels.  Called by k_channel_mlp (one workgroup per image) and by
+// k_chain (csrc/ldn_tail.hip).  Per output the summation order does not depend on NT: decisions are identical for any NT.
+// s_f: C + max(hidden, 1) + 2 G floats of LDS; s_w: NT / 64 ints.
+template <int NT>
+__device__ __forceinline__ void channel_mlp_body(const int b, const float* __restrict__ partial, int HW, int C, int splits,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      int hidden, int G, int gran, const float* __restrict__ mask_in,
+                                                      float* __restrict__ mask, float* __restrict__ logits,
+                                                      int32_t* __restrict__ ch_idx, int32_t* __restrict__ ch_cnt,
+                                                      float* s_f, int* s_w) {
+    float* s_gap = s_f;                 // [C]
+    float* s_hid = s_gap + C;           // [max(hidden,1)]
+    float* s_log = s_hid + (hidden > 0 ? hidden : 1);  // [2G]
+    constexpr int NW = NT / 64;          // waves per block (one block per image)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G2 = 2 * G;
+    if (!mask_in) {
+        const float inv = 1.f / (float)HW;
+        for (int c = tid; c < C; c += NT) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
+            s_gap[c] = s * inv;
+        }
+        __syncthreads();
+        const int n1 = hidden > 0 ? hidden : G2;     // outputs of the first (or only) layer
+        float* dst1 = hidden > 0 ? s_hid : s_log;
+        // each wave owns outputs wave, wave + NW, ...; eight of them per pass so that their weight loads are in flight
+        // together and their cross-lane reductions interleave (per output the summation order is unchanged)
+        constexpr int OB = 8;
+        for (int o0 = wave; o0 < n1; o0 += NW * OB) {
+            float acc[OB];
+#pragma unroll
+            for (int k = 0; k < OB; ++k) acc[k] = 0.f;
+            if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(w1) & 15) == 0) {
+                // 16 bytes per lane: a wave instruction covers 256 consecutive weights of a row (1 KiB instead of 256 B)
+                for (int c = lane * 4; c < C; c += 256) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(s_gap + c);
+#pragma unroll
+                    for (int k = 0; k < OB; ++k) {
+                        const int o = o0 + NW * k;
+                        if (o < n1) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(w1 + (size_t)o * C + c);
+                            acc[k] += wv[0] * g[0] + wv[1] * g[1] + wv[2] * g[2] + wv[3] * g[3];
+                        }
+                    }
+                }
+            } else {
+                for (int c = lane; c < C; c += 64) {
+                    const float g = s_gap[c];
+#pragma unroll
+                    for (int k = 0; k < OB; ++k) {
+                        const int o = o0 + NW * k;
+                        if (o < n1) acc[k] += w1[(size_t)o * C + c] * g;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < OB; ++k) acc[k] = wave_sum(acc[k]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < OB; ++k) {
+                    const int o = o0 + NW * k;
+                    if (o < n1) {
+                        const float a = acc[k] + b1[o];
+                        dst1[o] = hidden > 0 ? fmaxf(a, 0.f) : a;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (hidden > 0) {
+            // one thread per output; its weight row is read as 16-byte vectors (consecutive instructions of a lane stay
+            // inside the same cache lines), s_hid reads are LDS broadcasts
+            for (int o = tid; o < G2; o += NT) {
+                float a = b2[o];
+                const float* wr = w2 + (size_t)o * hidden;
+                if ((hidden & 3) == 0 && (reinterpret_cast<uintptr_t>(wr) & 15) == 0) {
+                    for (int j = 0; j < hidden; j += 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(wr + j);
+                        a += v[0] * s_hid[j];
+                        a += v[1] * s_hid[j + 1];
+                        a += v[2] * s_hid[j + 2];
+                        a += v[3] * s_hid[j + 3];
+                    }
+                } else {
+                    for (int j = 0; j < hidden; ++j) a += wr[j] * s_hid[j];
+                }
+                s_log[o] = a;
+            }
+            __syncthreads();
+        }
+        for (int j = tid; j < G; j += NT) mask[(size_t)b * G + j] = s_log[j] >= s_log[G + j] ? 1.f : 0.f;
+        if (logits)
+            for (int o = tid; o < G2; o += NT) logits[(size_t)b * G2 + o] = s_log[o];
+    } else {
+        for (int j = tid; j < G; j += NT) mask[(size_t)b * G + j] = mask_in[(size_t)b * G + j];
+    }
+    __syncthreads();
+    // ordered compaction of the active channels (group j owns [j*gran, (j+1)*gran))
+    const int width = G * gran;
+    int running = 0;
+    for (int c0 = 0; c0 < width; c0 += NT) {
+        const int c = c0 + tid;
+        bool f = false;
+        if (c < width) {
+            const int j = c / gran;
+            f = mask_in ? mask_in[(size_t)b * G + j] > 0.5f : s_log[j] >= s_log[G + j];
+        }
+        int tot;
+        const int r = block_rank_n<NW>(f, s_w, tot);
+        if (f) ch_idx[(size_t)b * width + running + r] = c;
+        running += tot;
+    }
+    if (tid == 0) ch_cnt[b] = running;
+}
+
+}  // namespace ldn

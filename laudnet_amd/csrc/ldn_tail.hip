@@ -20,6 +20,7 @@
 // issues its share of the LDS-DMA (inline asm, counted s_waitcnt vmcnt(N): the DMA of chunk c+2 and of the next h1 slice fly
 // across the barriers of chunks c and c+1).
 #include "ldn_common.h"
+#include "ldn_mlp.h"
 
 namespace ldn {
 
@@ -88,7 +89,7 @@ constexpr int T_W2_SLOTS = 3;
 
 // NS = W / 32 (maximum n-subtiles / K slices of an image): 2, 4 or 8
 template <int NS>
-__global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_tail(const TailArgs p) {
+__device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const int mb, unsigned char* const smem, const int tid) {
     constexpr int W = NS * 32;
     // NS == 2 (stage 1: 14 short blocks per image, all of them bound by the CU's memory pipe in their conv3 phase and idle on it in
     // their conv2 phase): ONE h1 slice slot and 128 registers, so that TWO workgroups fit a CU and overlap each other's phases.
@@ -101,7 +102,6 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_tail(const TailArgs 
     constexpr int RPI = 1024 / W3_ROW;                // rows per DMA instruction
     constexpr int W3_SLOT = (W / 2) * W3_ROW;
     constexpr int NP = W;                             // table width
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* const s_kidx = reinterpret_cast<int*>(smem);
     unsigned char* const s_h1 = smem + T_KIDX_BYTES;                      // 2 slice slots (conv2 phase)
     unsigned char* const s_w2 = s_h1 + SLICE_BUFS * p.slice_bytes;        // 3 W2 slots   (conv2 phase)
@@ -109,15 +109,13 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_tail(const TailArgs 
     float* const s_tab = reinterpret_cast<float*>(s_w3 + 2 * W3_SLOT);    // sc2[NP], ps2[NP], sh2[16][NP] (conversion)
     unsigned char* const s_scr = reinterpret_cast<unsigned char*>(s_tab + 18 * NP);   // 8 x 4 KiB transpose scratch
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
 #ifdef LDN_TRACE
     unsigned long long tr0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, ta = 0, tb = 0, w2wait = 0, w3wait = 0, w3bar = 0, w3epi = 0, w3k = 0;
     TT(tr0)
 #endif
-    const int b = blockIdx.x % p.B, mb = blockIdx.x / p.B;     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
-
     // ---- geometry of this workgroup's block of output rows and of its halo'd input region (stride 1, pad 1)
     const int y0 = mb * p.rows_per_blk;
     const int rows = min(p.rows_per_blk, p.Ho - y0);
@@ -484,11 +482,17 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_tail(const TailArgs 
 #ifdef LDN_TRACE
     TT(tr4)
     if (g_tail_trace && lane == 0) {
-        unsigned long long* r = g_tail_trace + ((size_t)blockIdx.x * 8 + wave) * 12;
+        unsigned long long* r = g_tail_trace + (((size_t)mb * p.B + b) * 8 + wave) * 12;
         r[0] = tr0; r[1] = tr1; r[2] = tr2; r[3] = tr3; r[4] = tr4; r[5] = w2wait; r[6] = w3k; r[7] = w3wait; r[8] = w3epi; r[9] = w3bar;
         r[10] = nsub; r[11] = 0;
     }
 #endif
+}
+
+template <int NS>
+__global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_tail(const TailArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tail_body<NS>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, threadIdx.x);     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
 }
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_tail)
@@ -612,17 +616,15 @@ __device__ __forceinline__ void wait_vm_rt(int n) {   // counted wait with a run
 constexpr int H_XROWS = 256;                          // rows of the x tile of a ring slot (pixels of the block, padded)
 
 template <int NS>
-__global__ __launch_bounds__(512, 2) void k_head(const HeadArgs p) {
+__device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const int mb, unsigned char* const smem, const int lds_total, const int tid) {
     constexpr int W = NS * 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* const s_nidx = reinterpret_cast<int*>(smem);                    // [W + 32]
     float* const s_tab = reinterpret_cast<float*>(smem + T_KIDX_BYTES);  // sc1 | sh1 | ps1 of the packed columns, 3 x W
     unsigned char* const s_ring = smem + T_KIDX_BYTES + 3 * W * 4;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int b = blockIdx.x % p.B, mb = blockIdx.x / p.B;
     const int m0 = mb * p.pix_per_blk;
     const int npix = min(p.pix_per_blk, p.HW - m0);
     const long row0 = (long)b * p.HW + m0;
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void k_head(const HeadArgs p) {
     // ring geometry: slot = [256 x rows | wrows weight rows] x 128 B; as many slots as fit (2..4)
     const int xrows = round_up(npix, 32);                                // x rows staged per chunk: whole 32-pixel subtiles of busy waves
     const int slot_bytes = (xrows + wrows) * 128;
-    const int avail = 160 * 1024 - (T_KIDX_BYTES + 3 * W * 4);
+    const int avail = lds_total - (T_KIDX_BYTES + 3 * W * 4);
     const int D = min(4, avail / slot_bytes);                            // >= 2 for W <= 256
     const int nchunks = p.cin / 32;
     const unsigned lds_ring = lds_off(s_ring);
@@ -760,6 +762,12 @@ __global__ __launch_bounds__(512, 2) void k_head(const HeadArgs p) {
 }
 
 template <int NS>
+__global__ __launch_bounds__(512, 2) void k_head(const HeadArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    head_body<NS>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, 160 * 1024, threadIdx.x);
+}
+
+template <int NS>
 static int launch_head(HeadArgs& a, hipStream_t st) {
     const size_t lds = 160 * 1024;
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_head<NS>), lds), "k_head: cannot reserve %zu B of LDS", lds);
@@ -790,4 +798,148 @@ extern "C" int ldn_bottleneck_head(const float* x, int ldx, int B, int HW, int c
     if (width == 64) return launch_head<2>(a, st);
     if (width == 128) return launch_head<4>(a, st);
     return launch_head<8>(a, st);
+}
+
+namespace ldn {
+
+// ================================================================================================================ k_chain
+// A RUN of consecutive stride-1 channel-mode bottlenecks whose map fits one workgroup (H * W <= 256: stage 3 of the ResNets)
+// as ONE launch: workgroup b walks image b through   masker (GAP partials -> MLP -> channel list)  ->  conv1 (head_body)  ->
+// conv2 + conv3 (tail_body)   of every block of the run (laud_resnet.py:104-147 block after block).  Eval-mode images are
+// independent, so nothing synchronises across images: with one launch per phase every launch lasts as long as its heaviest
+// image (conv2 work grows with the square of the image's active channels: measured max / mean = 1.32 at stage 3); chained,
+// an image's cost is its own sum over the run, the light and heavy blocks of an image average out, and the workgroups drift apart so
+// that some are in their MFMA-bound conv2 phase while others are in their memory-bound conv3 phase.
+// Same device code as the three stand-alone kernels (channel_mlp_body / head_body / tail_body): results are bit-identical.
+// Between phases the workgroup's own global writes (channel list, h1, the residual stream, GAP partials) are made visible to
+// its own later reads: workgroup-scope release fence + barrier + acquire fence, and a scalar-cache invalidate.
+struct ChainBlock {   // per-block constants; every field is 8 bytes (= ldn_chain_block of include/ldn_hip.h)
+    const unsigned char* w1s; const float* sc1; const float* sh1; const float* ps1;
+    const unsigned char* w2p; const unsigned char* w3p; const float* sc2; const float* sh2; const float* ps2; const float* sh3;
+    const float* mw1; const float* mb1; const float* mw2; const float* mb2;
+};
+static_assert(sizeof(ChainBlock) == 14 * 8, "ChainBlock must mirror ldn_chain_block");
+
+struct ChainArgs {
+    const ChainBlock* blocks; int nblocks;
+    const float* x_in; float* x_work; int ldx;        // block 0 reads x_in (input and residual), every block writes x_work
+    int B, H, Wd, C;
+    int hidden, G, gran;
+    const float* gap_in; int gap_splits;              // GAP partials of x_in [B][gap_splits][C]
+    float* colsum;                                    // [B][8][C]: GAP partials of the latest block's output (the run's GAP output)
+    float* masks; int32_t* ch_idx; int32_t* ch_cnt;   // [nblocks][B][G], [nblocks][B][W], [nblocks][B]
+    unsigned char* h1; long h1_row_bytes;
+    int slice_bytes, lds_total;
+};
+
+__device__ __forceinline__ void phase_fence() {
+    // WORKGROUP scope: the waves of a workgroup share their CU's vector L1, which is coherent with its own writes.  (An
+    // agent-scope fence writes back and invalidates the XCD's L2 on gfx950 -- measured: +200 us per block.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// the thread index behind an optimisation barrier: the per-lane geometry of a phase (tap rows, swizzles, source offsets) is the
+// same for every block of the run, and hoisted out of the block loop it would stay live through all three phases
+__device__ __forceinline__ int opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+template <typename T> __device__ __forceinline__ T uniform_ptr(T v) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<T>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int NS>
+__global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArgs p) {
+    constexpr int W = NS * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int HW = p.H * p.Wd;
+    for (int i = 0; i < p.nblocks; ++i) {
+        const ChainBlock* cb = p.blocks + i;
+        float* const mask_i = p.masks + (size_t)i * p.B * p.G;
+        int32_t* const idx_i = p.ch_idx + (size_t)i * p.B * W;
+        int32_t* const cnt_i = p.ch_cnt + (size_t)i * p.B;
+        const float* const xin = i == 0 ? p.x_in : p.x_work;
+        {   // ---- channel masker of block i on the GAP of its input
+            float* const s_f = reinterpret_cast<float*>(smem);
+            int* const s_w = reinterpret_cast<int*>(s_f + p.C + (p.hidden > 0 ? p.hidden : 1) + 2 * p.G);
+            channel_mlp_body<512>(b, i == 0 ? p.gap_in : p.colsum, HW, p.C, i == 0 ? p.gap_splits : 8, uniform_ptr(cb->mw1),
+                                  uniform_ptr(cb->mb1), uniform_ptr(cb->mw2), uniform_ptr(cb->mb2), p.hidden, p.G, p.gran, nullptr,
+                                  mask_i, nullptr, idx_i, cnt_i, s_f, s_w);
+        }
+        phase_fence();
+        {   // ---- conv1 -> h1 (pre-split)
+            HeadArgs ha;
+            ha.x = xin; ha.ldx = p.ldx; ha.B = p.B; ha.HW = HW; ha.cin = p.C; ha.W = W;
+            ha.w1s = uniform_ptr(cb->w1s); ha.n_idx = idx_i; ha.n_cnt = cnt_i;
+            ha.sc1 = uniform_ptr(cb->sc1); ha.sh1 = uniform_ptr(cb->sh1); ha.ps1 = uniform_ptr(cb->ps1);
+            ha.h1 = p.h1; ha.h1_row_bytes = p.h1_row_bytes; ha.pix_per_blk = HW; ha.mblocks = 1;
+            head_body<NS>(ha, b, 0, smem, p.lds_total, opaque_tid());
+        }
+        phase_fence();
+        {   // ---- conv2 -> conv3 + residual, GAP partials of the output
+            TailArgs ta;
+            ta.h1 = p.h1; ta.h1_row_bytes = p.h1_row_bytes;
+            ta.B = p.B; ta.Hi = p.H; ta.Wi = p.Wd; ta.Ho = p.H; ta.Wo = p.Wd; ta.W = W; ta.cout = p.C;
+            ta.w2p = uniform_ptr(cb->w2p); ta.w3p = uniform_ptr(cb->w3p); ta.k_idx = idx_i; ta.k_cnt = cnt_i;
+            ta.sc2 = uniform_ptr(cb->sc2); ta.sh2 = uniform_ptr(cb->sh2); ta.ps2 = uniform_ptr(cb->ps2); ta.sh3 = uniform_ptr(cb->sh3);
+            ta.residual = xin; ta.ldr = p.ldx; ta.out = p.x_work; ta.ldo = p.ldx; ta.colsum = p.colsum;
+            ta.rows_per_blk = p.H; ta.mblocks = 1; ta.slice_bytes = p.slice_bytes;
+            tail_body<NS>(ta, b, 0, smem, opaque_tid());
+        }
+        phase_fence();
+    }
+}
+
+template <int NS>
+static int launch_chain(ChainArgs& a, hipStream_t st) {
+    constexpr int W = NS * 32;
+    const int nr = a.H * a.Wd;
+    a.slice_bytes = round_up((round_up(nr, 8) + 1) * 128, 1024);
+    const size_t lds2 = (size_t)T_KIDX_BYTES + (NS == 2 ? 1 : 2) * (size_t)a.slice_bytes + (size_t)T_W2_SLOTS * 16 * NS * 256;
+    const size_t lds3 = (size_t)T_KIDX_BYTES + 2 * (size_t)(W / 2) * (NS == 8 ? 32 : 64) * 8 + (size_t)18 * W * 4 + 8 * 4096;
+    const size_t ldsm = (size_t)(a.C + (a.hidden > 0 ? a.hidden : 1) + 2 * a.G) * 4 + 64;
+    const size_t lds = 160 * 1024;
+    LDN_REQUIRE(lds2 <= lds && lds3 <= lds && ldsm <= lds, "ldn_bottleneck_chain: the phases need more than 160 KiB of LDS (map %dx%d, width %d)", a.H, a.Wd, W);
+    a.lds_total = (int)lds;
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_chain<NS>), lds), "k_chain: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((k_chain<NS>), dim3((unsigned)a.B), dim3(512), lds, st, a);
+    LDN_CHECK_LAUNCH("k_chain");
+    return LDN_OK;
+}
+
+}  // namespace ldn
+
+extern "C" int ldn_bottleneck_chain(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
+                                    const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran,
+                                    const float* gap_in, int gap_splits, float* colsum, float* masks, int32_t* ch_idx,
+                                    int32_t* ch_cnt, void* h1_split, int ldh, void* stream) {
+    using namespace ldn;
+    LDN_REQUIRE(x_in && x_work && blocks && gap_in && colsum && masks && ch_idx && ch_cnt && h1_split, "ldn_bottleneck_chain: null pointer");
+    LDN_REQUIRE(width == 64 || width == 128 || width == 256, "ldn_bottleneck_chain: width must be 64, 128 or 256 (got %d)", width);
+    LDN_REQUIRE(B > 0 && H > 0 && Wd > 0 && H * Wd <= 256, "ldn_bottleneck_chain: the map must fit one workgroup (H * W <= 256, got %dx%d)", H, Wd);
+    LDN_REQUIRE(C > 0 && C % 64 == 0, "ldn_bottleneck_chain: C must be a multiple of 64 (got %d)", C);
+    LDN_REQUIRE(nblocks > 0 && gap_splits > 0 && hidden >= 0 && G > 0 && gran > 0 && gran % 2 == 0 && G * gran == width,
+                "ldn_bottleneck_chain: bad run / masker shape (G * gran must equal width, gran even)");
+    LDN_REQUIRE(ldx >= C && ldx % 4 == 0 && ldh >= width && ldh % 8 == 0, "ldn_bottleneck_chain: bad ldx / ldh");
+    LDN_REQUIRE((uintptr_t)x_in % 16 == 0 && (uintptr_t)x_work % 16 == 0 && (uintptr_t)h1_split % 16 == 0 && (uintptr_t)colsum % 16 == 0 &&
+                (uintptr_t)blocks % 8 == 0, "ldn_bottleneck_chain: pointers must be 16-byte aligned");
+    LDN_REQUIRE((long)9 * (width / 2) * (width / 2) * 16 < (1L << 31), "ldn_bottleneck_chain: weights too large");
+    ChainArgs a{};
+    a.blocks = reinterpret_cast<const ChainBlock*>(blocks); a.nblocks = nblocks;
+    a.x_in = x_in; a.x_work = x_work; a.ldx = ldx; a.B = B; a.H = H; a.Wd = Wd; a.C = C;
+    a.hidden = hidden; a.G = G; a.gran = gran; a.gap_in = gap_in; a.gap_splits = gap_splits; a.colsum = colsum;
+    a.masks = masks; a.ch_idx = ch_idx; a.ch_cnt = ch_cnt;
+    a.h1 = static_cast<unsigned char*>(h1_split); a.h1_row_bytes = (long)ldh * 4;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (width == 64) return launch_chain<2>(a, st);
+    if (width == 128) return launch_chain<4>(a, st);
+    return launch_chain<8>(a, st);
 }

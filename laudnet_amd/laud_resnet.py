@@ -18,6 +18,9 @@ masks for "identical inputs/masks" parity runs (mask_override).
 """
 from __future__ import annotations
 
+import itertools
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -70,6 +73,9 @@ def _after_load(module, _incompatible_keys):
     module._drop_cache()
 
 
+_PREP_GEN = itertools.count()
+
+
 class _PrepCache(nn.Module):
     """Mixin: lazily built, device-resident folded weights.  The cache is keyed on (data_ptr, _version) of every parameter
     and buffer of the module's OWN sub-tree, so in-place edits (p.data.copy_, BN re-estimation, an optimizer step) are
@@ -101,6 +107,7 @@ class _PrepCache(nn.Module):
     def _cache_store(self, prep):
         self._prep = prep
         self._prep_key = self._src_key()
+        self._prep_gen = next(_PREP_GEN)      # identifies THIS build of the cache (tables of device pointers are keyed on it)
         return prep
 
     def train(self, mode: bool = True):
@@ -444,6 +451,7 @@ class Bottleneck(_PrepCache):
         return ops.from_nhwc(out), mask
 
     use_fused_head = True    # conv1 on k_head (False: the general ldn_conv_image with out_format 1)
+    fused_head_widths = (256,)   # ... for these widths when a block runs on its own (measured: the early stages' short blocks are faster on ldn_conv_image)
     use_fused_tail = True    # class-level switch (A/B measurements): False keeps the three-launch gathered execution
 
     def _tail_eligible(self, Hi, Wi, Ho, Wo, cout):
@@ -521,7 +529,7 @@ class Bottleneck(_PrepCache):
             w2p, w3p = self.tail_weights(p)
             # k_head (deep staging ring, one workgroup per CU) pays where an image fills a workgroup and K is long (stage 3);
             # the early stages stream many short blocks and stay on the general kernel, two workgroups per CU (measured)
-            if self.use_fused_head and Cin % 32 == 0 and self.width == 256:
+            if self.use_fused_head and Cin % 32 == 0 and self.width in self.fused_head_widths:
                 ops.bottleneck_head(xn, p["w1s"], idx, cnt, p["s1"], p["t1"], p["c1"], h1)
             else:
                 ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1, out_split=True)
@@ -819,8 +827,22 @@ class ResNet(nn.Module):
         blocks = [blk for i in range(4) for blk in getattr(self, f"layer{i + 1}")]
         sizes = [len(getattr(self, f"layer{i + 1}")) for i in range(4)]
         gap = None
-        for j, blk in enumerate(blocks):
+        j = -1
+        while j + 1 < len(blocks):
+            j += 1
+            blk = blocks[j]
             nxt = blocks[j + 1] if j + 1 < len(blocks) else None
+            # a run of stride-1 channel-mode blocks on a map that fits one workgroup (stage 3): ONE launch, image by image
+            n_run = self._chain_len(blocks, j, x, gap)
+            if n_run >= 2:
+                x, run_stats, gap = self._run_chain(blocks[j:j + n_run], x, gap)
+                stats.extend(run_stats)
+                j += n_run - 1
+                nxt = blocks[j + 1] if j + 1 < len(blocks) else None
+                if not (nxt is not None and nxt.dyn_mode == "channel" and nxt.forced_channel_mask is None
+                        and getattr(nxt.masker_channel, "accepts_fused_gap", False)):
+                    gap = None
+                continue
             # a channel-mode block leaves the GAP partials of its output for the next block's MLP masker
             want_gap = (nxt is not None and blk.dyn_mode == "channel" and nxt.dyn_mode == "channel"
                         and getattr(nxt.masker_channel, "accepts_fused_gap", False) and nxt.forced_channel_mask is None)
@@ -838,6 +860,68 @@ class ResNet(nn.Module):
         x = self.fc(x)
         split = lambda v: list(torch.split(v, sizes))
         return x, split(s3), split(s2), split(s1), split(cs), perc, flops
+
+    # ---- chained execution of a run of blocks (ldn_bottleneck_chain)
+    use_chain = os.environ.get("LDN_CHAIN", "1") != "0"     # class-level switch (A/B measurements, tests): False launches every block on its own
+
+    chain_max_blocks = int(os.environ.get("LDN_CHAIN_MAX", "64"))   # longest run per launch (tuning)
+
+    def _chain_len(self, blocks, j, x, gap):
+        """Number of consecutive blocks from j that ldn_bottleneck_chain can execute as one launch (0 = none).  The run needs the
+        GAP partials of its input (left by the producing block), identical shapes, MLP maskers deciding on their own, and
+        everything ldn_bottleneck_tail needs; the result is bit-identical to the block-by-block execution."""
+        if not self.use_chain or gap is None or self._tap is not None or not x.is_cuda:
+            return 0
+        B, C, H, W = x.shape
+        if H * W > 256 or H * W <= 64 or gap.dim() != 3 or gap.shape[0] != B or gap.shape[2] != C:
+            return 0
+        first, n = blocks[j], 0
+        for blk in blocks[j:]:
+            m = blk.masker_channel
+            ok = (isinstance(blk, Bottleneck) and blk.dyn_mode == "channel" and isinstance(m, Masker_channel_MLP)
+                  and blk.forced_channel_mask is None and blk.downsample is None and blk.stride == 1
+                  and blk.use_fused_head and blk._tail_eligible(H, W, H, W, C) and C % 32 == 0
+                  and blk.conv1.in_channels == C and blk.conv3.out_channels == C
+                  and blk.width == first.width and blk.channel_dyn_granularity == first.channel_dyn_granularity
+                  and m.layers == first.masker_channel.layers and m.channel_dyn_group == first.masker_channel.channel_dyn_group
+                  and (m.layers == 1 or m.conv[0].out_features == first.masker_channel.conv[0].out_features))
+            if not ok or n >= self.chain_max_blocks:
+                break
+            n += 1
+        return n
+
+    def _run_chain(self, run, x, gap):
+        dev = x.device
+        preps = [blk._prep if blk._cache_valid() else blk._prepare(dev) for blk in run]
+        mws = [blk.masker_channel._weights() for blk in run]
+        key = (str(dev),) + tuple(blk._prep_gen for blk in run) + tuple(blk.masker_channel._prep_gen for blk in run)
+        cache = getattr(self, "_chain_cache", None)
+        if cache is None:
+            cache = self._chain_cache = {}
+        ent = cache.get(id(run[0]))
+        if ent is None or ent[0] != key:
+            rows = []
+            for blk, p, mw in zip(run, preps, mws):
+                w2p, w3p = blk.tail_weights(p)
+                rows.append((p["w1s"], p["s1"], p["t1"], p["c1"], w2p, w3p, p["s2"], p["t2_tab"], p["c2"], p["t3c"],
+                             mw[0], mw[1], mw[2], mw[3]))
+            ent = cache[id(run[0])] = (key, ops.chain_table(rows, dev), rows)     # rows: keeps the tensors alive
+        first = run[0]
+        m = first.masker_channel
+        hidden = m.conv[0].out_features if m.layers == 2 else 0
+        xn = ops.as_nhwc(x)
+        work = xn if self.inplace_residual else torch.empty_like(xn)
+        masks, idx, cnt, colsum = ops.bottleneck_chain(xn, work, ent[1], first.width, hidden, m.channel_dyn_group,
+                                                       first.channel_dyn_granularity, gap)
+        stats = []
+        denom = float(x.shape[0] * first.width)
+        for i, blk in enumerate(run):
+            blk.last_channel_mask = masks[i]
+            blk.last_channel_cnt = cnt[i]
+            blk.last_gap = None
+            stats.append((cnt[i], denom))
+        run[-1].last_gap = colsum
+        return ops.from_nhwc(work), stats, colsum
 
     # ---- FLOPs bookkeeping (laud_resnet.py:112-147, 321-356) as a function of the input SHAPE and the sparsities only
     def flops_table(self, x_shape):

@@ -407,6 +407,50 @@ def bottleneck_head(x_nhwc, w1_split, ch_idx, ch_cnt, scale1, shift1, post_sub1,
     return h1_split
 
 
+CHAIN_BLOCK_FIELDS = 14   # pointers of one ldn_chain_block
+
+
+def chain_table(rows, device):
+    """Device array of ldn_chain_block for ldn_bottleneck_chain.  rows: per block the 14 tensors (or None) in the order of the
+    struct (w1_split, scale1, shift1, post_sub1, w2_pairs, w3_pairs, scale2, shift2_tab, post_sub2, shift3, mw1, mb1, mw2, mb2).
+    The caller keeps the tensors alive for as long as it uses the table."""
+    flat = []
+    for row in rows:
+        if len(row) != CHAIN_BLOCK_FIELDS:
+            raise L.LdnError("chain_table: a block takes 14 tensors")
+        for t in row:
+            if t is not None and (not t.is_contiguous() or t.device != torch.device(device)):
+                raise L.LdnError("chain_table: tensors must be contiguous and on the table's device")
+            flat.append(0 if t is None else t.data_ptr())
+    return torch.tensor(flat, dtype=torch.int64).view(len(rows), CHAIN_BLOCK_FIELDS).to(device)
+
+
+def bottleneck_chain(x_in, x_work, table, width, hidden, G, gran, gap_in):
+    """A run of stride-1 channel-mode bottlenecks as one launch (see ldn_bottleneck_chain).  x_in / x_work [B,H,Wd,C] NHWC fp32
+    (may be the same tensor); table = chain_table(...); gap_in [B,splits,C].
+    Returns (masks [n,B,G], ch_idx [n,B,width], ch_cnt [n,B], colsum [B,8,C]); x_work holds the run's output."""
+    L.require_device(x_in, x_work, table, gap_in)
+    lib = L.load()
+    B, H, Wd, C = x_in.shape
+    n = table.shape[0]
+    dev = x_in.device
+    if x_work.shape != x_in.shape or not (x_in.is_contiguous() and x_work.is_contiguous()) or x_in.dtype != torch.float32:
+        raise L.LdnError("bottleneck_chain: x_in / x_work must be contiguous fp32 NHWC tensors of the same shape")
+    if table.dtype != torch.int64 or table.dim() != 2 or table.shape[1] != CHAIN_BLOCK_FIELDS or not table.is_contiguous():
+        raise L.LdnError("bottleneck_chain: table must come from chain_table")
+    if gap_in.dim() != 3 or gap_in.shape[0] != B or gap_in.shape[2] != C:
+        raise L.LdnError("bottleneck_chain: gap_in must be [B, splits, C]")
+    masks = torch.empty(n, B, G, device=dev, dtype=torch.float32)
+    ch_idx = torch.empty(n, B, width, device=dev, dtype=torch.int32)
+    ch_cnt = torch.empty(n, B, device=dev, dtype=torch.int32)
+    colsum = torch.empty(B, 8, C, device=dev, dtype=torch.float32)
+    h1 = torch.empty(B, H, Wd, width, device=dev, dtype=torch.float32)
+    L.check(lib.ldn_bottleneck_chain(L.ptr(x_in), L.ptr(x_work), C, B, H, Wd, C, width, L.ptr(table), n, hidden, G, gran,
+                                     L.ptr(_f32c(gap_in, "gap_in")), gap_in.shape[1], L.ptr(colsum), L.ptr(masks), L.ptr(ch_idx),
+                                     L.ptr(ch_cnt), L.ptr(h1), width, L.stream_ptr(x_work)), "ldn_bottleneck_chain")
+    return masks, ch_idx, ch_cnt, colsum
+
+
 def bottleneck_tail_splits(H, W):
     return L.load().ldn_bottleneck_tail_splits(H, W)
 

@@ -146,15 +146,17 @@ class KernelTimer:
         self.records = []
         self.rows = []
         self.tails = []
+        self.chains = []
         self.step = 0          # index of the timed step in flight (set by the timed loop)
         self.steps_of = {}     # kind -> set of steps in which its launches were bracketed
 
     # Two event records per launch cost ~4 us of stream time each (0.48 ms of a 19.7 ms step when every conv2 and conv3
     # launch is bracketed): each kind is bracketed in every OTHER timed step, which still samples the whole timed region.
     PHASE = {"conv2_3x3": 0, "conv3_1x1": 1, "rows_3x3": 0, "tail_fused": 1}
+    EVERY_STEP = ("chain_fused",)   # one launch per forward: two event records per step cost nothing measurable
 
     def sampled(self, kind):
-        if (self.step + self.PHASE[kind]) % 2:
+        if kind not in self.EVERY_STEP and (self.step + self.PHASE[kind]) % 2:
             return False
         self.steps_of.setdefault(kind, set()).add(self.step)
         return True
@@ -187,6 +189,18 @@ class KernelTimer:
             out = fn(*a, **kw)
             e1.record()
             self.tails.append((e0, e1, a[4], tuple(a[0].shape), tuple(a[9].shape), kw.get("residual") is not None))
+            return out
+        return timed
+
+    def wrap_chain(self, fn):
+        """ops.bottleneck_chain: a run of stride-1 channel-mode blocks (stage 3) as ONE launch (k_chain)."""
+        def timed(*a, **kw):
+            self.sampled("chain_fused")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.chains.append((e0, e1, out[2], tuple(a[0].shape), a[3]))   # ch_cnt [n,B], x shape, width
             return out
         return timed
 
@@ -227,6 +241,18 @@ class KernelTimer:
             nbytes = 4.0 * (H * Wd * float(kb.sum()) + 9 * width * width + width * cout + B * H * Wd * cout * (2 if has_res else 1))
             n, ms, f, by = agg.get("tail_fused", (0, 0.0, 0.0, 0.0))
             agg["tail_fused"] = (n + 1, ms + e0.elapsed_time(e1), f + flops, by + nbytes)
+        for e0, e1, cnt, xshape, width in self.chains:
+            # algorithmic work of a chained run per launch, block by block: conv1 + conv2 + conv3 on the image's active subset;
+            # bytes with full fusion (4 * H^2 * (Cin + Cout)): the block's input read ONCE (conv1 operand and residual
+            # are the same tensor), its output written once, the three weight tensors once.  h1 / h2 / masks are not counted.
+            B, H, Wd, C = xshape
+            kb = cnt.double().cpu()                       # [n, B]
+            n_blk = kb.shape[0]
+            flops = float((2.0 * H * Wd * (2.0 * C * kb + 9.0 * kb * kb)).sum())
+            nbytes = n_blk * 4.0 * (2.0 * B * H * Wd * C + 2 * C * width + 9 * width * width)
+            n, ms, f, by = agg.get("chain_fused", (0, 0.0, 0.0, 0.0))
+            agg["chain_fused"] = (n + 1, ms + e0.elapsed_time(e1), f + flops, by + nbytes)
+            self.chain_blocks = n_blk
         for e0, e1, mc, cap, wshape in self.rows:          # w [cout][9][cin]; rows = active output pixels of the batch
             cout, taps, cin = wshape
             m = float(mc.item()) if mc is not None else float(cap)
@@ -321,10 +347,12 @@ def main():
     orig_conv_image = ops.conv_image
     orig_conv_rows = ops.conv_rows
     orig_tail = ops.bottleneck_tail
+    orig_chain = ops.bottleneck_chain
     if not os.environ.get("LDN_BENCH_NO_EVENTS"):   # tuning only: what the per-launch HIP events cost
         ops.conv_image = timer.wrap(orig_conv_image)
         ops.conv_rows = timer.wrap_rows(orig_conv_rows)
         ops.bottleneck_tail = timer.wrap_tail(orig_tail)
+        ops.bottleneck_chain = timer.wrap_chain(orig_chain)
 
     if world > 1:
         torch.distributed.barrier()
@@ -347,6 +375,7 @@ def main():
     ops.conv_image = orig_conv_image
     ops.conv_rows = orig_conv_rows
     ops.bottleneck_tail = orig_tail
+    ops.bottleneck_chain = orig_chain
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -413,7 +442,21 @@ def main():
                     "launches": n, "avg_launch_us": 1e3 * ms / n, "algorithmic_mbytes_per_launch": nbytes / n / 1e6,
                     "algorithmic_tflops": tf, "executed_mfma_tflops": 3 * tf, "frac_of_bf16_mfma_peak_executed": 3 * tf / BF16_MFMA_PEAK_TFLOPS}
 
-        pick = {"conv3_1x1": hbm_roofline, "tail_fused": tail_roofline}
+        def chain_roofline(n, ms, flops, nbytes):
+            # whole stage-3 run in one launch; with full fusion a block moves its input once and its output once (411 MB at bs256)
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            tf = flops / (ms * 1e-3) / 1e12
+            nb = getattr(timer, "chain_blocks", 1)
+            return {"kernel": "k_chain (one launch = a run of stride-1 channel-mode bottlenecks: masker -> conv1 -> conv2 3x3 -> conv3 "
+                              "+ residual per block, one workgroup per image, bf16x3)",
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic.get("chain_fused_bf16x3", {}).get("traffic_bytes_per_launch"),
+                    "traffic_scope": traffic.get("chain_fused_bf16x3", {}).get("scope"),
+                    "launches": n, "avg_launch_us": 1e3 * ms / n, "blocks_per_launch": nb, "avg_us_per_block": 1e3 * ms / n / nb,
+                    "algorithmic_mbytes_per_launch": nbytes / n / 1e6, "algorithmic_mbytes_per_block": nbytes / n / nb / 1e6,
+                    "algorithmic_tflops": tf, "executed_mfma_tflops": 3 * tf, "frac_of_bf16_mfma_peak_executed": 3 * tf / BF16_MFMA_PEAK_TFLOPS}
+
+        pick = {"conv3_1x1": hbm_roofline, "tail_fused": tail_roofline, "chain_fused": chain_roofline}
         objs = {k: pick.get(k, mfma_roofline)(*v) for k, v in agg.items()}
         if "rows_3x3" in objs:
             objs["rows_3x3"]["kernel"] = objs["rows_3x3"]["kernel"].replace("3x3 per-image channel-subset conv", "3x3 conv over packed active rows, shared weights")

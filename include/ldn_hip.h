@@ -36,7 +36,7 @@ int ldn_version(void);
  * laudnet_amd.build --debug -> libldn_hip_debug.so) every kernel checks the index lists it consumes or produces on the device
  * (entries inside their tensor, counts inside the list capacity, channel pairs aligned and ascending, every in-bounds 3x3 tap
  * of an active pixel present in the dilated list); violations are counted, never trapped.  *count = violations since the last
- * reset (synchronises the device), *first_code = code of the first one (1xx conv, 2xx index build, 3xx fused tail, 4xx RegNet);
+ * reset (synchronises the device), *first_code = code of the first one (1xx conv, 2xx index build, 3xx fused tail, 4xx RegNet, 5xx packed-row 1x1);
  * the release build reports *count = -1 (checks compiled away).  Debug-only tooling: not on the hot path. */
 int ldn_debug_violations(int* count, int* first_code, int reset);
 /* number of compute units of the current device (used by callers to size persistent grids) */
@@ -220,6 +220,19 @@ int ldn_bottleneck_chain(const float* x_in, float* x_work, int ldx, int B, int H
                          const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran, const float* gap_in,
                          int gap_splits, float* colsum, float* masks, int32_t* ch_idx, int32_t* ch_cnt, void* h1_split,
                          int ldh, void* stream);
+
+/* ---- a8: the static stem of ResNet.forward in eval mode (laud_resnet.py:316-326: conv1 7x7 stride 2 pad 3 -> bn1 -> ReLU ->
+ * max-pool 3x3 stride 2 pad 1) as ONE launch, bf16x3 arithmetic.  The full-resolution conv output never exists in memory.
+ *   x [B,H,W,3] NHWC fp32;  out [B,Hp,Wp,cout] NHWC fp32 with Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W);  cout = 32 or 64
+ *   out = relu(maxpool(conv(x, bn1.scale * conv1.weight)) + shift)     shift[c] = bn1.bias - bn1.running_mean * bn1.scale
+ *         (== maxpool(relu(bn1(conv1(x)))): adding a per-channel constant and the ReLU commute with the max)
+ *   w_frag: ldn_stem_weight_bytes(cout) bytes, MFMA fragment order [cout/32][11 k-steps][64 lanes][8 hi | 8 lo] bf16:
+ *           lane (n = lane & 31, h = lane >> 5) of step s holds k-group q = 2s + h: kernel row ky = q / 3 and elements
+ *           i = 8 (q % 3) + e of that row's 24 slots, slot i = (kx = i / 3, c = i % 3) for i < 21, zero for the 3 pad slots
+ *           and for ky == 7. */
+size_t ldn_stem_weight_bytes(int cout);
+int ldn_stem_conv_pool(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout, float* out,
+                       int Hp, int Wp, void* stream);
 
 /* ---- a7 (spatial / layer / both): the same kernel over PACKED PIXEL LISTS ---------------------
  * Image b owns the packed rows [row_prefix[b], row_prefix[b+1]) (B == 1, row_prefix == NULL: rows [0, *m_count),

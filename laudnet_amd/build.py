@@ -8,7 +8,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libldn_hip.so")
-SOURCES = ["ldn_conv_image.hip", "ldn_index.hip", "ldn_regnet.hip", "ldn_tail.hip", "ldn_dense.hip"]
+SOURCES = ["ldn_conv_image.hip", "ldn_index.hip", "ldn_regnet.hip", "ldn_tail.hip", "ldn_dense.hip", "ldn_stem.hip"]
 HEADERS = [os.path.join(CSRC, "ldn_common.h"), os.path.join(os.path.dirname(PKG), "include", "ldn_hip.h")]
 
 
@@ -21,33 +21,47 @@ def needs_build() -> bool:
 
 
 DEBUG_LIB = os.path.join(PKG, "libldn_hip_debug.so")
+OBJ_DIR = os.path.join(PKG, "_obj")      # per-source objects (git-ignored): only the sources that changed are recompiled
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _compile_and_link(lib: str, tag: str, extra: list, force: bool, verbose: bool) -> str:
+    """One object per translation unit (compiled in parallel, only when its source or a header is newer), then one link."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in HEADERS if os.path.exists(h))
+    mlp = os.path.join(CSRC, "ldn_mlp.h")
+    if os.path.exists(mlp):
+        hdr_t = max(hdr_t, os.path.getmtime(mlp))
+    objs, jobs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ_DIR, f"{os.path.splitext(src)[0]}.{tag}.o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(sp), hdr_t):
+            cmd = [hipcc] + FLAGS + extra + ["-c", "-o", obj, sp]
+            if verbose:
+                print("[laudnet_amd.build]", " ".join(cmd), file=sys.stderr)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, cmd)
+    if jobs or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+        if verbose:
+            print("[laudnet_amd.build]", " ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return lib
 
 
 def build_debug(force: bool = False, verbose: bool = True) -> str:
     """The LDN_DEBUG build (device-side index-bounds checks, include/ldn_hip.h: ldn_debug_violations); select it with
     LDN_LIB_PATH=laudnet_amd/libldn_hip_debug.so."""
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    if not force and os.path.exists(DEBUG_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(DEBUG_LIB) for d in deps):
-        return DEBUG_LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-DLDN_DEBUG",
-           "-o", DEBUG_LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print("[laudnet_amd.build]", " ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    return DEBUG_LIB
+    return _compile_and_link(DEBUG_LIB, "debug", ["-DLDN_DEBUG"], force, verbose)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print("[laudnet_amd.build]", " ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    return LIB
+    return _compile_and_link(LIB, "rel", [], force, verbose)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,209 @@
+// k_stem -- the static stem of the LAUD-ResNets as ONE kernel (gfx950 / CDNA4, bf16x3 arithmetic):
+//
+//     conv 7x7 stride 2 pad 3 (3 -> C channels, bn1's scale folded into the weights)  ->  max-pool 3x3 stride 2 pad 1
+//     ->  + bn1's shift  ->  ReLU                                  (imagenet_classification/models/laud_resnet.py:316-326)
+//
+// relu(maxpool(s * conv + t)) == relu(maxpool(s * conv) + t): adding a per-channel constant and the ReLU are monotone and the
+// pool's padding is -inf, so the shift and the ReLU are applied to the POOLED map.  The full-resolution conv output (822 MB at
+// bs256 / 224^2, written once and read once by the library's conv -> max-pool pair) never exists in memory: the kernel reads
+// the image (154 MB) and writes the pooled map (205 MB).
+//
+// One persistent 512-thread workgroup per CU walks tiles of 8 x 7 pooled pixels = 17 x 15 conv pixels (255: one 32-pixel MFMA
+// column tile per wave; the conv rows / columns shared with the neighbouring tiles are recomputed, 1.14x):
+//   * the 39 x 35 x 3 input patch of the tile is fetched into registers while the previous tile is computed and then written to
+//     LDS as raw fp32 (zero outside the image);
+//   * transposed MFMA formulation (A operand = weights, B operand = activations, lane = conv pixel): K = (ky, kx, c) is laid out
+//     as 7 rows of 24 (21 real + 3 zero-weight slots), so that the 8 k-values of a lane are 8 CONSECUTIVE floats of the patch
+//     (an im2col that is a per-lane LDS address); they are split into bf16 hi / lo by the wave that owns the pixels; the weights
+//     are pre-split once per module into MFMA fragment order (two ds_read_b128 per fragment, no VALU);
+//   * the conv tile goes to LDS ([pixel][C] fp32, 16-byte slots XOR-swizzled with the pixel) and is pooled from there:
+//     thread = (pooled pixel, 4 channels), nine 16-byte reads, 16-byte coalesced stores of the NHWC output.
+#include "ldn_common.h"
+
+namespace ldn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int S_PH = 8, S_PW = 7;                     // pooled pixels per tile
+constexpr int S_CH = 2 * S_PH + 1, S_CW = 2 * S_PW + 1;   // conv pixels per tile: 17 x 15 = 255
+constexpr int S_IH = 2 * (S_CH - 1) + 7, S_IW = 2 * (S_CW - 1) + 7;   // input patch: 39 x 35
+constexpr int S_ROWF = S_IW * 3;                      // floats per patch row (105)
+constexpr int S_PATCH = (S_IH + 1) * S_ROWF + 32;     // + one row and a tail: the zero-weight k slots read past the window
+constexpr int S_KSTEPS = 11;                          // 7 rows x 24 = 168 -> 11 steps of 16 (the last half step has zero weights)
+constexpr int S_LOADS = (S_IH * S_ROWF + 511) / 512;  // patch floats per thread (8)
+
+struct StemArgs {
+    const float* x; int B, H, W;                      // NHWC fp32, 3 channels
+    const unsigned char* wf;                          // [C / 32][11][64 lanes][8 hi | 8 lo] bf16
+    const float* shift;                               // [C]
+    float* out; int C, Hc, Wc, Hp, Wp;                // NHWC [B, Hp, Wp, C]
+    int tiles_y, tiles_x, ntiles;
+};
+
+template <int NSUB>   // C = 32 * NSUB
+__global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
+    constexpr int C = 32 * NSUB;
+    constexpr int WF_BYTES = NSUB * S_KSTEPS * 64 * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const s_w = smem;                                           // weight fragments
+    float* const s_patch = reinterpret_cast<float*>(smem + WF_BYTES);          // [40][105] (+ tail)
+    float* const s_conv = s_patch + round_up(S_PATCH, 4);                      // [256][C]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < WF_BYTES / 16; i += 512)
+        reinterpret_cast<f32x4*>(s_w)[i] = reinterpret_cast<const f32x4*>(p.wf)[i];
+    for (int i = tid; i < S_PATCH; i += 512) s_patch[i] = 0.f;                 // the pad row / tail stay zero
+
+    // this lane's conv pixel of the tile and its patch offset (floats)
+    const int pm = wave * 32 + l31;
+    const int pmc = min(pm, S_CH * S_CW - 1);
+    const int coy = pmc / S_CW, cox = pmc - coy * S_CW;
+    const int pbase = (2 * coy * S_IW + 2 * cox) * 3;
+
+    auto tile_origin = [&](int t, int& b, int& py0, int& px0) {
+        const int per_img = p.tiles_y * p.tiles_x;
+        b = t / per_img;
+        const int r = t - b * per_img;
+        const int ty = r / p.tiles_x;
+        py0 = ty * S_PH;
+        px0 = (r - ty * p.tiles_x) * S_PW;
+    };
+    float pre[S_LOADS];
+    auto fetch = [&](int t) {
+        int b, py0, px0;
+        tile_origin(t, b, py0, px0);
+        const int iy0 = 4 * py0 - 5, ix0 = 4 * px0 - 5;
+#pragma unroll
+        for (int i = 0; i < S_LOADS; ++i) {
+            const int e = i * 512 + tid;
+            const int r = e / S_ROWF, cc = e - r * S_ROWF;
+            const int iy = iy0 + r, ix = ix0 + cc / 3;
+            const bool ok = e < S_IH * S_ROWF && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const long off = (((long)b * p.H + iy) * p.W + ix0) * 3 + cc;       // >= 0 whenever ok
+            pre[i] = ok ? p.x[off] : 0.f;
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t < p.ntiles) fetch(t);
+    for (; t < p.ntiles; t += gridDim.x) {
+        __syncthreads();           // every wave has left the previous tile's patch and conv tile (and, first, the weights are staged)
+#pragma unroll
+        for (int i = 0; i < S_LOADS; ++i) {
+            const int e = i * 512 + tid;
+            if (e < S_IH * S_ROWF) s_patch[e] = pre[i];
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < p.ntiles) fetch(t + gridDim.x);   // in flight during the MFMA loop
+
+        f32x16 acc[NSUB];
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < S_KSTEPS; ++s) {
+            const int q = 2 * s + h;                   // this lane's k8 group: patch row q / 3, floats 8 (q % 3) .. + 7 of the row window
+            const float* src = s_patch + pbase + (q / 3) * S_ROWF + 8 * (q % 3);
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = src[e];
+                const __bf16 hb = (__bf16)v;
+                bh[e] = hb;
+                bl[e] = (__bf16)(v - (float)hb);
+            }
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                const unsigned char* wp = s_w + ((j * S_KSTEPS + s) * 64 + lane) * 32;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wp);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wp + 16);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+            }
+        }
+        // C layout (lane = pixel l31, register r = channel (r & 3) + 8 (r >> 2) + 4 h of the subtile) -> s_conv[pixel][C]
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = {acc[j][4 * q4], acc[j][4 * q4 + 1], acc[j][4 * q4 + 2], acc[j][4 * q4 + 3]};
+                const int slot = 8 * j + 2 * q4 + h;
+                *reinterpret_cast<f32x4*>(s_conv + pm * C + ((slot ^ (pm & 7)) << 2)) = v;
+            }
+        __syncthreads();
+
+        // ---- max-pool 3x3 stride 2 pad 1 over the conv tile, + shift, ReLU
+        int b, py0, px0;
+        tile_origin(t, b, py0, px0);
+        constexpr int QUADS = C / 4;
+        for (int w = tid; w < S_PH * S_PW * QUADS; w += 512) {
+            const int cq = w % QUADS, pp = w / QUADS;
+            const int ly = pp / S_PW, lx = pp - ly * S_PW;
+            const int py = py0 + ly, px = px0 + lx;
+            if (py >= p.Hp || px >= p.Wp) continue;
+            f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cy = 2 * py - 1 + dy, cx = 2 * px - 1 + dx;      // conv pixel (global); tile-local = (2 ly + dy, 2 lx + dx)
+                    if (cy < 0 || cy >= p.Hc || cx < 0 || cx >= p.Wc) continue;
+                    const int cp = (2 * ly + dy) * S_CW + 2 * lx + dx;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(s_conv + cp * C + ((cq ^ (cp & 7)) << 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+                }
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + cq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e] + sh[e], 0.f);
+            __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(p.out + (((size_t)b * p.Hp + py) * p.Wp + px) * C + cq * 4));
+        }
+    }
+}
+
+
+template <int NSUB>
+static int launch_stem(const StemArgs& a, int cus, hipStream_t st) {
+    constexpr int C = 32 * NSUB;
+    const size_t lds = (size_t)NSUB * S_KSTEPS * 64 * 32 + (size_t)round_up(S_PATCH, 4) * 4 + (size_t)256 * C * 4;
+    LDN_REQUIRE(lds <= 160 * 1024, "ldn_stem_conv_pool: %zu B of LDS exceed 160 KiB", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_stem<NSUB>), lds), "k_stem: cannot reserve %zu B of LDS", lds);
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int grid = min(a.ntiles, cus * per_cu);
+    hipLaunchKernelGGL((k_stem<NSUB>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    LDN_CHECK_LAUNCH("k_stem");
+    return LDN_OK;
+}
+
+}  // namespace ldn
+
+using namespace ldn;
+
+extern "C" size_t ldn_stem_weight_bytes(int cout) { return cout > 0 && cout % 32 == 0 ? (size_t)(cout / 32) * S_KSTEPS * 64 * 32 : 0; }
+
+extern "C" int ldn_stem_conv_pool(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout,
+                                  float* out, int Hp, int Wp, void* stream) {
+    LDN_REQUIRE(x && w_frag && shift && out, "ldn_stem_conv_pool: null pointer");
+    LDN_REQUIRE(B > 0 && H > 0 && W > 0, "ldn_stem_conv_pool: bad geometry");
+    LDN_REQUIRE(cout == 32 || cout == 64, "ldn_stem_conv_pool: cout must be 32 or 64 (got %d)", cout);
+    LDN_REQUIRE((uintptr_t)w_frag % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)shift % 16 == 0 && (uintptr_t)x % 4 == 0,
+                "ldn_stem_conv_pool: w_frag / shift / out must be 16-byte aligned");
+    StemArgs a{};
+    a.x = x; a.B = B; a.H = H; a.W = W;
+    a.wf = static_cast<const unsigned char*>(w_frag); a.shift = shift; a.out = out; a.C = cout;
+    a.Hc = (H - 1) / 2 + 1; a.Wc = (W - 1) / 2 + 1;            // conv 7x7 stride 2 pad 3
+    a.Hp = (a.Hc - 1) / 2 + 1; a.Wp = (a.Wc - 1) / 2 + 1;      // max-pool 3x3 stride 2 pad 1
+    LDN_REQUIRE(Hp == a.Hp && Wp == a.Wp, "ldn_stem_conv_pool: output must be %dx%d for a %dx%d input (got %dx%d)", a.Hp, a.Wp, H, W, Hp, Wp);
+    a.tiles_y = ceil_div(a.Hp, S_PH); a.tiles_x = ceil_div(a.Wp, S_PW);
+    LDN_REQUIRE((long)B * a.tiles_y * a.tiles_x < (1L << 31), "ldn_stem_conv_pool: too many tiles");
+    a.ntiles = B * a.tiles_y * a.tiles_x;
+    int cus = 0;
+    if (ldn_device_cus(&cus) != LDN_OK || cus <= 0) cus = 256;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return cout == 64 ? launch_stem<2>(a, cus, st) : launch_stem<1>(a, cus, st);
+}

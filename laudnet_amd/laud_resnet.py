@@ -28,6 +28,10 @@ import torch.nn.functional as F
 from . import ops
 from ._lib import LdnError
 
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
 __all__ = ["uni_resnet50", "uni_resnet101", "ResNet", "Bottleneck", "Masker_spatial", "Masker_channel_MLP",
            "Masker_channel_conv_linear", "ExpandMask"]
 
@@ -815,11 +819,16 @@ class ResNet(nn.Module):
         in_shape = tuple(x.shape)
         # static stem (laud_resnet.py:318-324): plain library ops, channels-last so the blocks see NHWC rows
         x = x.contiguous(memory_format=torch.channels_last)
-        # eval-mode stem = conv with the BN folded into its weights, then max-pool, then ReLU on the pooled map
-        # (relu(maxpool(y)) == maxpool(relu(y)): both are monotone) -- two full-resolution passes fewer than conv, bn, relu
+        # eval-mode stem = conv with bn1's scale folded into its weights, then max-pool, then bn1's shift and the ReLU on the POOLED
+        # map: relu(maxpool(y + t)) == relu(maxpool(y) + t) exactly (adding a per-channel constant and ReLU are monotone, the pool's
+        # padding is -inf) -- three full-resolution passes fewer than conv, bn, relu (a conv bias is a separate full-size pass in MIOpen)
         w, b = self._folded_stem()
-        x = F.conv2d(x, w, b, self.conv1.stride, self.conv1.padding)
-        x = self.maxpool(x).relu_()
+        if self._stem_fused_ok(x):
+            # one launch: conv 7x7 -> max-pool -> + shift -> ReLU; the full-resolution conv output never exists (ldn_stem_conv_pool)
+            x = ops.from_nhwc(ops.stem_conv_pool(ops.as_nhwc(x), self._stem_frag, b, self.conv1.out_channels))
+        else:
+            x = F.conv2d(x, w, None, self.conv1.stride, self.conv1.padding)
+            x = self.maxpool(x).add_(b.view(1, -1, 1, 1)).relu_()
 
         # dynamic blocks: each returns its 4 sparsities as a device vector; the FLOPs bookkeeping of
         # laud_resnet.py:112-147,329-347 is done ONCE below on [n_blocks] vectors (no per-block scalar kernels)
@@ -865,6 +874,7 @@ class ResNet(nn.Module):
     use_chain = os.environ.get("LDN_CHAIN", "1") != "0"     # class-level switch (A/B measurements, tests): False launches every block on its own
 
     chain_max_blocks = int(os.environ.get("LDN_CHAIN_MAX", "64"))   # longest run per launch (tuning)
+    use_fused_stem = os.environ.get("LDN_FUSED_STEM", "1") != "0"    # the one-launch stem (ldn_stem_conv_pool); 0 = library conv + pool
 
     def _chain_len(self, blocks, j, x, gap):
         """Number of consecutive blocks from j that ldn_bottleneck_chain can execute as one launch (0 = none).  The run needs the
@@ -964,6 +974,19 @@ class ResNet(nn.Module):
         perc = sparse / tm.sum(dim=1)
         flops = sparse.sum() + self._static_flops
         return perc.float(), flops.float()
+
+    def _stem_fused_ok(self, x):
+        """The one-launch stem (k_stem) covers the standard geometry in bf16x3 arithmetic; anything else (fp32 math mode, the
+        reduced widths of the tiny test models, a modified stem) runs conv -> max-pool as library ops."""
+        c, mp = self.conv1, self.maxpool
+        ok = (self.use_fused_stem and ops.get_math_mode() == "bf16x3" and c.in_channels == 3 and c.out_channels in (32, 64)
+              and c.kernel_size == (7, 7) and c.stride == (2, 2) and c.padding == (3, 3) and c.dilation == (1, 1) and c.groups == 1
+              and _pair(mp.kernel_size) == (3, 3) and _pair(mp.stride) == (2, 2) and _pair(mp.padding) == (1, 1)
+              and _pair(mp.dilation) == (1, 1) and not mp.ceil_mode)
+        if ok and getattr(self, "_stem_frag_key", None) != self._stem_key:
+            self._stem_frag = ops.pack_stem_weights(self._stem[0])
+            self._stem_frag_key = self._stem_key
+        return ok
 
     def _folded_stem(self):
         """conv1 weights scaled by bn1's eval affine (laud_resnet.py:318-320), cached until a parameter or buffer changes."""

@@ -473,3 +473,37 @@ def bottleneck_tail(h1_split, w2_pairs, w3_pairs, ch_idx, ch_cnt, scale2, shift2
                                     residual.shape[-1] if residual is not None else 0, L.ptr(_f32c(out_nhwc, "out")), cout,
                                     L.ptr(colsum), L.stream_ptr(out_nhwc)), "ldn_bottleneck_tail")
     return out_nhwc
+
+
+# ---------------------------------------------------------------------------------------- a8: the static stem
+def pack_stem_weights(w_scaled):
+    """bn1-scaled conv1.weight [cout,3,7,7] fp32 -> MFMA fragment order [cout/32][11][64][hi 8 | lo 8] bf16 (ldn_stem_conv_pool):
+    K is 7 kernel rows x 24 slots (slot i < 21 = (kx = i // 3, c = i % 3), 3 zero pad slots), padded to 11 steps of 16."""
+    cout = w_scaled.shape[0]
+    if tuple(w_scaled.shape[1:]) != (3, 7, 7) or cout % 32:
+        raise L.LdnError("pack_stem_weights: expected [cout % 32 == 0, 3, 7, 7]")
+    w = w_scaled.detach().float().permute(0, 2, 3, 1).reshape(cout, 7, 21)         # [n][ky][kx*3 + c]
+    k = torch.zeros(cout, 8, 24, device=w.device, dtype=torch.float32)             # + zero row ky == 7 (step 10, upper half)
+    k[:, :7, :21] = w
+    k = k.reshape(cout, 24, 8)[:, :22]                                             # k-groups q = 3 ky + g; q == 21 is the zero pad
+    k = k.reshape(cout // 32, 32, 11, 2, 8)                                        # [j][n][s][h][e]: q = 2 s + h
+    k = k.permute(0, 2, 3, 1, 4).reshape(cout // 32, 11, 64, 8)                    # lane = h * 32 + n
+    hi, lo = _hi_lo(k)
+    return torch.stack((hi, lo), dim=-2).contiguous()                              # [j][s][lane][2][8]
+
+
+def stem_conv_pool(x_nhwc, w_frag, shift, cout):
+    """relu(maxpool3x3s2p1(conv7x7s2p3(x, w)) + shift) in one launch (see ldn_stem_conv_pool).  x_nhwc [B,H,W,3] -> [B,Hp,Wp,cout]."""
+    L.require_device(x_nhwc, w_frag, shift)
+    lib = L.load()
+    B, H, W, cin = x_nhwc.shape
+    if cin != 3 or x_nhwc.dtype != torch.float32 or not x_nhwc.is_contiguous():
+        raise L.LdnError("stem_conv_pool: x must be a contiguous fp32 [B,H,W,3] tensor")
+    if w_frag.dtype != torch.bfloat16 or not w_frag.is_contiguous() or w_frag.numel() * 2 != lib.ldn_stem_weight_bytes(cout):
+        raise L.LdnError("stem_conv_pool: w_frag must be the contiguous bf16 tensor of pack_stem_weights")
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    out = torch.empty(B, Hp, Wp, cout, device=x_nhwc.device, dtype=torch.float32)
+    L.check(lib.ldn_stem_conv_pool(L.ptr(x_nhwc), B, H, W, L.ptr(w_frag), L.ptr(_f32c(shift, "shift")), cout, L.ptr(out), Hp, Wp,
+                                   L.stream_ptr(out)), "ldn_stem_conv_pool")
+    return out

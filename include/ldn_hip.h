@@ -87,7 +87,7 @@ size_t ldn_spatial_masker_workspace_bytes(int B, int Hi, int Wi, int C, int S);
 int ldn_mask_to_index(const float* patch_mask, int B, int S, int Ho, int Wo, int stride, int32_t* idx3,
                       int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
                       int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work, void* stream);
-size_t ldn_mask_to_index_workspace_bytes(int B);
+size_t ldn_mask_to_index_workspace_bytes(int B, int Ho, int Wo, int stride);
 
 /* ---- K2/K5: stand-alone row gather / masked scatter-add (DyNetSimulator simulate_gather,
  * simulate_scatter_add; laud_resnet.py:133,143-144) ----------------------------------------- */

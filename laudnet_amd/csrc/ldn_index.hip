@@ -272,6 +272,202 @@ __global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ pa
     }
 }
 
+// ---- the same lists built by BANDS of output rows (grid = B x bands) for maps whose per-image tables do not fit one workgroup's
+// LDS (detection-size inputs).  Band j of image b owns the output rows [y0, y1) and the input rows [y0 s, y1 s);
+// packed positions are row-major inside an image and images follow each other, so band (b, j) starts at the sum of the counts of
+// all (image, band) pairs before it -- the lists are identical to the whole-image kernel's.  What a band needs from its
+// neighbours it recomputes: two halo rows of mask3 on each side (mask1 of the halo input rows) and the packed positions of the
+// input row just above / below its own rows (the 3x3 neighbour table): the row above ends right before the band's first
+// position, the row below starts right after its last one.
+struct BandGeom {
+    int R, nb;        // output rows per band, bands per image
+};
+
+__device__ __forceinline__ void fill_mask3_rows(const float* __restrict__ patch, const IdxGeom g, int b, int ya, int yb,
+                                                unsigned char* s_m3) {   // rows [ya, yb) -> s_m3[(y - ya) * Wo + x]; rows outside the map = 0
+    const float sh = (float)g.S / (float)g.Ho, sw = (float)g.S / (float)g.Wo;
+    const int n = (yb - ya) * g.Wo;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = ya + i / g.Wo, x = i % g.Wo;
+        unsigned char v = 0;
+        if (y >= 0 && y < g.Ho) {
+            const int sy = nearest_src(y, sh, g.S), sx = nearest_src(x, sw, g.S);
+            v = patch[((size_t)b * g.S + sy) * g.S + sx] > 0.5f ? 1 : 0;
+        }
+        s_m3[i] = v;
+    }
+}
+
+// mask1 of input pixel (iy, ix) from the band-local mask3 rows starting at output row ya
+__device__ __forceinline__ bool mask1_rows(const unsigned char* s_m3, const IdxGeom g, int ya, int iy, int ix) {
+    const int s = g.stride;
+    int oy0 = (iy - 1 + s - 1) / s, oy1 = (iy + 1) / s;
+    if (iy - 1 < 0) oy0 = 0;
+    int ox0 = (ix - 1 + s - 1) / s, ox1 = (ix + 1) / s;
+    if (ix - 1 < 0) ox0 = 0;
+    oy1 = oy1 < g.Ho - 1 ? oy1 : g.Ho - 1;
+    ox1 = ox1 < g.Wo - 1 ? ox1 : g.Wo - 1;
+    bool any = false;
+    for (int oy = oy0; oy <= oy1; ++oy)
+        for (int ox = ox0; ox <= ox1; ++ox) any |= s_m3[(oy - ya) * g.Wo + ox] != 0;
+    return any;
+}
+
+__global__ __launch_bounds__(256) void k_mask_count_band(const float* __restrict__ patch, const IdxGeom g, const BandGeom bg,
+                                                          int32_t* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_bytes[];
+    unsigned char* s_m3 = s_bytes;
+    __shared__ int s_red[3];
+    const int b = blockIdx.x / bg.nb, j = blockIdx.x - b * bg.nb;
+    const int y0 = j * bg.R, y1 = min(y0 + bg.R, g.Ho);
+    const int ya = y0 - 2;
+    if (threadIdx.x < 3) s_red[threadIdx.x] = 0;
+    fill_mask3_rows(patch, g, b, ya, y1 + 2, s_m3);
+    __syncthreads();
+    int c3 = 0, c1 = 0, cp = 0;
+    for (int i = threadIdx.x; i < (y1 - y0) * g.Wo; i += 256) c3 += s_m3[2 * g.Wo + i];
+    const int i0 = y0 * g.stride * g.Wi, i1 = y1 * g.stride * g.Wi;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int iy = i / g.Wi, ix = i - iy * g.Wi;
+        c1 += mask1_rows(s_m3, g, ya, iy, ix) ? 1 : 0;
+    }
+    if (j == 0)
+        for (int i = threadIdx.x; i < g.S * g.S; i += 256) cp += patch[(size_t)b * g.S * g.S + i] > 0.5f ? 1 : 0;
+    atomicAdd(&s_red[0], c3);
+    atomicAdd(&s_red[1], c1);
+    atomicAdd(&s_red[2], cp);
+    __syncthreads();
+    const int nent = g.B * bg.nb;
+    if (threadIdx.x < 3) work[threadIdx.x * nent + blockIdx.x] = s_red[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_mask_index_band(const float* __restrict__ patch, const IdxGeom g, const BandGeom bg,
+                                                          const int32_t* __restrict__ work, int32_t* __restrict__ idx3,
+                                                          int32_t* __restrict__ pos3, int32_t* __restrict__ idx1,
+                                                          int32_t* __restrict__ pos1, int32_t* __restrict__ nbr,
+                                                          int32_t* __restrict__ cnt, int32_t* __restrict__ pre3,
+                                                          int32_t* __restrict__ pre1, float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_bytes[];
+    const int HWo = g.Ho * g.Wo, HWi = g.Hi * g.Wi;
+    const int b = blockIdx.x / bg.nb, j = blockIdx.x - b * bg.nb, tid = threadIdx.x;
+    const int y0 = j * bg.R, y1 = min(y0 + bg.R, g.Ho);
+    const int ya = y0 - 2;
+    const int r0 = y0 * g.stride, r1 = y1 * g.stride;            // own input rows [r0, r1); s_pos1 covers [r0 - 1, r1 + 1)
+    int* s_pos3 = reinterpret_cast<int*>(s_bytes);               // [(y1 - y0) * Wo]
+    int* s_pos1 = s_pos3 + bg.R * g.Wo;                          // [(R s + 2) * Wi]
+    unsigned char* s_m3 = reinterpret_cast<unsigned char*>(s_pos1 + (bg.R * g.stride + 2) * g.Wi);   // [(R + 4) * Wo]
+    __shared__ int s_w[4];
+    __shared__ int s_base[3];
+    const int nent = g.B * bg.nb;
+    if (tid < 3) s_base[tid] = 0;
+    __syncthreads();
+    {
+        int a3 = 0, a1 = 0, ap = 0;
+        const bool last = (int)blockIdx.x == nent - 1;
+        for (int i = tid; i < (last ? nent : (int)blockIdx.x); i += 256) {
+            const bool own = i == (int)blockIdx.x;   // only in the last block: totals of the patch count
+            a3 += own ? 0 : work[i];
+            a1 += own ? 0 : work[nent + i];
+            ap += work[2 * nent + i];
+        }
+        atomicAdd(&s_base[0], a3);
+        atomicAdd(&s_base[1], a1);
+        atomicAdd(&s_base[2], ap);
+    }
+    fill_mask3_rows(patch, g, b, ya, y1 + 2, s_m3);
+    __syncthreads();
+    const int base3 = s_base[0], base1 = s_base[1];
+    const int own1 = work[nent + blockIdx.x];                    // mask1 pixels of this band
+    if (tid == 0) {
+        if (j == 0) { pre3[b] = base3; pre1[b] = base1; }
+        if ((int)blockIdx.x == nent - 1) {
+            const int tot3 = base3 + work[blockIdx.x], tot1 = base1 + own1;
+            pre3[g.B] = tot3;
+            pre1[g.B] = tot1;
+            cnt[0] = tot3;
+            cnt[1] = tot1;
+            stats[0] = (float)s_base[2] / (float)((long)g.B * g.S * g.S);
+            stats[1] = (float)tot3 / (float)((long)g.B * HWo);
+            stats[2] = (float)tot1 / (float)((long)g.B * HWi);
+        }
+    }
+    // own output pixels
+    int running = 0;
+    const int n3 = (y1 - y0) * g.Wo;
+    for (int i0 = 0; i0 < n3; i0 += 256) {
+        const int i = i0 + tid;
+        const bool f = i < n3 && s_m3[2 * g.Wo + i];
+        int tot;
+        const int r = block_rank(f, s_w, tot);
+        if (i < n3) {
+            const int pp = f ? base3 + running + r : -1;
+            s_pos3[i] = pp;
+            pos3[(size_t)b * HWo + y0 * g.Wo + i] = pp;
+            LDN_DCHECK(!f || (pp >= 0 && pp < g.B * HWo), 201);
+            if (f) idx3[pp] = b * HWo + y0 * g.Wo + i;
+        }
+        running += tot;
+    }
+    // own input pixels -> s_pos1 rows 1 .. (r1 - r0)
+    running = 0;
+    const int n1 = (r1 - r0) * g.Wi;
+    for (int i0 = 0; i0 < n1; i0 += 256) {
+        const int i = i0 + tid;
+        bool f = false;
+        if (i < n1) f = mask1_rows(s_m3, g, ya, r0 + i / g.Wi, i % g.Wi);
+        int tot;
+        const int r = block_rank(f, s_w, tot);
+        if (i < n1) {
+            const int pp = f ? base1 + running + r : -1;
+            s_pos1[g.Wi + i] = pp;
+            pos1[(size_t)b * HWi + (size_t)r0 * g.Wi + i] = pp;
+            LDN_DCHECK(!f || (pp >= 0 && pp < g.B * HWi), 202);
+            if (f) idx1[pp] = b * HWi + r0 * g.Wi + i;
+        }
+        running += tot;
+    }
+    // the input rows just above (ends right before base1) and just below (starts at base1 + own1) the band: positions only
+    for (int side = 0; side < 2; ++side) {
+        const int iy = side == 0 ? r0 - 1 : r1;
+        int* dst = s_pos1 + (side == 0 ? 0 : (r1 - r0 + 1) * g.Wi);
+        const bool inmap = iy >= 0 && iy < g.Hi;
+        // total of the row first (the row above is addressed from its end)
+        int rowtot = 0;
+        if (side == 0 && inmap) {
+            for (int i0 = 0; i0 < g.Wi; i0 += 256) {
+                const int i = i0 + tid;
+                const bool f = i < g.Wi && mask1_rows(s_m3, g, ya, iy, i);
+                int tot;
+                (void)block_rank(f, s_w, tot);
+                rowtot += tot;
+            }
+        }
+        running = 0;
+        for (int i0 = 0; i0 < g.Wi; i0 += 256) {
+            const int i = i0 + tid;
+            const bool f = inmap && i < g.Wi && mask1_rows(s_m3, g, ya, iy, i);
+            int tot;
+            const int r = block_rank(f, s_w, tot);
+            if (i < g.Wi) dst[i] = !f ? -1 : (side == 0 ? base1 - rowtot + running + r : base1 + own1 + running + r);
+            running += tot;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n3; i += 256) {
+        const int pp = s_pos3[i];
+        if (pp < 0) continue;
+        const int oy = y0 + i / g.Wo, ox = i % g.Wo;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = oy * g.stride - 1 + t / 3, ix = ox * g.stride - 1 + t % 3;
+            const bool inb = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+            const int v = inb ? s_pos1[(iy - (r0 - 1)) * g.Wi + ix] : -1;
+            LDN_DCHECK(!inb || v >= 0, 203);
+            nbr[(size_t)pp * 9 + t] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- K2 / K5
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, int ld_src,
                                                       const int32_t* __restrict__ rows,
@@ -429,7 +625,32 @@ extern "C" size_t ldn_spatial_masker_workspace_bytes(int B, int Hi, int Wi, int 
     if (!(S < Hi && S == 1)) return 0;   // only the whole-image window (layer skip) is reduced in two stages
     return (size_t)B * ldn_channel_masker_splits(Hi * Wi) * C * sizeof(float);
 }
-extern "C" size_t ldn_mask_to_index_workspace_bytes(int B) { return (size_t)3 * B * sizeof(int32_t); }
+constexpr size_t kWholeImageLds = 150 * 1024;   // per-image tables up to this size are built by one workgroup per image
+constexpr size_t kBandLds = 64 * 1024;          // LDS budget of a band (several workgroups per CU)
+
+// rows per band / bands per image / LDS bytes of the banded index build; false if not even one row fits
+static bool index_bands(int Ho, int Wo, int stride, int* R, int* nb, size_t* lds) {
+    const size_t Wi = (size_t)Wo * stride;
+    auto bytes = [&](int r) { return (size_t)r * Wo * 4 + ((size_t)r * stride + 2) * Wi * 4 + (size_t)(r + 4) * Wo; };
+    const char* env = getenv("LDN_INDEX_BAND_LDS");             // tests: a small budget forces many bands on small maps
+    const size_t budget = env ? (size_t)atol(env) : kBandLds;
+    int r = Ho;
+    while (r > 1 && bytes(r) > budget) r = (r + 1) / 2;
+    if (bytes(r) > 150 * 1024) return false;
+    const int n = (Ho + r - 1) / r;
+    r = (Ho + n - 1) / n;                        // balance the bands
+    *R = r; *nb = (Ho + r - 1) / r; *lds = bytes(r);
+    return true;
+}
+
+extern "C" size_t ldn_mask_to_index_workspace_bytes(int B, int Ho, int Wo, int stride) {
+    if (B <= 0 || Ho <= 0 || Wo <= 0 || stride <= 0) return 0;
+    int R = 0, nb = 1;
+    size_t lds = 0;
+    const size_t whole = (size_t)Ho * Wo * 5 + (size_t)Ho * stride * Wo * stride * 4;
+    if ((whole > kWholeImageLds || getenv("LDN_INDEX_BANDS")) && !index_bands(Ho, Wo, stride, &R, &nb, &lds)) nb = 1;
+    return (size_t)3 * B * nb * sizeof(int32_t);
+}
 extern "C" size_t ldn_channel_masker_workspace_bytes(int B, int HW, int C) {
     return (size_t)B * ldn_channel_masker_splits(HW) * C * sizeof(float);
 }
@@ -470,16 +691,29 @@ extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Ho, 
     LDN_REQUIRE(B > 0 && S > 0 && Ho > 0 && Wo > 0 && stride >= 1, "ldn_mask_to_index: bad shape");
     LDN_REQUIRE((long)B * Ho * stride * Wo * stride < (1l << 31), "ldn_mask_to_index: index space exceeds int32");
     IdxGeom g{B, S, Ho, Wo, stride, Ho * stride, Wo * stride};
+    hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds1 = (size_t)Ho * Wo;
     const size_t lds2 = (size_t)Ho * Wo * 5 + (size_t)g.Hi * g.Wi * 4;
-    LDN_REQUIRE(lds2 <= 150 * 1024, "ldn_mask_to_index: feature map %dx%d too large for the LDS-resident index build", g.Hi, g.Wi);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_mask_index), lds2), "k_mask_index: cannot reserve %zu B of LDS", lds2);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_mask_count, dim3(B), dim3(256), lds1, st, patch_mask, g, work);
-    LDN_CHECK_LAUNCH("k_mask_count");
-    hipLaunchKernelGGL(k_mask_index, dim3(B), dim3(256), lds2, st, patch_mask, g, work, idx3, pos3, idx1, pos1, nbr,
-                       cnt, img_prefix3, img_prefix1, stats);
-    LDN_CHECK_LAUNCH("k_mask_index");
+    if (lds2 <= kWholeImageLds && !getenv("LDN_INDEX_BANDS")) {   // whole image in one workgroup's LDS
+        LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_mask_index), lds2), "k_mask_index: cannot reserve %zu B of LDS", lds2);
+        hipLaunchKernelGGL(k_mask_count, dim3(B), dim3(256), lds1, st, patch_mask, g, work);
+        LDN_CHECK_LAUNCH("k_mask_count");
+        hipLaunchKernelGGL(k_mask_index, dim3(B), dim3(256), lds2, st, patch_mask, g, work, idx3, pos3, idx1, pos1, nbr,
+                           cnt, img_prefix3, img_prefix1, stats);
+        LDN_CHECK_LAUNCH("k_mask_index");
+        return LDN_OK;
+    }
+    // bands of output rows (large / detection-size maps)
+    BandGeom bg{};
+    size_t ldsb = 0;
+    LDN_REQUIRE(index_bands(Ho, Wo, stride, &bg.R, &bg.nb, &ldsb), "ldn_mask_to_index: a row of the %dx%d map does not fit the LDS", g.Hi, g.Wi);
+    LDN_REQUIRE((long)B * bg.nb < (1l << 24), "ldn_mask_to_index: too many bands");
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_mask_index_band), ldsb), "k_mask_index_band: cannot reserve %zu B of LDS", ldsb);
+    hipLaunchKernelGGL(k_mask_count_band, dim3((unsigned)B * bg.nb), dim3(256), (size_t)(bg.R + 4) * Wo, st, patch_mask, g, bg, work);
+    LDN_CHECK_LAUNCH("k_mask_count_band");
+    hipLaunchKernelGGL(k_mask_index_band, dim3((unsigned)B * bg.nb), dim3(256), ldsb, st, patch_mask, g, bg, work, idx3, pos3, idx1,
+                       pos1, nbr, cnt, img_prefix3, img_prefix1, stats);
+    LDN_CHECK_LAUNCH("k_mask_index_band");
     return LDN_OK;
 }
 

@@ -404,7 +404,7 @@ class Bottleneck(_PrepCache):
             cache[key] = ops.mask_to_index(torch.ones(B, Ho, Wo, device=dev), Ho, Wo, self.stride)
         return cache[key]
 
-    def _run_channel_dense(self, x, p):
+    def _run_channel_dense(self, x, p, gap_in=None):
         """Channel mode without gathers: conv1/conv2 run over all channels with shared (n-major) weights on row tiles that
         span images, their outputs u = relu(bn(.)) - c are zeroed on the masked channels of each image (exactly what the
         gathered form stores / skips), conv3 reads the zero-filled u2.  Same channel algebra, same results."""
@@ -412,7 +412,10 @@ class Bottleneck(_PrepCache):
         W, gran = self.width, self.channel_dyn_granularity
         Ho, Wo = (Hi - 1) // self.stride + 1, (Wi - 1) // self.stride + 1
         xn = ops.as_nhwc(x)
-        mask, _, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
+        if gap_in is not None and getattr(self.masker_channel, "accepts_fused_gap", False):   # GAP partials left by the producer
+            mask, _, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask, gap=gap_in)
+        else:
+            mask, _, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
         chm = mask.repeat_interleave(gran, dim=1).unsqueeze(1) if gran > 1 else mask.unsqueeze(1)   # [B,1,W]
         dev = x.device
         if "w2_nk" not in p:
@@ -501,7 +504,7 @@ class Bottleneck(_PrepCache):
         if self.channel_exec == "dense" and not dense_ok:
             raise LdnError(f"Bottleneck: channel_exec='dense' needs a square map with Hi == Ho*stride (got {Hi}x{Wi} -> {Ho}x{Wo})")
         if dense_ok and (self.channel_exec == "dense" or (self.channel_exec == "auto" and Ho * Wo <= 64)):
-            return self._run_channel_dense(x, p)
+            return self._run_channel_dense(x, p, gap_in)
         xn = ops.as_nhwc(x)
         if gap_in is not None and getattr(self.masker_channel, "accepts_fused_gap", False):
             mask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask, gap=gap_in)

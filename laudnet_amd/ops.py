@@ -129,7 +129,7 @@ def mask_to_index(patch_mask, out_h, out_w, stride):
                   pos1=torch.empty(cap1, **i32), nbr=torch.empty(cap3 * 9, **i32), cnt=torch.empty(2, **i32),
                   pre3=torch.empty(B + 1, **i32), pre1=torch.empty(B + 1, **i32),
                   stats=torch.empty(3, device=dev, dtype=torch.float32), cap3=cap3, cap1=cap1)
-    work = torch.empty(lib.ldn_mask_to_index_workspace_bytes(B) // 4, **i32)
+    work = torch.empty(max(lib.ldn_mask_to_index_workspace_bytes(B, out_h, out_w, stride) // 4, 1), **i32)
     L.check(lib.ldn_mask_to_index(L.ptr(_f32c(patch_mask, "patch_mask")), B, S, out_h, out_w, stride, L.ptr(ix.idx3),
                                   L.ptr(ix.pos3), L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr), L.ptr(ix.cnt),
                                   L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr()),

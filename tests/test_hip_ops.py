@@ -57,6 +57,50 @@ def test_mask_to_index(ops, B, S, Ho, stride, p):
     assert np.allclose(stats, want, atol=1e-6)
 
 
+def _check_index(ops, patch, Ho, Wo, stride):
+    ix = ops.mask_to_index(patch.to(DEV), Ho, Wo, stride)
+    torch.cuda.synchronize()
+    m3 = IR.upsample_patch_mask(patch.numpy() > 0.5, Ho, Wo)
+    m1 = IR.dilate_mask(m3, stride, 1)
+    idx3, pre3 = IR.nonzero_rows(m3)
+    idx1, pre1 = IR.nonzero_rows(m1)
+    cnt = ix.cnt.cpu().numpy()
+    assert cnt[0] == len(idx3) and cnt[1] == len(idx1)
+    assert np.array_equal(ix.idx3.cpu().numpy()[:cnt[0]], idx3)
+    assert np.array_equal(ix.idx1.cpu().numpy()[:cnt[1]], idx1)
+    assert np.array_equal(ix.pre3.cpu().numpy(), pre3) and np.array_equal(ix.pre1.cpu().numpy(), pre1)
+    assert np.array_equal(ix.pos3.cpu().numpy(), IR.position_map(m3).reshape(-1))
+    assert np.array_equal(ix.pos1.cpu().numpy(), IR.position_map(m1).reshape(-1))
+    nbr = ix.nbr.cpu().numpy().reshape(-1, 9)[:cnt[0]]
+    assert np.array_equal(nbr, IR.neighbour_table(m3, m1, stride))
+    want = np.array([patch.mean().item(), m3.mean(), m1.mean()], dtype=np.float32)
+    assert np.allclose(ix.stats.cpu().numpy(), want, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,S,Ho,Wo,stride,p", [
+    (2, 1, 100, 152, 2, 0.5),      # detection-size layer skip (800x1216 input, stage 2): 200x304 input map, bands of rows
+    (2, 1, 200, 304, 1, 0.5),      # ... stage 1
+    (1, 25, 200, 304, 1, 0.3),     # 8x8 patches on a map that does not fit one workgroup's LDS
+    (3, 7, 120, 120, 1, 0.5), (2, 5, 96, 160, 2, 0.4), (1, 3, 14, 40, 1, 0.5), (2, 4, 9, 23, 2, 0.5),
+])
+def test_mask_to_index_nonsquare_and_large(ops, B, S, Ho, Wo, stride, p):
+    """Non-square maps and maps whose per-image tables exceed one workgroup's LDS (the banded build): bit-exact lists."""
+    _check_index(ops, seeded_bernoulli((B, S, S), p, 11 + B + S + Ho), Ho, Wo, stride)
+
+
+@pytest.mark.parametrize("B,S,Ho,Wo,stride,p", [
+    (3, 14, 14, 14, 1, 0.5), (2, 3, 14, 14, 2, 0.4), (4, 1, 7, 7, 2, 0.5), (2, 7, 28, 28, 2, 0.5), (5, 14, 56, 56, 1, 0.3),
+    (2, 56, 56, 56, 1, 0.5), (8, 7, 7, 7, 2, 0.0), (8, 7, 7, 7, 2, 1.0), (1, 14, 56, 56, 2, 0.5), (2, 9, 28, 20, 1, 0.5),
+])
+def test_mask_to_index_forced_bands(ops, B, S, Ho, Wo, stride, p, monkeypatch):
+    """The banded build forced onto small maps with a tiny LDS budget (one or two rows per band): same lists as the whole-image
+    kernel and the oracle -- every band boundary is exercised (halo rows of mask3, the neighbour rows' positions)."""
+    monkeypatch.setenv("LDN_INDEX_BANDS", "1")
+    for budget in ("1", "6000"):
+        monkeypatch.setenv("LDN_INDEX_BAND_LDS", budget)
+        _check_index(ops, seeded_bernoulli((B, S, S), p, 7 + B + S + Ho), Ho, Wo, stride)
+
+
 def test_gather_scatter(ops):
     rows_total, C = 500, 64
     src = seeded_randn((rows_total, C), 3).to(DEV)

@@ -68,8 +68,8 @@ int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float
 size_t ldn_spatial_masker_workspace_bytes(int B, int Hi, int Wi, int C, int S);
 
 /* ---- a4/a11: F.interpolate(nearest) + ExpandMask x2 -> packed index lists -------------------
- * (laud_resnet.py:106-110, models/utils.py:74-89).  patch_mask [B,S,S] fp32 {0,1} (one mask
- * group) is up-sampled (nearest: src = min(floor(i*float(S)/float(Ho)), S-1)) to the output
+ * (laud_resnet.py:106-110, models/utils.py:74-89).  patch_mask [B,Sy,Sx] fp32 {0,1} (one mask
+ * group) is up-sampled (nearest: src = min(floor(i*float(Sy)/float(Ho)), Sy-1), same for x) to the output
  * resolution Ho x Wo (= mask3 = mask2) and dilated to the block's input resolution
  * Hi x Wi = Ho*stride x Wo*stride with a 3x3 box after zero-insertion (= mask1).
  * Outputs (all row-major over b,y,x; "row" = flat pixel number b*H*W + y*W + x):
@@ -83,8 +83,9 @@ size_t ldn_spatial_masker_workspace_bytes(int B, int Hi, int Wi, int C, int S);
  *   img_prefix3/1 [B+1]  exclusive per-image prefix of the two lists
  *   stats [3]        {mean(patch_mask), mean(mask2 pixels), mean(mask1 pixels)}  (the three
  *                    spatial sparsities of laud_resnet.py:98,108,110)
- * work: int32 scratch of 3*B entries. */
-int ldn_mask_to_index(const float* patch_mask, int B, int S, int Ho, int Wo, int stride, int32_t* idx3,
+ * work: int32 scratch of ldn_mask_to_index_workspace_bytes (3 entries per image; per (image, band of rows) for maps whose
+ * per-image tables do not fit one workgroup's LDS -- those are built by bands of output rows, same lists). */
+int ldn_mask_to_index(const float* patch_mask, int B, int Sy, int Sx, int Ho, int Wo, int stride, int32_t* idx3,
                       int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
                       int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work, void* stream);
 size_t ldn_mask_to_index_workspace_bytes(int B, int Ho, int Wo, int stride);
@@ -182,7 +183,7 @@ int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, in
  *   w3_pairs [width/2][cout][8 B]  entry (kp, c) = bf16 {hi(w3[c][2kp]), hi(w3[c][2kp+1]), lo(..), lo(..)}, w3 = bn3.scale * conv3.weight
  *   u   = relu(scale2[n] * conv2 + shift2_tab[class(pixel)][n]) - post_sub2[n]      (16 border classes as in ldn_conv_image)
  *   out = relu(w3 . u + shift3 + residual)          out/residual [B*H*Wd][ldo/ldr] fp32, may alias (in-place residual stream)
- *   colsum (optional) [B][ldn_bottleneck_tail_splits(H, Wd)][cout]: partial sums of out over disjoint pixel sets covering
+ *   colsum (optional) [B][ldn_bottleneck_tail_splits(H, Wd, width)][cout]: partial sums of out over disjoint pixel sets covering
  *   the image (the next block's channel masker takes them as gap_partial). */
 /* conv1 of the same block in the same style (k_head): h1 = relu(scale1 * conv1x1(x)[active channels] + shift1) - post_sub1, written
  * in out_format 1 for ldn_bottleneck_tail (laud_resnet.py:115-118).  x [B*HW][ldx] fp32, cin % 32 == 0;
@@ -191,7 +192,7 @@ int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, in
 int ldn_bottleneck_head(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
                         const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
                         const float* post_sub1, void* h1_split, int ldh, void* stream);
-int ldn_bottleneck_tail_splits(int H, int Wd);
+int ldn_bottleneck_tail_splits(int H, int Wd, int width);   /* 0 = this map / width does not fit the fused tail */
 int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int width, const void* w2_pairs,
                         const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale2,
                         const float* shift2_tab, const float* post_sub2, const float* shift3, const float* residual,

@@ -22,7 +22,7 @@ SIGNATURES = {
     "ldn_default_math_mode": ([], _I),
     "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P], _I),
     "ldn_spatial_masker_workspace_bytes": ([_I, _I, _I, _I, _I], C.c_size_t),
-    "ldn_mask_to_index": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "ldn_mask_to_index": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "ldn_mask_to_index_workspace_bytes": ([_I, _I, _I, _I], C.c_size_t),
     "ldn_gather_rows": ([_P, _I, _P, _P, _I, _I, _P, _I, _P], _I),
     "ldn_scatter_add_relu": ([_P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P], _I),
@@ -41,7 +41,7 @@ SIGNATURES = {
     "ldn_conv_image": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I,
                         _P, _I, _P, _I, _P, _I, _I, _P], _I),
     "ldn_bottleneck_head": ([_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P], _I),
-    "ldn_bottleneck_tail_splits": ([_I, _I], _I),
+    "ldn_bottleneck_tail_splits": ([_I, _I, _I], _I),
     "ldn_bottleneck_tail": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
     "ldn_stem_weight_bytes": ([_I], C.c_size_t),
     "ldn_stem_conv_pool": ([_P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P], _I),

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------- a4 / a11
 struct IdxGeom {
-    int B, S, Ho, Wo, stride, Hi, Wi;
+    int B, S, Sx, Ho, Wo, stride, Hi, Wi;      // patch mask [B][S][Sx]
 };
 
 __device__ __forceinline__ int nearest_src(int i, float scale, int S) {
@@ -126,12 +126,12 @@ __device__ __forceinline__ int nearest_src(int i, float scale, int S) {
 // fills s_m3[Ho*Wo] (bytes) for image b; returns nothing. all threads participate.
 __device__ __forceinline__ void fill_mask3(const float* __restrict__ patch, const IdxGeom g, int b,
                                            unsigned char* s_m3) {
-    const float sh = (float)g.S / (float)g.Ho, sw = (float)g.S / (float)g.Wo;
+    const float sh = (float)g.S / (float)g.Ho, sw = (float)g.Sx / (float)g.Wo;
     const int n = g.Ho * g.Wo;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int y = i / g.Wo, x = i - y * g.Wo;
-        const int sy = nearest_src(y, sh, g.S), sx = nearest_src(x, sw, g.S);
-        s_m3[i] = patch[((size_t)b * g.S + sy) * g.S + sx] > 0.5f ? 1 : 0;
+        const int sy = nearest_src(y, sh, g.S), sx = nearest_src(x, sw, g.Sx);
+        s_m3[i] = patch[((size_t)b * g.S + sy) * g.Sx + sx] > 0.5f ? 1 : 0;
     }
 }
 
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_mask_count(const float* __restrict__ pa
         const int iy = i / g.Wi, ix = i - iy * g.Wi;
         c1 += mask1_at(s_m3, g, iy, ix) ? 1 : 0;
     }
-    for (int i = threadIdx.x; i < g.S * g.S; i += 256) cp += patch[(size_t)b * g.S * g.S + i] > 0.5f ? 1 : 0;
+    for (int i = threadIdx.x; i < g.S * g.Sx; i += 256) cp += patch[(size_t)b * g.S * g.Sx + i] > 0.5f ? 1 : 0;
     atomicAdd(&s_red[0], c3);   // integer LDS atomics: order-independent
     atomicAdd(&s_red[1], c1);
     atomicAdd(&s_red[2], cp);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ pa
             pre1[g.B] = tot1;
             cnt[0] = tot3;
             cnt[1] = tot1;
-            stats[0] = (float)s_base[2] / (float)((long)g.B * g.S * g.S);
+            stats[0] = (float)s_base[2] / (float)((long)g.B * g.S * g.Sx);
             stats[1] = (float)tot3 / (float)((long)g.B * HWo);
             stats[2] = (float)tot1 / (float)((long)g.B * HWi);
         }
@@ -285,14 +285,14 @@ struct BandGeom {
 
 __device__ __forceinline__ void fill_mask3_rows(const float* __restrict__ patch, const IdxGeom g, int b, int ya, int yb,
                                                 unsigned char* s_m3) {   // rows [ya, yb) -> s_m3[(y - ya) * Wo + x]; rows outside the map = 0
-    const float sh = (float)g.S / (float)g.Ho, sw = (float)g.S / (float)g.Wo;
+    const float sh = (float)g.S / (float)g.Ho, sw = (float)g.Sx / (float)g.Wo;
     const int n = (yb - ya) * g.Wo;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int y = ya + i / g.Wo, x = i % g.Wo;
         unsigned char v = 0;
         if (y >= 0 && y < g.Ho) {
-            const int sy = nearest_src(y, sh, g.S), sx = nearest_src(x, sw, g.S);
-            v = patch[((size_t)b * g.S + sy) * g.S + sx] > 0.5f ? 1 : 0;
+            const int sy = nearest_src(y, sh, g.S), sx = nearest_src(x, sw, g.Sx);
+            v = patch[((size_t)b * g.S + sy) * g.Sx + sx] > 0.5f ? 1 : 0;
         }
         s_m3[i] = v;
     }
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_mask_count_band(const float* __restrict
         c1 += mask1_rows(s_m3, g, ya, iy, ix) ? 1 : 0;
     }
     if (j == 0)
-        for (int i = threadIdx.x; i < g.S * g.S; i += 256) cp += patch[(size_t)b * g.S * g.S + i] > 0.5f ? 1 : 0;
+        for (int i = threadIdx.x; i < g.S * g.Sx; i += 256) cp += patch[(size_t)b * g.S * g.Sx + i] > 0.5f ? 1 : 0;
     atomicAdd(&s_red[0], c3);
     atomicAdd(&s_red[1], c1);
     atomicAdd(&s_red[2], cp);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void k_mask_index_band(const float* __restrict
             pre1[g.B] = tot1;
             cnt[0] = tot3;
             cnt[1] = tot1;
-            stats[0] = (float)s_base[2] / (float)((long)g.B * g.S * g.S);
+            stats[0] = (float)s_base[2] / (float)((long)g.B * g.S * g.Sx);
             stats[1] = (float)tot3 / (float)((long)g.B * HWo);
             stats[2] = (float)tot1 / (float)((long)g.B * HWi);
         }
@@ -682,15 +682,15 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
     return LDN_OK;
 }
 
-extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Ho, int Wo, int stride, int32_t* idx3,
+extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, int Ho, int Wo, int stride, int32_t* idx3,
                                  int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
                                  int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work,
                                  void* stream) {
     LDN_REQUIRE(patch_mask && idx3 && pos3 && idx1 && pos1 && nbr && cnt && img_prefix3 && img_prefix1 && stats && work,
                 "ldn_mask_to_index: null pointer");
-    LDN_REQUIRE(B > 0 && S > 0 && Ho > 0 && Wo > 0 && stride >= 1, "ldn_mask_to_index: bad shape");
+    LDN_REQUIRE(B > 0 && S > 0 && Sx > 0 && Ho > 0 && Wo > 0 && stride >= 1, "ldn_mask_to_index: bad shape");
     LDN_REQUIRE((long)B * Ho * stride * Wo * stride < (1l << 31), "ldn_mask_to_index: index space exceeds int32");
-    IdxGeom g{B, S, Ho, Wo, stride, Ho * stride, Wo * stride};
+    IdxGeom g{B, S, Sx, Ho, Wo, stride, Ho * stride, Wo * stride};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds1 = (size_t)Ho * Wo;
     const size_t lds2 = (size_t)Ho * Wo * 5 + (size_t)g.Hi * g.Wi * 4;

@@ -497,10 +497,21 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_tail(const TailArgs 
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_tail)
 
-static int tail_rows_per_block(int Ho, int Wo, int* mblocks) {
+// bytes of LDS of the conv2 phase for blocks of R output rows of an Ho x Wo map (NS = width / 32)
+static size_t tail_lds2(int R, int Ho, int Wo, int NS) {
+    const int nr = min(R + 2, Ho) * Wo;
+    const size_t slice = (size_t)round_up((round_up(nr, 8) + 1) * 128, 1024);
+    return (size_t)T_KIDX_BYTES + (NS == 2 ? 1 : 2) * slice + (size_t)T_W2_SLOTS * 16 * NS * 256;
+}
+
+// output rows per workgroup: as many as 256 pixels, the 160 KiB of LDS and the 72-piece slice pipeline allow; 0 = the map does not fit
+static int tail_rows_per_block(int Ho, int Wo, int NS, int* mblocks) {
     int R = 256 / Wo;
-    if (R < 1) R = 1;
+    if (R < 1) return 0;
     if (R > Ho) R = Ho;
+    auto fits = [&](int r) { return tail_lds2(r, Ho, Wo, NS) <= 160 * 1024 && round_up(min(r + 2, Ho) * Wo, 8) / 8 <= 72; };
+    while (R > 1 && !fits(R)) --R;
+    if (!fits(R)) return 0;
     const int mbk = ceil_div(Ho, R);
     *mblocks = mbk;
     return ceil_div(Ho, mbk);
@@ -512,7 +523,7 @@ static int launch_tail(TailArgs& a, hipStream_t st) {
     const int R = a.rows_per_blk;
     const int nr = min(R + 2, a.Hi) * a.Wi;
     a.slice_bytes = round_up((round_up(nr, 8) + 1) * 128, 1024);
-    const size_t lds2 = (size_t)T_KIDX_BYTES + (NS == 2 ? 1 : 2) * (size_t)a.slice_bytes + (size_t)T_W2_SLOTS * 16 * NS * 256;
+    const size_t lds2 = tail_lds2(R, a.Hi, a.Wi, NS);
     const size_t lds3 = (size_t)T_KIDX_BYTES + 2 * (size_t)(W / 2) * (NS == 8 ? 32 : 64) * 8 + (size_t)18 * W * 4 + 8 * 4096;
     const size_t lds = lds2 > lds3 ? lds2 : lds3;
     LDN_REQUIRE(lds <= 160 * 1024, "ldn_bottleneck_tail: %zu B of LDS exceed 160 KiB (map %dx%d, width %d)", lds, a.Ho, a.Wo, W);
@@ -534,10 +545,10 @@ extern "C" int ldn_debug_set_tail_trace(void* buf) {
 }
 #endif
 
-extern "C" int ldn_bottleneck_tail_splits(int Ho, int Wo) {
+extern "C" int ldn_bottleneck_tail_splits(int Ho, int Wo, int width) {
     int mbk = 0;
-    if (Ho < 1 || Wo < 1 || Wo > 256) return 0;
-    (void)tail_rows_per_block(Ho, Wo, &mbk);
+    if (Ho < 1 || Wo < 1 || Wo > 256 || (width != 64 && width != 128 && width != 256)) return 0;
+    if (tail_rows_per_block(Ho, Wo, width / 32, &mbk) == 0) return 0;
     return mbk * 8;
 }
 
@@ -566,7 +577,8 @@ extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, 
     a.k_idx = ch_idx; a.k_cnt = ch_cnt;
     a.sc2 = scale2; a.sh2 = shift2_tab; a.ps2 = post_sub2; a.sh3 = shift3;
     a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo; a.colsum = colsum;
-    a.rows_per_blk = tail_rows_per_block(H, Wd, &a.mblocks);
+    a.rows_per_blk = tail_rows_per_block(H, Wd, width / 32, &a.mblocks);
+    LDN_REQUIRE(a.rows_per_blk > 0, "ldn_bottleneck_tail: a %dx%d map of width %d does not fit the workgroup (ldn_bottleneck_tail_splits == 0)", H, Wd, width);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (width == 64) return launch_tail<2>(a, st);
     if (width == 128) return launch_tail<4>(a, st);

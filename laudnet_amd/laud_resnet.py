@@ -399,9 +399,7 @@ class Bottleneck(_PrepCache):
         key = (B, Ho, Wo, self.stride, str(dev))
         cache = self.__dict__.setdefault("_dense_ix_cache", {})
         if key not in cache:
-            if Ho != Wo:
-                raise LdnError("Bottleneck: dense channel execution needs square maps")
-            cache[key] = ops.mask_to_index(torch.ones(B, Ho, Wo, device=dev), Ho, Wo, self.stride)
+            cache[key] = ops.mask_to_index(torch.ones(B, 1, 1, device=dev), Ho, Wo, self.stride)
         return cache[key]
 
     def _run_channel_dense(self, x, p, gap_in=None):
@@ -467,7 +465,7 @@ class Bottleneck(_PrepCache):
         return (self.use_fused_tail and self.channel_exec in ("auto", "fused") and ops.get_math_mode() == "bf16x3"
                 and self.stride == 1 and (Hi, Wi) == (Ho, Wo) and self.channel_dyn_granularity % 2 == 0
                 and self.width in (64, 128, 256) and Wo <= 256 and cout % 64 == 0
-                and (min(Ho, 256 // Wo) + 2) * Wo <= 576)
+                and ops.bottleneck_tail_splits(Ho, Wo, self.width) > 0)    # LDS / slice-pipeline limits, decided by the library
 
     def tail_weights(self, p):
         """conv2 / conv3 weights in the pre-split pair-interleaved layouts of ldn_bottleneck_tail (built once, cached with the
@@ -500,9 +498,9 @@ class Bottleneck(_PrepCache):
         # dense execution uses the packed-row machinery, whose index set hard-codes Hi = Ho*stride on square maps: odd maps in
         # front of a stride-2 block (208 / 240 px inputs: 13x13, 15x15) and non-square maps stay on the gather path, which
         # takes the geometry explicitly
-        dense_ok = Ho == Wo and Hi == Ho * self.stride and Wi == Wo * self.stride
+        dense_ok = Hi == Ho * self.stride and Wi == Wo * self.stride
         if self.channel_exec == "dense" and not dense_ok:
-            raise LdnError(f"Bottleneck: channel_exec='dense' needs a square map with Hi == Ho*stride (got {Hi}x{Wi} -> {Ho}x{Wo})")
+            raise LdnError(f"Bottleneck: channel_exec='dense' needs Hi == Ho*stride (got {Hi}x{Wi} -> {Ho}x{Wo})")
         if dense_ok and (self.channel_exec == "dense" or (self.channel_exec == "auto" and Ho * Wo <= 64)):
             return self._run_channel_dense(x, p, gap_in)
         xn = ops.as_nhwc(x)
@@ -542,7 +540,7 @@ class Bottleneck(_PrepCache):
                 ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1, out_split=True)
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)
-            gap_out = (torch.empty(B, ops.bottleneck_tail_splits(Ho, Wo), cout, device=dev, dtype=torch.float32)
+            gap_out = (torch.empty(B, ops.bottleneck_tail_splits(Ho, Wo, W), cout, device=dev, dtype=torch.float32)
                        if want_gap else None)
             ops.bottleneck_tail(h1, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], out, residual=identity,
                                 colsum=gap_out)
@@ -567,9 +565,7 @@ class Bottleneck(_PrepCache):
     def _run_spatial(self, x, p):
         B, Cin, Hi, Wi = x.shape
         W = self.width
-        Ho = Wo = self.output_size
-        if Hi != Ho * self.stride or Wi != Wo * self.stride:
-            raise LdnError(f"Bottleneck: input {Hi}x{Wi} does not match output_size {Ho} * stride {self.stride}")
+        Ho, Wo = self._out_hw(Hi, Wi)
         ms = self.masker_spatial
         G = ms.mask_channel_group
         xn = ops.as_nhwc(x)
@@ -624,9 +620,7 @@ class Bottleneck(_PrepCache):
         """dyn_mode 'both' (laud_resnet.py:101-103): packed pixel lists (spatial mask) x per-image channel lists."""
         B, Cin, Hi, Wi = x.shape
         W, gran = self.width, self.channel_dyn_granularity
-        Ho = Wo = self.output_size
-        if Hi != Ho * self.stride or Wi != Wo * self.stride:
-            raise LdnError(f"Bottleneck: input {Hi}x{Wi} does not match output_size {Ho} * stride {self.stride}")
+        Ho, Wo = self._out_hw(Hi, Wi)
         ms = self.masker_spatial
         if ms.mask_channel_group != 1:
             raise LdnError("HIP path: spatial_mask_channel_group > 1 is not built (all shipped configs use 1)")
@@ -662,6 +656,15 @@ class Bottleneck(_PrepCache):
                         out_map=ix.idx3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual2d=resid)
         self.last_channel_mask, self.last_spatial_mask = cmask, patch
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), cmask, ix
+
+    def _out_hw(self, Hi, Wi):
+        """Output map of the block for an Hi x Wi input.  The masks are interpolated to the ACTUAL output map (what the
+        reference's detection backbone does, lad_mmdet_resnet.py:274; on the classifier's own input size it is output_size, as
+        laud_resnet.py:106 hard-codes): non-square and non-224 inputs work.  The packed-row index build needs Hi = Ho * stride."""
+        s = self.stride
+        if Hi % s or Wi % s:
+            raise LdnError(f"Bottleneck: a {Hi}x{Wi} input is not a multiple of the block's stride {s} (spatial / layer / both modes)")
+        return Hi // s, Wi // s
 
     def _ds_rows(self, B, Hi, Wi, Ho, Wo, s, dev):
         key = (B, Hi, Wi, s, str(dev))
@@ -820,6 +823,19 @@ class ResNet(nn.Module):
     def forward(self, x, temperature):
         _eval_only(self, x)
         in_shape = tuple(x.shape)
+        x = self._stem_forward(x)
+        x, stats, sizes = self._run_blocks(x)
+        st = self._stack_stats(stats, x.device)                    # [n_blocks, 4] = s3, s2, s1, cs
+        s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+        perc, flops = self.flops_from_sparsities(in_shape, s3, s2, s1, cs)
+
+        x = self.avgpool(x)
+        x = torch.flatten(x, 1)
+        x = self.fc(x)
+        split = lambda v: list(torch.split(v, sizes))
+        return x, split(s3), split(s2), split(s1), split(cs), perc, flops
+
+    def _stem_forward(self, x):
         # static stem (laud_resnet.py:318-324): plain library ops, channels-last so the blocks see NHWC rows
         x = x.contiguous(memory_format=torch.channels_last)
         # eval-mode stem = conv with bn1's scale folded into its weights, then max-pool, then bn1's shift and the ReLU on the POOLED
@@ -833,11 +849,17 @@ class ResNet(nn.Module):
             x = F.conv2d(x, w, None, self.conv1.stride, self.conv1.padding)
             x = self.maxpool(x).add_(b.view(1, -1, 1, 1)).relu_()
 
+        return x
+
+    def _run_blocks(self, x, stage_outs=None):
+        """The four stages on the HIP path.  Returns (x, per-block stats, blocks per stage); stage_outs (a list) receives every
+        stage's output map (the detection backbone's feature taps)."""
         # dynamic blocks: each returns its 4 sparsities as a device vector; the FLOPs bookkeeping of
         # laud_resnet.py:112-147,329-347 is done ONCE below on [n_blocks] vectors (no per-block scalar kernels)
         stats = []
         blocks = [blk for i in range(4) for blk in getattr(self, f"layer{i + 1}")]
         sizes = [len(getattr(self, f"layer{i + 1}")) for i in range(4)]
+        ends = set(itertools.accumulate(sizes))        # a stage's output = the output of its last block
         gap = None
         j = -1
         while j + 1 < len(blocks):
@@ -854,6 +876,8 @@ class ResNet(nn.Module):
                 if not (nxt is not None and nxt.dyn_mode == "channel" and nxt.forced_channel_mask is None
                         and getattr(nxt.masker_channel, "accepts_fused_gap", False)):
                     gap = None
+                if stage_outs is not None and j + 1 in ends:
+                    stage_outs.append(x)
                 continue
             # a channel-mode block leaves the GAP partials of its output for the next block's MLP masker
             want_gap = (nxt is not None and blk.dyn_mode == "channel" and nxt.dyn_mode == "channel"
@@ -863,15 +887,9 @@ class ResNet(nn.Module):
             x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap, defer_stats=True, inplace=self.inplace_residual)
             gap = getattr(blk, "last_gap", None) if want_gap else None
             stats.append(st)
-        st = self._stack_stats(stats, x.device)                    # [n_blocks, 4] = s3, s2, s1, cs
-        s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
-        perc, flops = self.flops_from_sparsities(in_shape, s3, s2, s1, cs)
-
-        x = self.avgpool(x)
-        x = torch.flatten(x, 1)
-        x = self.fc(x)
-        split = lambda v: list(torch.split(v, sizes))
-        return x, split(s3), split(s2), split(s1), split(cs), perc, flops
+            if stage_outs is not None and j + 1 in ends:
+                stage_outs.append(x)
+        return x, stats, sizes
 
     # ---- chained execution of a run of blocks (ldn_bottleneck_chain)
     use_chain = os.environ.get("LDN_CHAIN", "1") != "0"     # class-level switch (A/B measurements, tests): False launches every block on its own
@@ -954,9 +972,12 @@ class ResNet(nn.Module):
                 terms.append(blk.flops_terms((1, c, h, w)))
                 c = blk.conv3.out_channels
                 h, w = (h - 1) // blk.stride + 1, (w - 1) // blk.stride + 1
-        static += c            # adaptive average pool to 1x1: x.shape[1] * 1 * 1 after pooling (laud_resnet.py:350)
-        static += c * self.fc.out_features
+        static += self._head_flops(c)
         return terms, static
+
+    def _head_flops(self, c):
+        """adaptive average pool to 1x1 (x.shape[1] * 1 * 1 after pooling, laud_resnet.py:350) + classifier (:356)"""
+        return c + c * self.fc.out_features
 
     def flops_from_sparsities(self, x_shape, s3, s2, s1, cs):
         """(flops_perc [n_blocks], flops) from per-block sparsities (flat [n_blocks] tensors or per-stage lists).  This is the

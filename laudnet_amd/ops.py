@@ -116,12 +116,12 @@ class IndexSet:
 
 
 def mask_to_index(patch_mask, out_h, out_w, stride):
-    """patch_mask [B,S,S] float {0,1} -> packed index lists (see ldn_mask_to_index)."""
+    """patch_mask [B,Sy,Sx] float {0,1} -> packed index lists (see ldn_mask_to_index)."""
     L.require_device(patch_mask)
     lib = L.load()
-    if patch_mask.dim() != 3 or patch_mask.shape[1] != patch_mask.shape[2]:
-        raise L.LdnError("mask_to_index: patch_mask must be [B,S,S]")
-    B, S, _ = patch_mask.shape
+    if patch_mask.dim() != 3:
+        raise L.LdnError("mask_to_index: patch_mask must be [B,Sy,Sx]")
+    B, S, Sx = patch_mask.shape
     dev = patch_mask.device
     cap3, cap1 = B * out_h * out_w, B * out_h * stride * out_w * stride
     i32 = dict(device=dev, dtype=torch.int32)
@@ -130,7 +130,7 @@ def mask_to_index(patch_mask, out_h, out_w, stride):
                   pre3=torch.empty(B + 1, **i32), pre1=torch.empty(B + 1, **i32),
                   stats=torch.empty(3, device=dev, dtype=torch.float32), cap3=cap3, cap1=cap1)
     work = torch.empty(max(lib.ldn_mask_to_index_workspace_bytes(B, out_h, out_w, stride) // 4, 1), **i32)
-    L.check(lib.ldn_mask_to_index(L.ptr(_f32c(patch_mask, "patch_mask")), B, S, out_h, out_w, stride, L.ptr(ix.idx3),
+    L.check(lib.ldn_mask_to_index(L.ptr(_f32c(patch_mask, "patch_mask")), B, S, Sx, out_h, out_w, stride, L.ptr(ix.idx3),
                                   L.ptr(ix.pos3), L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr), L.ptr(ix.cnt),
                                   L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr()),
             "ldn_mask_to_index")
@@ -451,8 +451,9 @@ def bottleneck_chain(x_in, x_work, table, width, hidden, G, gran, gap_in):
     return masks, ch_idx, ch_cnt, colsum
 
 
-def bottleneck_tail_splits(H, W):
-    return L.load().ldn_bottleneck_tail_splits(H, W)
+def bottleneck_tail_splits(H, W, width):
+    """GAP partial slots of the fused tail on an H x W map (0: the map / width does not fit ldn_bottleneck_tail)."""
+    return L.load().ldn_bottleneck_tail_splits(H, W, width)
 
 
 def bottleneck_tail(h1_split, w2_pairs, w3_pairs, ch_idx, ch_cnt, scale2, shift2_tab, post_sub2, shift3, out_nhwc, *,

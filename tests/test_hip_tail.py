@@ -83,7 +83,7 @@ def test_tail_vs_reference_algebra(ops, B, H, cin, W, gran, down):
             assert bool((dech[b, :, :, n:pad] == 0).all()), "k_head: columns up to the next multiple of 32 must be zero"
         h1s = h1h     # the tail below consumes k_head's output
     idn = ident.permute(0, 2, 3, 1).contiguous().to(DEV)
-    splits = ops.bottleneck_tail_splits(H, H)
+    splits = ops.bottleneck_tail_splits(H, H, W)
     colsum = torch.full((B, splits, cout), float("nan"), device=DEV)
     out = torch.full((B, H, H, cout), float("nan"), device=DEV)
     ops.bottleneck_tail(h1s, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], out, residual=idn, colsum=colsum)

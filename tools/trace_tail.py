@@ -25,7 +25,7 @@ tab = torch.randn(16, W, device=dev) * 0.1
 tC = torch.randn(Cin, device=dev) * 0.1
 fn = lambda: ops.bottleneck_tail(h1, w2p, w3p, idx, cnt, sW, tab, cW, tC, out, residual=x)
 lib = _lib.load()
-nwg = B * ops.bottleneck_tail_splits(H, H) // 8
+nwg = B * ops.bottleneck_tail_splits(H, H, W) // 8
 trace = torch.zeros(nwg * 8 * 12, dtype=torch.int64, device=dev)
 for _ in range(3):
     fn()

@@ -23,3 +23,12 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA
   echo "== $c   (FETCH_SIZE / WRITE_SIZE in KiB per dispatch)" >> $OUT/r2_pmc_tail.txt
   python $R/tools/rocpd_pmc.py $(ls /tmp/pmc_t/*.db | head -1) k_tail 2>&1 | awk 'NR==1 || !seen[$2$3$4$5$6$7$8]++' | tail -4 >> $OUT/r2_pmc_tail.txt
 done
+# 3. the same PMC passes over the chained stage-3 launch (k_chain: 22 blocks of LAUD-ResNet101 in one launch) inside the bench itself
+rm -f $OUT/r2_pmc_chain.txt
+for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD"; do
+  rm -rf /tmp/pmc_c
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_c -o r -- python $R/bench.py --steps 2 --warmup 1 --no-legs > /tmp/pmc_c.log 2>&1
+  echo "== $c   (FETCH_SIZE / WRITE_SIZE in KiB per dispatch)" >> $OUT/r2_pmc_chain.txt
+  python $R/tools/rocpd_pmc.py $(ls /tmp/pmc_c/*.db | head -1) k_chain 2>&1 | tail -3 >> $OUT/r2_pmc_chain.txt
+done
+python $R/tools/rocpd_period.py $(ls /tmp/prof_channel/*.db | head -1) 15 > $OUT/r2_period_channel.txt 2>&1

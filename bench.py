@@ -608,6 +608,29 @@ def main():
                 if "realised_speedup_fp32_mode" in result:   # the predictor models fp32 FMA lanes: the like-for-like comparison
                     result["realised_over_predicted"]["math_fp32"] = result["realised_speedup_fp32_mode"] / best
                 result["realised_over_predicted"]["predicted"] = best
+    if rank == 0 and args.workload == "channel":
+        # the MI355X-native latency model of THIS implementation (laudnet_amd/predictor.py, calibrated on profiles/r02_density_sweep.jsonl):
+        # predicted step time at the keep probability of this run, and its predicted speedup over the same kernels at density 1
+        try:
+            from laudnet_amd.predictor import Predictor
+            P = Predictor()
+            keep = args.keep if args.keep is not None else wl["p_channel"]
+            ps = P.predicted_speedup(args.batch, density=(keep,) * 4)
+            sweep = os.path.join(ROOT, "profiles", "r02_density_sweep.jsonl")
+            own_dense_ms = None
+            if os.path.exists(sweep) and args.batch == 256:
+                for line in open(sweep):
+                    d = json.loads(line)
+                    if "(keep 1.0)" in d["config"]["workload"]:
+                        own_dense_ms = d["ms_per_step"]
+            result["mi355x_model"] = {
+                "predicted_ms_per_step": ps["dynamic_ms"], "predicted_ms_at_density_1": ps["static_ms"], "predicted_speedup_vs_density_1": ps["speedup"],
+                "measured_over_predicted_ms": result["ms_per_step"] / ps["dynamic_ms"],
+                "realised_speedup_vs_density_1": (own_dense_ms / result["ms_per_step"]) if own_dense_ms else None,
+                "note": "same HIP kernels with every channel kept (keep 1.0, measured once: profiles/r02_density_sweep.jsonl) as the static baseline",
+                "calibration": P.cal.source}
+        except Exception as e:   # informative only
+            result["mi355x_model"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -1,0 +1,275 @@
+"""MI355X latency model of the HIP path ("MI355X-calibrated latency predictor ... with CU / LDS / Infinity-Cache
+terms and MFMA instead of the scalar-lane model").
+
+The reference predicts the latency of its dynamic operators analytically (DyNetSimulator/hardware_models/static_predictor.py
+MultiCoresPredictor, multi_cores.py GPGPUDynamicPredictor: per-operator tile search over scalar fp32 lanes, an L2 / DRAM
+bandwidth pair, latency = max or sum of a compute and a memory term, block formulas eval_example.py:12-122) and uses it to choose
+granularities per hardware.  tools/predict_speedup.py drives that model unmodified (pinned to its V100 numbers).  THIS module is
+the same idea re-derived for what the kernels of this repository actually do on CDNA4 -- it is not a restatement of the
+reference's formulas:
+
+  * work is counted in EXECUTED matrix-core FLOPs: three bf16 MFMA products per fp32 product (bf16x3), active channels padded to
+    the 32-wide MFMA tile (E[32 ceil(K/32)] over the binomial number of active channel groups of an image), pixel tiles of 32;
+  * a channel-mode block is one workgroup per (image, row block) on one CU: its time is a per-phase fixed cost + executed FLOPs /
+    (the CU's MFMA rate x efficiency) + bytes through the CU's memory pipe / (per-CU stream rate) -- phases do not overlap inside a
+    workgroup (measured), so the terms ADD (the reference's latency_mode "add");
+  * bytes through the CU = activations (the block input twice: conv1 operand and residual; h1 out and back with the halo factor
+    of the LDS-resident row block; the output) + the PER-IMAGE gathered weight subsets, which come from the XCD's L2 / the
+    Infinity Cache, not from HBM;
+  * a launch lasts ceil(workgroups / (CUs x workgroups per CU)) rounds (256 CUs; LDS decides the workgroups per CU);
+  * density-independent launches (stem, projection shortcuts, the dense execution of stage 4, the stride-2 first blocks' gathered
+    convs at their measured efficiency) are priced with a roofline: max(executed FLOPs / (2.5 PFLOP/s x eta_mfma), HBM bytes /
+    (8 TB/s x eta_hbm)) + launch.
+
+The free constants (per-CU MFMA efficiency, HBM efficiency of the activation streams, per-CU L2 gather rate, dense-kernel MFMA
+efficiency, a per-forward residual) are FITTED to
+measurements of this repository on MI355X (tools/calibrate_predictor.py -> profiles/r02_predictor_calibration.json: the step
+time and the chained stage-3 block time of LAUD-ResNet101 bs256 at seven keep probabilities); tests/test_predictor.py checks
+the fit against the committed measurements.  Use: `predict_resnet(...)`, `predicted_speedup(...)`, `best_channel_granularity(...)`.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from dataclasses import dataclass, field
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALIBRATION = os.path.join(ROOT, "profiles", "r02_predictor_calibration.json")
+
+
+@dataclass
+class MI355X:
+    """MI355X_MICROARCH.md: 256 CUs in 8 XCDs, 4 SIMDs per CU, v_mfma_f32_32x32x16_bf16 = 32768 FLOP in 32 cycles per SIMD
+    (1024 FLOP / clk / SIMD -> 2.5 PFLOP/s dense bf16 at 2.4 GHz), 8 TB/s HBM3E, 256 MB Infinity Cache, 160 KB LDS per CU."""
+    cus: int = 256
+    simds: int = 4
+    mfma_flop_per_clk_simd: float = 1024.0
+    clock_hz: float = 2.4e9
+    hbm_bytes_per_s: float = 8.0e12
+    infinity_cache_bytes: float = 256e6
+    lds_bytes: int = 160 * 1024
+
+    @property
+    def mfma_peak(self) -> float:
+        return self.cus * self.simds * self.mfma_flop_per_clk_simd * self.clock_hz
+
+    @property
+    def cu_mfma_peak(self) -> float:
+        return self.simds * self.mfma_flop_per_clk_simd * self.clock_hz
+
+
+@dataclass
+class Calibration:
+    """Fitted constants (defaults = the round-2 fit; profiles/r02_predictor_calibration.json overrides them)."""
+    cu_mfma_eff: float = 0.5          # fraction of a CU's MFMA peak a per-image workgroup sustains inside its matrix phases
+    act_hbm_eff: float = 0.7          # fraction of 8 TB/s the per-image workgroups' activation streams reach together
+    cu_l2_bytes_per_s: float = 60e9   # bytes / s one CU gathers its image's weight subsets from the XCD's L2 (LDS-DMA)
+    phase_cost_s: float = 4.0e-6      # fixed cost per phase of a per-image workgroup (set-up 9 k + conversion 14 k cycles per block)
+    dense_mfma_eff: float = 0.28      # shared-weight row kernels (k_dense / dense k_conv_bf3 / streaming 1x1): fraction of the chip's peak
+    hbm_eff: float = 0.6              # fraction of 8 TB/s a streaming kernel reaches
+    co_resident_gain: float = 1.3     # throughput gain of two co-resident workgroups per CU (64-wide layers) over one
+    launch_s: float = 6.0e-6          # launch gap between dependent kernels
+    fixed_s: float = 0.0              # residual per forward (bookkeeping kernels, pooling, classifier)
+    source: str = "defaults"
+
+    @staticmethod
+    def load(path: str = CALIBRATION) -> "Calibration":
+        c = Calibration()
+        if os.path.exists(path):
+            d = json.load(open(path))
+            for k, v in d.get("constants", {}).items():
+                if hasattr(c, k):
+                    setattr(c, k, v)
+            c.source = os.path.relpath(path, ROOT)
+        return c
+
+
+# ------------------------------------------------------------------------------------------------ counting
+def expected_padded_channels(groups: int, gran: int, density: float, tile: int = 32) -> float:
+    """E[tile * ceil(K / tile)] with K = gran * Binomial(groups, density): the MFMA tile padding of an image's active subset."""
+    if density >= 1.0:
+        return float(tile * math.ceil(groups * gran / tile))
+    if density <= 0.0:
+        return 0.0
+    e = 0.0
+    logp, logq = math.log(density), math.log1p(-density)
+    for k in range(groups + 1):
+        lp = math.lgamma(groups + 1) - math.lgamma(k + 1) - math.lgamma(groups - k + 1) + k * logp + (groups - k) * logq
+        e += math.exp(lp) * tile * math.ceil(k * gran / tile)
+    return e
+
+
+def expected_padded_sq(groups: int, gran: int, density: float, tile: int = 32) -> float:
+    """E[(tile * ceil(K / tile))^2]: the 3x3 conv gathers inputs AND outputs."""
+    if density >= 1.0:
+        return float((tile * math.ceil(groups * gran / tile)) ** 2)
+    if density <= 0.0:
+        return 0.0
+    e = 0.0
+    logp, logq = math.log(density), math.log1p(-density)
+    for k in range(groups + 1):
+        lp = math.lgamma(groups + 1) - math.lgamma(k + 1) - math.lgamma(groups - k + 1) + k * logp + (groups - k) * logq
+        e += math.exp(lp) * (tile * math.ceil(k * gran / tile)) ** 2
+    return e
+
+
+@dataclass
+class BlockShape:
+    cin: int
+    width: int
+    cout: int
+    h_in: int
+    w_in: int
+    stride: int
+    downsample: bool
+    gran: int = 2
+
+    @property
+    def h(self):
+        return self.h_in // self.stride
+
+    @property
+    def w(self):
+        return self.w_in // self.stride
+
+
+def resnet_blocks(layers=(3, 4, 23, 3), input_hw=(224, 224), gran=(2, 2, 2, 2), base=64):
+    """Block shapes of a LAUD-ResNet (laud_resnet.py:208-250): [(stage, BlockShape)]."""
+    h, w = input_hw[0] // 4, input_hw[1] // 4
+    cin = base
+    out = []
+    for s, n in enumerate(layers):
+        width = base * 2 ** s
+        for j in range(n):
+            stride = 2 if (j == 0 and s > 0) else 1
+            out.append((s, BlockShape(cin, width, 4 * width, h, w, stride, j == 0, gran[s])))
+            h, w = h // stride, w // stride
+            cin = 4 * width
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ kernel models
+@dataclass
+class Predictor:
+    hw: MI355X = field(default_factory=MI355X)
+    cal: Calibration = field(default_factory=Calibration.load)
+
+    # -- per-image workgroups (k_head / k_tail / k_chain): one workgroup = one image x one block of output rows
+    def rows_per_workgroup(self, b: BlockShape) -> tuple:
+        """(output rows per workgroup, workgroups per image, halo factor of h1): at most 256 pixels per workgroup (8 waves x 32)."""
+        r = max(1, min(b.h, 256 // b.w))
+        mb = math.ceil(b.h / r)
+        r = math.ceil(b.h / mb)
+        return r, mb, min(r + 2, b.h) / r
+
+    def fused_block(self, b: BlockShape, batch: int, density: float, chained: bool) -> dict:
+        """conv1 + conv2 + conv3 of a stride-1 channel-mode block as per-image workgroups (two launches, or a share of the chained
+        stage launch).  Returns seconds and the terms."""
+        G = b.width // b.gran
+        kp = expected_padded_channels(G, b.gran, density)
+        kp2 = expected_padded_sq(G, b.gran, density)
+        k64 = expected_padded_channels(G, b.gran, density, 64)
+        r, mb, halo = self.rows_per_workgroup(b)
+        px = r * b.w
+        px_pad = 32 * math.ceil(px / 32)                       # one wave per 32 pixels
+        flops = 6.0 * px_pad * (b.cin * kp + 9.0 * kp2 + kp * b.cout)          # executed: 3 bf16 products per fp32 product
+        act = 4.0 * px * (b.cin + 2.0 * b.cout) + 4.0 * px * kp * (1.0 + halo)    # x, residual, out; h1 written once, staged with its halo
+        wts = 4.0 * (k64 * b.cin + 9.0 * kp2 + kp * b.cout)                        # per-image gathered subsets (L2 / Infinity Cache)
+        phases = 3 if chained else 4                             # masker | conv1 | conv2 | conv3 (chained: the masker rides along)
+        # activations stream from HBM / the Infinity Cache while every CU does the same: a CU's share of the chip's rate;
+        # the gathered weights are re-read by every image from the XCD's L2 at the per-CU rate
+        act_rate = self.hw.hbm_bytes_per_s * self.cal.act_hbm_eff / self.hw.cus
+        t_wg = phases * self.cal.phase_cost_s + flops / (self.hw.cu_mfma_peak * self.cal.cu_mfma_eff) + \
+            act / act_rate + wts / self.cal.cu_l2_bytes_per_s
+        wgs = batch * mb
+        # 64-wide layers fit two workgroups per CU (LDS), whose matrix and memory phases overlap each other: priced as one
+        # workgroup slot per CU running at 1 / co_resident_gain of the solo time
+        gain = self.cal.co_resident_gain if b.width <= 64 else 1.0
+        rounds = math.ceil(wgs / self.hw.cus)
+        t = rounds * t_wg / gain
+        if not chained:
+            t += 2 * self.cal.launch_s
+        return {"s": t, "flops": flops * wgs, "cu_bytes": (act + wts) * wgs, "rounds": rounds, "k_padded": kp}
+
+    # -- shared-weight row kernels / density-independent launches: roofline with fitted efficiencies
+    def dense_rows(self, rows: float, k: float, n: float, in_bytes: float, out_bytes: float) -> float:
+        flops = 6.0 * rows * k * n
+        t_m = flops / (self.hw.mfma_peak * self.cal.dense_mfma_eff)
+        t_b = (in_bytes + out_bytes + 4.0 * k * n) / (self.hw.hbm_bytes_per_s * self.cal.hbm_eff)
+        return max(t_m, t_b) + self.cal.launch_s
+
+    def first_block(self, b: BlockShape, batch: int, density: float) -> float:
+        """The stage's first block (projection shortcut, stride 2 from stage 2 on): gathered conv1 / conv2 / conv3 on the general
+        kernels (their K and N shrink with the density) + the dense projection."""
+        G = b.width // b.gran
+        kp = expected_padded_channels(G, b.gran, density)
+        kp2 = expected_padded_sq(G, b.gran, density)
+        px_in, px = b.h_in * b.w_in, b.h * b.w
+        t = self.dense_rows(batch * px_in, b.cin, kp, 4.0 * batch * px_in * b.cin, 4.0 * batch * px_in * kp)          # conv1
+        t += self.dense_rows(batch * px, 9.0 * kp2 / max(kp, 1.0), kp, 4.0 * batch * px_in * kp, 4.0 * batch * px * kp)   # conv2
+        t += self.dense_rows(batch * px, kp, b.cout, 4.0 * batch * px * (kp + b.cout), 4.0 * batch * px * b.cout)         # conv3 + residual
+        t += self.dense_rows(batch * px, b.cin, b.cout, 4.0 * batch * px * b.cin, 4.0 * batch * px * b.cout)             # projection
+        return t
+
+    def dense_block(self, b: BlockShape, batch: int) -> float:
+        """A channel-mode block executed densely (maps of <= 64 pixels: stage 4): masks applied in the epilogues, no work skipped."""
+        px = b.h * b.w
+        t = self.dense_rows(batch * b.h_in * b.w_in, b.cin, b.width, 4.0 * batch * b.h_in * b.w_in * b.cin, 4.0 * batch * b.h_in * b.w_in * b.width)
+        t += self.dense_rows(batch * px, 9.0 * b.width, b.width, 4.0 * batch * b.h_in * b.w_in * b.width, 4.0 * batch * px * b.width)
+        t += self.dense_rows(batch * px, b.width, b.cout, 4.0 * batch * px * (b.width + b.cout), 4.0 * batch * px * b.cout)
+        if b.downsample:
+            t += self.dense_rows(batch * px, b.cin, b.cout, 4.0 * batch * px * b.cin, 4.0 * batch * px * b.cout)
+        return t + 2 * self.cal.launch_s                          # GAP + masker MLP launches
+
+    def stem(self, batch: int, input_hw=(224, 224)) -> float:
+        """k_stem: conv 7x7 (K padded to 176) on 17x15-pixel tiles recomputed 1.14x + pooled output."""
+        px = batch * (input_hw[0] // 2) * (input_hw[1] // 2)
+        flops = 6.0 * px * 1.14 * 176 * 64
+        t_m = flops / (self.hw.mfma_peak * self.cal.dense_mfma_eff)
+        t_b = 4.0 * batch * (3 * input_hw[0] * input_hw[1] + 64 * (input_hw[0] // 4) * (input_hw[1] // 4)) / (self.hw.hbm_bytes_per_s * self.cal.hbm_eff)
+        return max(t_m, t_b) + self.cal.launch_s
+
+    # -- whole model
+    def predict_resnet(self, batch: int = 256, layers=(3, 4, 23, 3), density=(0.62,) * 4, gran=(2, 2, 2, 2), input_hw=(224, 224)) -> dict:
+        """Channel-mode LAUD-ResNet forward.  density: keep probability of a channel group per stage."""
+        blocks = resnet_blocks(layers, input_hw, gran)
+        rows, total = [], self.stem(batch, input_hw)
+        rows.append(("stem", total))
+        i = 0
+        while i < len(blocks):
+            s, b = blocks[i]
+            d = density[s]
+            if b.h * b.w <= 64:                                                  # dense execution (stage 4 at 224)
+                t = self.dense_block(b, batch)
+                kind = "dense"
+            elif b.downsample or b.stride != 1:
+                t = self.first_block(b, batch, d)
+                kind = "first"
+            else:
+                chained = b.h * b.w <= 256 and batch <= 4 * self.hw.cus
+                t = self.fused_block(b, batch, d, chained)["s"]
+                kind = "chained" if chained else "fused"
+            rows.append((f"layer{s + 1}.{sum(1 for ss, _ in blocks[:i] if ss == s)} {kind}", t))
+            total += t
+            i += 1
+        total += self.cal.fixed_s
+        return {"s": total, "ms": 1e3 * total, "rows": rows}
+
+    def predicted_speedup(self, batch=256, layers=(3, 4, 23, 3), density=(0.62,) * 4, gran=(2, 2, 2, 2), input_hw=(224, 224)) -> dict:
+        """static (every channel kept: the same kernels at density 1) over dynamic -- eval_example.py:203-216 vs :219-360 for this
+        implementation."""
+        dyn = self.predict_resnet(batch, layers, density, gran, input_hw)
+        sta = self.predict_resnet(batch, layers, (1.0,) * 4, gran, input_hw)
+        return {"static_ms": sta["ms"], "dynamic_ms": dyn["ms"], "speedup": sta["ms"] / dyn["ms"]}
+
+    def best_channel_granularity(self, stage_shape: BlockShape, batch: int, density: float, candidates=(2, 4, 8, 16, 32)) -> dict:
+        """Latency of a fused block per channel granularity at equal density: coarser groups waste less MFMA tile padding
+        (E[32 ceil(K/32)] -> K as the group approaches the tile) -- the per-hardware choice the reference makes with its simulator."""
+        out = {}
+        for g in candidates:
+            if stage_shape.width % g:
+                continue
+            b = BlockShape(**{**stage_shape.__dict__, "gran": g})
+            out[g] = self.fused_block(b, batch, density, stage_shape.h * stage_shape.w <= 256)["s"]
+        return out

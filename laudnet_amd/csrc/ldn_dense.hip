@@ -60,7 +60,9 @@ constexpr int D_ROWS = 256;
 constexpr int D_ROW_RELU = 1 << 30;
 
 // NSUB = n-subtiles of 32 columns per workgroup (2, 4, 8); D = ring depth (2 for NSUB 8, 3 otherwise)
-template <int NSUB, bool T9>   // T9: 3x3 over a neighbour table (compiled apart: the 1x1 form carries none of its tables or branches)
+// T9: 3x3 over a neighbour table (compiled apart: the 1x1 form carries none of its tables or branches); FULL: cout is a multiple of
+// the tile width, so every workgroup owns NSUB whole n-subtiles (compiled apart: no per-subtile branch in the K loop)
+template <int NSUB, bool T9, bool FULL>
 __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     constexpr int NT = NSUB * 32;
     constexpr int D = NSUB == 8 ? 2 : 3;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     if (m0 >= M) return;
     const int rows = min(D_ROWS, M - m0);
     const int n0 = nt * NT;
-    const int nsub = min(NSUB, (p.cout - n0) / 32);
+    const int nsub = FULL ? NSUB : min(NSUB, (p.cout - n0) / 32);
 
     if (tid < D_ROWS) {
         int ar = -1, orw = -1;
@@ -174,27 +176,56 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         if (!active) continue;
         const unsigned char* xs = s_ring + (c % D) * SLOT;
         const unsigned char* ws = xs + D_ROWS * 128;
+        // B operands of both K16 steps of the chunk: the wave's 32 rows, split into bf16 hi / lo once for all n-subtiles
+        bf16x8 bh[2], bl[2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const unsigned sl = 4u * half + 2u * h;
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
-            bf16x8 bh, bl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = e < 4 ? x0[e] : x1[e - 4];
                 const __bf16 hb = (__bf16)v;
-                bh[e] = hb;
-                bl[e] = (__bf16)(v - (float)hb);
+                bh[half][e] = hb;
+                bl[half][e] = (__bf16)(v - (float)hb);
             }
+        }
+        auto frag = [&](int step, bf16x8& ah, bf16x8& al) {   // step = half * NSUB + j: weight row 32 j + l31, octet 2 half + h
+            const int half = step / NSUB, j = step - half * NSUB;
+            const unsigned sl = 4u * half + 2u * h;
+            ah = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl ^ wsw) << 4));
+            al = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl + 1) ^ wsw) << 4));
+        };
+        if constexpr (FULL) {
+            // one flat, branch-free sequence of 2 NSUB steps whose weight fragments are double-buffered: the two ds_read_b128 of step
+            // s + 1 are in flight during the three MFMAs of step s.  (Left to itself hipcc issues read, s_waitcnt lgkmcnt(0), MFMA
+            // per fragment behind a branch per subtile: a full LDS latency per 96 MFMA cycles, hidden only by the SIMD's other wave.)
+            bf16x8 ah[2], al[2];
+            frag(0, ah[0], al[0]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NSUB; ++j) {
-                if (j < nsub) {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl ^ wsw) << 4));
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl + 1) ^ wsw) << 4));
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+            for (int st = 0; st < 2 * NSUB; ++st) {
+                if (st + 1 < 2 * NSUB) frag(st + 1, ah[(st + 1) & 1], al[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);     // the schedule is pinned: the next step's reads are issued BEFORE this step's MFMAs
+                const int half = st / NSUB, j = st - half * NSUB;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st & 1], bh[half], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bl[half], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bh[half], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) {
+                    if (j < nsub) {
+                        bf16x8 ah, al;
+                        frag(half * NSUB + j, ah, al);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[half], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[half], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[half], acc[j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -264,18 +295,23 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_dense)
 
-template <int NSUB, bool T9>
-static int launch_dense(DenseArgs& a, hipStream_t st) {
+template <int NSUB, bool T9, bool FULL>
+static int launch_dense_f(DenseArgs& a, hipStream_t st) {
     constexpr int NT = NSUB * 32;
     constexpr int D = NSUB == 8 ? 2 : 3;
     const size_t lds = (size_t)(T9 ? 12 : 2) * D_ROWS * 4 + (size_t)D * (D_ROWS + NT) * 128;
     a.ntn = ceil_div(a.cout, NT);
     a.mtn = ceil_div(a.m_cap, D_ROWS);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB, T9>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB, T9, FULL>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
     const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
-    hipLaunchKernelGGL((k_dense<NSUB, T9>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_dense<NSUB, T9, FULL>), dim3(grid), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_dense");
     return LDN_OK;
+}
+
+template <int NSUB, bool T9>
+static int launch_dense(DenseArgs& a, hipStream_t st) {
+    return a.cout % (NSUB * 32) == 0 ? launch_dense_f<NSUB, T9, true>(a, st) : launch_dense_f<NSUB, T9, false>(a, st);
 }
 
 }  // namespace ldn

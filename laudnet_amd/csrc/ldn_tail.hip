@@ -642,7 +642,7 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
     const long row0 = (long)b * p.HW + m0;
 
     const int Nb = min(p.n_cnt[b], W);
-    const int nsub = ceil_div(Nb, 32);
+    const int nsub = __builtin_amdgcn_readfirstlane(ceil_div(Nb, 32));
     const int wrows = round_up(max(Nb, 1), 64);                          // weight rows staged per chunk (DMA instructions cover 8 rows)
     if (tid < W + 32) s_nidx[tid] = tid < Nb ? p.n_idx[(size_t)b * W + tid] : -1;
     __syncthreads();
@@ -706,31 +706,79 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
         if (!active) continue;
         const unsigned char* xs = s_ring + (c % D) * slot_bytes;
         const unsigned char* ws = xs + xrows * 128;
+        // B operands of both K16 steps of the chunk (this wave's 32 pixels), split once for all of the image's n-subtiles
+        bf16x8 bh[2], bl[2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const unsigned sl = 4u * half + 2u * h;          // logical 16-byte slot of this lane's 8 k values (x: fp32 k .. k+3, k+4 .. k+7)
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
-            bf16x8 bh, bl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = e < 4 ? x0[e] : x1[e - 4];
                 const __bf16 hb = (__bf16)v;
-                bh[e] = hb;
-                bl[e] = (__bf16)(v - (float)hb);
-            }
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                if (j < nsub) {
-                    // weight row 32 j + l31, octet 2 half + h: [8 hi] at logical slot sl, [8 lo] at sl + 1 -- no VALU
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl ^ wsw) << 4));
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl + 1) ^ wsw) << 4));
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
-                }
+                bh[half][e] = hb;
+                bl[half][e] = (__bf16)(v - (float)hb);
             }
         }
+        // The image's n-subtiles in DESCENDING order as ONE linear, software-pipelined sequence with an entry point per subtile count
+        // (a switch that falls through: no duplicated code, every accumulator keeps its registers).  Step j = the two K16 halves of
+        // subtile j; a weight fragment is two ds_read_b128 (8 hi | 8 lo of row 32 j + l31, no VALU), double-buffered in a0 / a1: the
+        // reads of (j, half 1) fly during the MFMAs of (j, half 0), those of (j - 1, half 0) during the MFMAs of (j, half 1).
+        // (Left to itself hipcc emits read, s_waitcnt lgkmcnt(0), MFMA per fragment behind a branch per subtile: a full LDS latency
+        // per 96 MFMA cycles, hidden only by the SIMD's other wave.)
+        bf16x8 a0h, a0l, a1h, a1l;
+        const unsigned sl0 = 2u * h, sl1 = 4u + 2u * h;
+        auto frag0 = [&](int j) {
+            a0h = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl0 ^ wsw) << 4));
+            a0l = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl0 + 1) ^ wsw) << 4));
+        };
+        auto frag1 = [&](int j) {
+            a1h = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl1 ^ wsw) << 4));
+            a1l = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl1 + 1) ^ wsw) << 4));
+        };
+#define LDN_HEAD_STEP(J)                                                                                  \
+        frag1(J);                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, bh[0], acc[J], 0, 0, 0);                    \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bl[0], acc[J], 0, 0, 0);                    \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bh[0], acc[J], 0, 0, 0);                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        if (J > 0) frag0(J > 0 ? J - 1 : 0);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, bh[1], acc[J], 0, 0, 0);                    \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bl[1], acc[J], 0, 0, 0);                    \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bh[1], acc[J], 0, 0, 0);                    \
+        __builtin_amdgcn_sched_barrier(0);
+        if (nsub > 0) {
+            frag0(nsub - 1);
+            switch (nsub) {
+                default:
+                    if constexpr (NS >= 8) { LDN_HEAD_STEP(7) }
+                    [[fallthrough]];
+                case 7:
+                    if constexpr (NS >= 8) { LDN_HEAD_STEP(6) }
+                    [[fallthrough]];
+                case 6:
+                    if constexpr (NS >= 8) { LDN_HEAD_STEP(5) }
+                    [[fallthrough]];
+                case 5:
+                    if constexpr (NS >= 8) { LDN_HEAD_STEP(4) }
+                    [[fallthrough]];
+                case 4:
+                    if constexpr (NS >= 4) { LDN_HEAD_STEP(3) }
+                    [[fallthrough]];
+                case 3:
+                    if constexpr (NS >= 4) { LDN_HEAD_STEP(2) }
+                    [[fallthrough]];
+                case 2:
+                    LDN_HEAD_STEP(1)
+                    [[fallthrough]];
+                case 1:
+                    LDN_HEAD_STEP(0)
+            }
+        }
+#undef LDN_HEAD_STEP
     }
     wait_vm_n<0>();      // no LDS-DMA may be in flight when the workgroup's LDS is released
 

@@ -104,27 +104,48 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
         for (int j = 0; j < NSUB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < S_KSTEPS; ++s) {
+        // software-pipelined over the 11 K16 steps (schedule pinned): the 8 patch floats and the weight fragments of step s + 1 are
+        // requested before the MFMAs of step s and split into bf16 hi / lo after them
+        float raw[2][8];
+        bf16x8 fh[2][NSUB], fl[2][NSUB];
+        auto request = [&](int s, int buf) {
             const int q = 2 * s + h;                   // this lane's k8 group: patch row q / 3, floats 8 (q % 3) .. + 7 of the row window
             const float* src = s_patch + pbase + (q / 3) * S_ROWF + 8 * (q % 3);
-            bf16x8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[buf][e] = src[e];
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                const unsigned char* wp = s_w + ((j * S_KSTEPS + s) * 64 + lane) * 32;
+                fh[buf][j] = *reinterpret_cast<const bf16x8*>(wp);
+                fl[buf][j] = *reinterpret_cast<const bf16x8*>(wp + 16);
+            }
+        };
+        auto split = [&](int buf, bf16x8& bh, bf16x8& bl) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = src[e];
+                const float v = raw[buf][e];
                 const __bf16 hb = (__bf16)v;
                 bh[e] = hb;
                 bl[e] = (__bf16)(v - (float)hb);
             }
+        };
+        bf16x8 bh, bl;
+        request(0, 0);
+        split(0, bh, bl);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < S_KSTEPS; ++s) {
+            if (s + 1 < S_KSTEPS) request(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NSUB; ++j) {
-                const unsigned char* wp = s_w + ((j * S_KSTEPS + s) * 64 + lane) * 32;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wp);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wp + 16);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s & 1][j], bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s & 1][j], bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s & 1][j], bh, acc[j], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < S_KSTEPS) split((s + 1) & 1, bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // C layout (lane = pixel l31, register r = channel (r & 3) + 8 (r >> 2) + 4 h of the subtile) -> s_conv[pixel][C]
 #pragma unroll

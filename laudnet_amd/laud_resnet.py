@@ -433,7 +433,7 @@ class Bottleneck(_PrepCache):
             ops.conv_packed(x2d, p["w1"], p["s1"], p["t1"], h1, taps=1, m_cap=ix.cap1, post_sub=p["c1"], relu=1)
             h1.view(B, -1, W).mul_(chm)
         h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
-        if fused_mask and 9 in ops.DENSE_TAPS:
+        if fused_mask and 9 in ops.DENSE_TAPS and ops.DENSE_CHANNEL_3X3:
             ops.conv_rows(h1, p["w2_nk"], p["s2"], p["t2_tab"], h2, a_rows=ix.nbr, taps=9, m_cap=ix.cap3, pix_map=ix.idx3,
                           geom=(Hi, Wi, Ho, Wo, self.stride), post_sub=p["c2"], relu=1, chan_mask=chm2d, rows_per_image=Ho * Wo)
         else:
@@ -456,7 +456,7 @@ class Bottleneck(_PrepCache):
         return ops.from_nhwc(out), mask
 
     use_fused_head = True    # conv1 on k_head (False: the general ldn_conv_image with out_format 1)
-    fused_head_widths = (256,)   # ... for these widths when a block runs on its own (measured: the early stages' short blocks are faster on ldn_conv_image)
+    fused_head_widths = tuple(int(t) for t in os.environ.get("LDN_HEAD_WIDTHS", "64,128,256").split(","))   # ... for these widths when a block runs on its own (with the pipelined fragment reads k_head is ahead at every width: 13.73 -> 13.62 ms)
     use_fused_tail = True    # class-level switch (A/B measurements): False keeps the three-launch gathered execution
 
     def _tail_eligible(self, Hi, Wi, Ho, Wo, cout):

@@ -58,14 +58,88 @@ __device__ __forceinline__ void channel_mlp_body(const int b, const float* __res
     const int G2 = 2 * G;
     if (!mask_in) {
         const float inv = 1.f / (float)HW;
+        const int n1 = hidden > 0 ? hidden : G2;     // outputs of the first (or only) layer
+        float* dst1 = hidden > 0 ? s_hid : s_log;
+        // LATENCY form (the masker is a chain of dependent global reads: GAP partials -> layer 1 weights -> layer 2 weights -> list;
+        // measured inside k_chain: 36 k cycles per block, 6 % of the run): when a wave owns at most two layer-1 outputs and a lane's
+        // share of a weight row is at most 8 quads, ALL global loads of the phase -- the lane's layer-1 weights, its layer-2 row, the
+        // GAP partials -- are issued before the first of them is waited for.  Per output the summation order is unchanged.
+        const bool lat = hidden > 0 && hidden <= 2 * NW && (C & 255) == 0 && C <= 2048 && (hidden & 3) == 0 && hidden <= 16 &&
+                         (reinterpret_cast<uintptr_t>(w1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w2) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
+        if (lat) {
+            const int nq = C >> 8;                                   // quads of a weight row per lane (<= 8)
+            f32x4 wq[2][8];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int o = wave + NW * k;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    wq[k][q] = (o < n1 && q < nq) ? *reinterpret_cast<const f32x4*>(w1 + (size_t)o * C + lane * 4 + 256 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            f32x4 w2q[4];
+            const int o2 = tid;                                      // layer-2 output of this thread (G2 <= NT in this form, else looped below)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w2q[q] = (o2 < G2 && 4 * q < hidden) ? *reinterpret_cast<const f32x4*>(w2 + (size_t)o2 * hidden + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float b2v = o2 < G2 ? b2[o2] : 0.f;
+            float b1v[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) b1v[k] = wave + NW * k < n1 ? b1[wave + NW * k] : 0.f;
+            // GAP: four channels per thread, the partials of up to 8 splits in flight together, added in split order
+            for (int c = tid * 4; c < C; c += NT * 4) {
+                f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+                for (int k0 = 0; k0 < splits; k0 += 8) {
+                    f32x4 pv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        pv[k] = k0 + k < splits ? *reinterpret_cast<const f32x4*>(partial + ((size_t)b * splits + k0 + k) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k0 + k < splits) sacc += pv[k];
+                }
+                *reinterpret_cast<f32x4*>(s_gap + c) = sacc * inv;
+            }
+            __syncthreads();
+            float a1[2] = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q < nq) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(s_gap + lane * 4 + 256 * q);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) a1[k] += wq[k][q][0] * g[0] + wq[k][q][1] * g[1] + wq[k][q][2] * g[2] + wq[k][q][3] * g[3];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) a1[k] = wave_sum(a1[k]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int o = wave + NW * k;
+                    if (o < n1) dst1[o] = fmaxf(a1[k] + b1v[k], 0.f);
+                }
+            }
+            __syncthreads();
+            for (int o = tid; o < G2; o += NT) {
+                float a = o == o2 ? b2v : b2[o];
+                const float* wr = w2 + (size_t)o * hidden;
+                for (int j = 0; j < hidden; j += 4) {
+                    const f32x4 v = o == o2 ? w2q[j >> 2] : *reinterpret_cast<const f32x4*>(wr + j);
+                    a += v[0] * s_hid[j];
+                    a += v[1] * s_hid[j + 1];
+                    a += v[2] * s_hid[j + 2];
+                    a += v[3] * s_hid[j + 3];
+                }
+                s_log[o] = a;
+            }
+            __syncthreads();
+        } else {
         for (int c = tid; c < C; c += NT) {
             float s = 0.f;
             for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
             s_gap[c] = s * inv;
         }
         __syncthreads();
-        const int n1 = hidden > 0 ? hidden : G2;     // outputs of the first (or only) layer
-        float* dst1 = hidden > 0 ? s_hid : s_log;
         // each wave owns outputs wave, wave + NW, ...; eight of them per pass so that their weight loads are in flight
         // together and their cross-lane reductions interleave (per output the summation order is unchanged)
         constexpr int OB = 8;
@@ -131,6 +205,7 @@ __device__ __forceinline__ void channel_mlp_body(const int b, const float* __res
             }
             __syncthreads();
         }
+        }   // !lat
         for (int j = tid; j < G; j += NT) mask[(size_t)b * G + j] = s_log[j] >= s_log[G + j] ? 1.f : 0.f;
         if (logits)
             for (int o = tid; o < G2; o += NT) logits[(size_t)b * G2 + o] = s_log[o];

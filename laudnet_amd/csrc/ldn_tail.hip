@@ -49,6 +49,7 @@ __device__ __attribute__((aligned(16))) float g_tail_zero[4] = {0.f, 0.f, 0.f, 0
 #endif
 #ifdef LDN_TRACE   // tuning only: per-workgroup phase timestamps of every wave (tools/trace_tail.py)
 __device__ unsigned long long* g_tail_trace = nullptr;
+__device__ unsigned long long* g_chain_trace = nullptr;   // k_chain: [B][4] = masker, conv1, conv2+conv3, fences (cycles summed over the run)
 #define TT(x) x = __builtin_amdgcn_s_memtime();
 #define TT_ADD(acc, a, b) acc += (b) - (a);
 #else
@@ -539,6 +540,10 @@ static int launch_tail(TailArgs& a, hipStream_t st) {
 using namespace ldn;
 
 #ifdef LDN_TRACE
+extern "C" int ldn_debug_set_chain_trace(void* buf) {
+    unsigned long long* q = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
+}
 extern "C" int ldn_debug_set_tail_trace(void* buf) {
     unsigned long long* q = static_cast<unsigned long long*>(buf);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tail_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
@@ -915,13 +920,23 @@ template <typename T> __device__ __forceinline__ T uniform_ptr(T v) {
     return reinterpret_cast<T>(((unsigned long long)hi << 32) | lo);
 }
 
+#ifdef LDN_TRACE   // tuning only: per-image cycles of the masker / conv1 / conv2+conv3 phases and of the fences, summed over the run
+#define CT(x) x = __builtin_amdgcn_s_memtime();
+#else
+#define CT(x)
+#endif
+
 template <int NS>
 __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArgs p) {
     constexpr int W = NS * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     const int HW = p.H * p.Wd;
+#ifdef LDN_TRACE
+    unsigned long long c0, c1, c2, c3, c4, c5, c6, am = 0, ah = 0, at = 0, af = 0;
+#endif
     for (int i = 0; i < p.nblocks; ++i) {
+        CT(c0)
         const ChainBlock* cb = p.blocks + i;
         float* const mask_i = p.masks + (size_t)i * p.B * p.G;
         int32_t* const idx_i = p.ch_idx + (size_t)i * p.B * W;
@@ -934,7 +949,9 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
                                   uniform_ptr(cb->mb1), uniform_ptr(cb->mw2), uniform_ptr(cb->mb2), p.hidden, p.G, p.gran, nullptr,
                                   mask_i, nullptr, idx_i, cnt_i, s_f, s_w);
         }
+        CT(c1)
         phase_fence();
+        CT(c2)
         {   // ---- conv1 -> h1 (pre-split)
             HeadArgs ha;
             ha.x = xin; ha.ldx = p.ldx; ha.B = p.B; ha.HW = HW; ha.cin = p.C; ha.W = W;
@@ -943,7 +960,9 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
             ha.h1 = p.h1; ha.h1_row_bytes = p.h1_row_bytes; ha.pix_per_blk = HW; ha.mblocks = 1;
             head_body<NS>(ha, b, 0, smem, p.lds_total, opaque_tid());
         }
+        CT(c3)
         phase_fence();
+        CT(c4)
         {   // ---- conv2 -> conv3 + residual, GAP partials of the output
             TailArgs ta;
             ta.h1 = p.h1; ta.h1_row_bytes = p.h1_row_bytes;
@@ -954,8 +973,19 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
             ta.rows_per_blk = p.H; ta.mblocks = 1; ta.slice_bytes = p.slice_bytes;
             tail_body<NS>(ta, b, 0, smem, opaque_tid());
         }
+        CT(c5)
         phase_fence();
+        CT(c6)
+#ifdef LDN_TRACE
+        am += c1 - c0; ah += c3 - c2; at += c5 - c4; af += (c2 - c1) + (c4 - c3) + (c6 - c5);
+#endif
     }
+#ifdef LDN_TRACE
+    if (g_chain_trace && threadIdx.x == 0) {
+        unsigned long long* r = g_chain_trace + (size_t)b * 4;
+        r[0] = am; r[1] = ah; r[2] = at; r[3] = af;
+    }
+#endif
 }
 
 template <int NS>

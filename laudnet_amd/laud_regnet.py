@@ -4,12 +4,14 @@ Same class names, constructor arguments, sub-module layout (hence state_dict key
 `trunk_output.block{S}.block{S}-{i}.{proj.{0,1},f.{a,b,c}.{0,1},f.se.fc{1,2},f.masker_*}.*`, `fc.*`) and
 `forward(x, temperature)` 7-tuple as the reference, so its checkpoints load unchanged.
 
-Execution (round 1): the configuration BASELINE.json names for RegNet -- **layer skip**, i.e. `dyn_mode='spatial'` with
-`mask_spatial_granularity = output size` (one keep/skip bit per image and block; the reference rejects
-`dyn_mode='layer'` for RegNet, laud_regnet.py:100).  Kept images run a (1x1) -> b (grouped 3x3) -> SE -> c (1x1) on
-packed rows in libldn_hip.so; skipped images cost nothing.  This is the only spatial setting for which a sparse
-execution of RegNet-Y is exact, because the SE squeeze pools the *dense* conv-b output (laud_regnet.py:194).
-Other dyn modes raise LdnError on the HIP path (the oracle covers them).  No CPU / PyTorch fallback.
+Execution.  **Layer skip** (the configuration BASELINE.json names for RegNet: `dyn_mode='spatial'` with
+`mask_spatial_granularity = output size`, one keep/skip bit per image and block; the reference rejects `dyn_mode='layer'` for
+RegNet, laud_regnet.py:100): kept images run a (1x1) -> b (grouped 3x3) -> SE -> c (1x1) on packed rows in libldn_hip.so,
+skipped images cost nothing.  **Channel mode**: the mask multiplies the outputs of a and b after their activation, so only the
+active channel subsets are computed (a with an output list, b on the active run of every group, SE gathered, c with an input
+list).  **General spatial / both**: the reference masks only conv c's output and the SE squeeze pools the dense conv-b output
+(laud_regnet.py:194,200), so a / b / SE run on every pixel (on the active channels in 'both') and c on the packed
+active pixels.  spatial_mask_channel_group > 1 raises LdnError.  No CPU / PyTorch fallback.
 """
 from __future__ import annotations
 
@@ -204,11 +206,10 @@ class ResBottleneckBlock(_PrepCache):
         f = self.f
         if f.dyn_mode == "channel":
             return self._run_channel(x, inplace)
-        if f.dyn_mode != "spatial" or f.mask_size != 1 or f.masker_spatial.mask_channel_group != 1:
-            raise LdnError("HIP path: LAD-RegNet runs channel mode and layer skip (dyn_mode='spatial' with "
-                           "mask_spatial_granularity equal to the stage's output size, BASELINE config 4); general spatial / "
-                           "both modes are not exactly sparsifiable (the SE squeeze pools the dense conv-b output before the "
-                           "mask is applied, SURVEY 0.9) and are covered by the oracle only")
+        if f.masker_spatial.mask_channel_group != 1:
+            raise LdnError("HIP path: LAD-RegNet spatial masks with spatial_mask_channel_group > 1 are not built")
+        if f.dyn_mode == "both" or f.mask_size != 1:
+            return self._run_spatial_general(x, inplace)
         p = f.prepared(x.device)
         B, Cin, Hi, Wi = x.shape
         Ho = Wo = f.output_size
@@ -245,6 +246,78 @@ class ResBottleneckBlock(_PrepCache):
         f.last_spatial_mask = patch
         stats = torch.cat((ix.stats, torch.ones(1, device=dev)))
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), stats
+
+    def _run_spatial_general(self, x, inplace):
+        """dyn_mode 'spatial' with patch masks, and 'both' (laud_regnet.py:164-217).  The reference masks ONLY conv c's output
+        spatially (:200): a and b run on every pixel and the SE squeeze pools the dense b output (:194), so what the pixel mask can
+        skip exactly is conv c (+ the residual update) on the inactive pixels -- a / b / SE are executed densely (in 'both' mode on
+        the image's active channels, as in channel mode), c on the packed rows of the active pixels, scattered back.  (Layer skip,
+        one patch per image, is the special case where a dropped image needs no a / b / SE at all: run_dynamic above.)"""
+        f = self.f
+        p = f.prepared(x.device)
+        B, Cin, Hi, Wi = x.shape
+        s = self.stride
+        if Hi % s or Wi % s:
+            raise LdnError(f"ResBottleneckBlock: a {Hi}x{Wi} input is not a multiple of the block's stride {s}")
+        Ho, Wo = Hi // s, Wi // s
+        dev = x.device
+        xn = ops.as_nhwc(x)
+        w_b = f.w_b
+        both = f.dyn_mode == "both"
+        if f.forced_spatial_mask is not None:
+            patch = f.forced_spatial_mask.to(device=dev, dtype=torch.float32).contiguous()
+        else:
+            patch = f.masker_spatial(x, 1.0)[0]
+        ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, s)          # mask3 list (conv c) and the three sparsities
+        x2d = xn.reshape(B * Hi * Wi, Cin)
+        cout = p["wc"].shape[0]
+        if both:
+            if w_b % 8 != 0:
+                raise LdnError("HIP path: LAD-RegNet 'both' mode needs a bottleneck width that is a multiple of 8")
+            gran = w_b // f.masker_channel.channel_dyn_group
+            cmask, idx, cnt, _ = f.masker_channel.lists(x, gran, mask_in=f.forced_channel_mask)
+            h_a = torch.empty(B, Hi, Wi, w_b, device=dev, dtype=torch.float32)
+            ops.conv_image(xn, p["wa"], p["sa"], p["ta"], h_a, n_idx=idx, n_cnt=cnt, relu=1)
+            h_b = torch.empty(B, Ho, Wo, w_b, device=dev, dtype=torch.float32)
+            ops.grouped_conv3x3_image(h_a, p["wb"], f.group_width, idx, cnt, p["sb"], p["tb"], h_b, stride=s, relu=1)
+            h_b2d = h_b.view(B * Ho * Wo, w_b)
+            ops.se_packed(h_b2d, self._img_prefix(B, Ho * Wo, dev), p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo,
+                          ch_idx=idx, ch_cnt=cnt)
+        else:
+            dense = self._dense_index(B, Ho, Wo, dev)                          # every pixel: the neighbour table of conv b
+            h_a = torch.empty(B * Hi * Wi, w_b, device=dev, dtype=torch.float32)
+            ops.conv_rows(x2d, p["wa"], p["sa"], p["ta"], h_a, taps=1, m_cap=B * Hi * Wi)
+            h_b2d = torch.empty(B * Ho * Wo, w_b, device=dev, dtype=torch.float32)
+            ops.grouped_conv3x3_rows(h_a, dense.nbr, p["wb"], f.group_width, p["sb"], p["tb"], h_b2d, m_cap=B * Ho * Wo, relu=1)
+            ops.se_packed(h_b2d, self._img_prefix(B, Ho * Wo, dev), p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo)
+        if self.proj is not None:
+            wp, sp, tp = self._proj(dev)
+            out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
+            ops.conv_rows(x2d, wp, sp, tp, out2d, a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, s, dev), taps=1, m_cap=ix.cap3, relu=2,
+                          relu_if_neg=ix.pos3)
+            resid = out2d
+        elif inplace:
+            resid = out2d = x2d
+        else:
+            resid, out2d = x2d, torch.relu(x2d)
+        if both:   # c: gathered input channels (per image) x packed active pixels
+            ops.conv_packed(h_b2d, p["wc_k"], p["sc"], p["tc"], out2d, B=B, row_prefix=ix.pre3, m_cap=Ho * Wo, a_map=ix.idx3, taps=1,
+                            out_map=ix.idx3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual2d=resid)
+            f.last_channel_mask = cmask
+            cs = cmask.mean().reshape(1)
+        else:
+            ops.conv_rows(h_b2d, p["wc"], p["sc"], p["tc"], out2d, a_rows=ix.idx3, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
+                          out_rows=ix.idx3, residual2d=resid)
+            cs = torch.ones(1, device=dev)
+        f.last_spatial_mask = patch
+        return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), torch.cat((ix.stats, cs))
+
+    def _dense_index(self, B, Ho, Wo, dev):
+        key = (B, Ho, Wo, self.stride, str(dev))
+        cache = self.__dict__.setdefault("_dense_ix_cache", {})
+        if key not in cache:
+            cache[key] = ops.mask_to_index(torch.ones(B, 1, 1, device=dev), Ho, Wo, self.stride)
+        return cache[key]
 
     def _run_channel(self, x, inplace):
         """dyn_mode 'channel' (laud_regnet.py:160-170,182-189): the mask multiplies the outputs of a and b AFTER conv+BN+ReLU, so

@@ -270,11 +270,34 @@ def test_regnet_channel_own_maskers(math_mode):
                        what="regnet channel logits")
 
 
-def test_regnet_general_spatial_raises():
-    """General spatial masks on RegNet-Y are not exactly sparsifiable (SE pools the dense conv-b output before the mask is
-    applied): the HIP path refuses them instead of approximating."""
-    from laudnet_amd import LdnError
-    fx = REGNET["cases"]["spatial_g2"]
+@pytest.mark.parametrize("case", ["spatial_g2", "both"])
+def test_regnet_spatial_and_both_injected(math_mode, case):
+    """LAD-RegNet with patch masks ('spatial') and with patch masks x channel masks ('both') (laud_regnet.py:164-217): the mask
+    only applies to conv c's output, so a / b / SE run densely (on the active channels in 'both') and c on the packed active pixels --
+    against the fixtures the reference generated with the same injected masks."""
+    from fill import seeded_bernoulli
+    fx = REGNET["cases"][case]
     model, x = _hip_regnet(fx)
-    with pytest.raises(LdnError):
-        model(x, 1.0)
+    for i, blk in enumerate(model.blocks()):
+        ms = blk.f.masker_spatial.mask_size
+        blk.f.forced_spatial_mask = seeded_bernoulli((fx["batch"], 1, ms, ms), 0.5, fx["mask_seed"] + 2 * i)
+        if blk.f.masker_channel is not None:
+            blk.f.forced_channel_mask = seeded_bernoulli((fx["batch"], blk.f.masker_channel.channel_dyn_group), 0.62,
+                                                         fx["mask_seed"] + 2 * i + 1).to(DEV)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=logit_atol(math_mode, fx["injected_run"]), rtol=LOGIT_RTOL[math_mode],
+                       what=f"regnet {case} logits")
+    assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what=f"regnet {case} stats")
+    assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what=f"regnet {case} flops")
+
+
+@pytest.mark.parametrize("case", ["spatial_g2", "both"])
+def test_regnet_spatial_and_both_own_maskers(math_mode, case):
+    fx = REGNET["cases"][case]
+    model, x = _hip_regnet(fx)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got[1:6], fx["masker_run"][1:6], atol=1e-6, what=f"regnet {case} stats (same masker decisions)")
+    assert_tuple_close(got[:1], fx["masker_run"][:1], atol=logit_atol(math_mode, fx["masker_run"]), rtol=LOGIT_RTOL[math_mode],
+                       what=f"regnet {case} logits")

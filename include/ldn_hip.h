@@ -274,6 +274,17 @@ int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B, int C, in
                   float* work, void* stream);
 size_t ldn_se_packed_workspace_bytes(int B, int C, int max_rows_per_image);
 
+/* ---- a14: token skipping (BASELINE config 5, AdaViT / DeiT-S shaped blocks).  The reference holds no model code for it, only the
+ * latency model of the operator (DyNetSimulator/adavit/simulate_adavit.py:77-131: q / k / v for every token, attention
+ * [B, heads, L_select, d] over the selected tokens): parity of this entry point is therefore UNPINNED -- it is tested against a
+ * dense masked attention written for the purpose (oracle/adavit_ref.py).
+ * qkv [rows][ld_qkv] fp32: per token row q | k | v, each [heads][64].  tok_rows [N]: flat row of every kept token, image-major and
+ * ascending (ldn_mask_to_index of the [B, L, 1] keep mask gives it as idx3); img_prefix [B + 1]: exclusive prefix of kept tokens per
+ * image (at most max_tokens <= 256 each).  out [N][ldo]: row n = softmax(scale * q_n K_b^T) V_b over the kept tokens of n's image,
+ * heads concatenated.  bf16x3 products, fp32 softmax. */
+int ldn_packed_mha(const float* qkv, int ld_qkv, const int32_t* tok_rows, const int32_t* img_prefix, int B, int heads,
+                   int head_dim, int max_tokens, float scale, float* out, int ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -510,3 +510,29 @@ def stem_conv_pool(x_nhwc, w_frag, shift, cout):
     L.check(lib.ldn_stem_conv_pool(L.ptr(x_nhwc), B, H, W, L.ptr(w_frag), L.ptr(_f32c(shift, "shift")), cout, L.ptr(out), Hp, Wp,
                                    L.stream_ptr(out)), "ldn_stem_conv_pool")
     return out
+
+
+# ---------------------------------------------------------------------------------------- a14: token skipping
+def token_lists(keep):
+    """keep [B, L] float {0,1} -> (tok_rows [B*L] int32: flat rows of the kept tokens, first `count` valid; prefix [B+1] int32;
+    count [1] int32 on the device).  The index kernel of the pixel masks does it: a [B, L, 1] patch mask on an L x 1 map."""
+    B, Lt = keep.shape
+    ix = mask_to_index(keep.reshape(B, Lt, 1).float().contiguous(), Lt, 1, 1)
+    return ix.idx3, ix.pre3, ix.cnt[0:1]
+
+
+def packed_mha(qkv2d, tok_rows, prefix, B, heads, max_tokens, scale=None):
+    """Multi-head attention among the kept tokens of every image (see ldn_packed_mha).  qkv2d [B*L, 3*dim]; returns the packed
+    rows [B*L (capacity), dim]: row n belongs to token tok_rows[n]."""
+    L.require_device(qkv2d, tok_rows, prefix)
+    lib = L.load()
+    rows, three_dim = qkv2d.shape
+    dim = three_dim // 3
+    d = dim // heads
+    if three_dim != 3 * dim or dim != heads * d or qkv2d.dtype != torch.float32 or qkv2d.stride(1) != 1:
+        raise L.LdnError("packed_mha: qkv must be fp32 [rows, 3 * heads * head_dim]")
+    out = torch.empty(rows, dim, device=qkv2d.device, dtype=torch.float32)
+    L.check(lib.ldn_packed_mha(L.ptr(qkv2d), qkv2d.stride(0), L.ptr(_i32c(tok_rows, "tok_rows")), L.ptr(_i32c(prefix, "prefix")), B, heads,
+                               d, max_tokens, float(scale if scale is not None else d ** -0.5), L.ptr(out), dim, L.stream_ptr(out)),
+            "ldn_packed_mha")
+    return out

@@ -50,7 +50,75 @@ WORKLOADS = {
     # BASELINE config 4: the reference rejects dyn_mode='layer' for RegNet; layer skip = spatial with one patch per image
     "regnet": dict(name="LAUD-RegNetY-800MF layer-skip target-0.5 @224", arch="lad_regnet_y_800mf",
                    kw=dict(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[56, 28, 14, 7]), p_channel=None, p_spatial=0.5),
+    # BASELINE config 5 (parity unpinned: the reference has no model code for it): DeiT-S shaped trunk of token-skipping blocks
+    "adavit": dict(name="DeiT-S shaped token-skip trunk (12 blocks, 197 tokens, dim 384, 6 heads, MLP x4), token keep 0.5"),
 }
+
+
+def bench_adavit(args):
+    """--workload adavit: the packed-token trunk of laudnet_amd/adavit.py (ldn_packed_mha + k_dense linears) on one GPU, beside its
+    dense masked restatement (oracle/adavit_ref.py) run through PyTorch on the same GPU.  Keep masks: seeded Bernoulli per block,
+    CLS always kept (the reference's token policy is not part of its repository).  One JSON line."""
+    import laudnet_amd
+    from laudnet_amd import ops
+    from laudnet_amd.adavit import TokenSkipViT
+    from oracle import adavit_ref as AR
+    from fill import seeded_bernoulli, seeded_randn
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    laudnet_amd.load_library()
+    ops.set_math_mode("bf16x3")
+    depth, L, dim, heads = 12, 197, 384, 6
+    keep_p = args.keep if args.keep is not None else 0.5
+    ref = AR.TokenSkipViTRef(depth, dim, heads).eval()
+    torch.manual_seed(1)
+    for p_ in ref.parameters():
+        if p_.dim() > 1:
+            torch.nn.init.normal_(p_, std=0.03)
+    hip = TokenSkipViT(depth, dim, heads).eval()
+    hip.load_state_dict(ref.state_dict())
+    hip, refg = hip.to(dev), ref.to(dev)
+    x = seeded_randn((args.batch, L, dim), 1000).to(dev)
+    keeps = []
+    for i in range(depth):
+        k = seeded_bernoulli((args.batch, L), keep_p, 2000 + i)
+        k[:, 0] = 1.0
+        keeps.append(k.to(dev))
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = hip(x, keeps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = hip(x, keeps)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        for _ in range(3):
+            want = refg(x, keeps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            want = refg(x, keeps)
+        torch.cuda.synchronize()
+        dtd = (time.perf_counter() - t0) / 10
+    kept = float(sum(k.sum().item() for k in keeps)) / (depth * args.batch * L)
+    # algorithmic FLOPs per image: qkv on every token, attention / proj / MLP on the kept ones (simulate_adavit.py:77-182)
+    lk = kept * L
+    flops = depth * 2.0 * (L * dim * 3 * dim + 2 * lk * lk * dim + lk * dim * dim + 2 * lk * dim * 4 * dim)
+    result = {"metric": f"images/sec, DeiT-S shaped token-skip trunk @197 tokens bs{args.batch} (dynamic-token packed MHA)",
+              "value": args.batch / dt, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "bf16x3 (fp32 tensors; fp32 softmax / LayerNorm / GELU)", "data": "synthetic (seeded randn tokens, seeded random weights and keep masks)",
+              "config": {"workload": WORKLOADS["adavit"]["name"].replace("keep 0.5", f"keep {keep_p}") + f" bs{args.batch}/GPU",
+                         "kept_token_fraction": round(kept, 4), "algorithmic_tflops": flops * args.batch / dt / 1e12,
+                         "parity": "UNPINNED: the reference holds no model code for this configuration (oracle/adavit_ref.py header)"},
+              "roofline": None,
+              "dense_emulation_gpu": {"value": args.batch / dtd, "unit": "images/sec", "ms_per_step": 1e3 * dtd,
+                                      "kind": "oracle/adavit_ref.py (dense masked attention, every token through every linear), PyTorch-ROCm fp32, same GPU",
+                                      "max_abs_diff_vs_hip_same_masks": (out - want).abs().max().item(),
+                                      "output_scale": want.abs().max().item()},
+              "realised_speedup_vs_dense_emulation": dtd / dt}
+    print(json.dumps(result))
 
 
 def blocks_of(model):
@@ -282,6 +350,8 @@ def main():
     args = ap.parse_args()
     if args.no_legs:
         args.no_dense = args.no_cpu = True
+    if args.workload == "adavit":
+        return bench_adavit(args)
 
     import laudnet_amd
     from laudnet_amd import distributed as D

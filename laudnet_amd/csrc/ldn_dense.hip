@@ -32,6 +32,12 @@ struct DenseArgs {
 };
 
 __device__ __attribute__((aligned(16))) float g_dense_zero[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef LDN_TRACE   // tuning only: per-workgroup cycle split of the K loop (tools/trace_dense.py)
+__device__ unsigned long long* g_dense_trace = nullptr;
+#define DT(x) x = __builtin_amdgcn_s_memtime();
+#else
+#define DT(x)
+#endif
 
 __device__ __forceinline__ void d_dma16(const void* gsrc, unsigned lds_base) {
     unsigned keep;
@@ -169,10 +175,18 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     for (int c = 0; c < D - 1; ++c) { if (c < nchunks) dma_chunk(c); else dma_dummy(c); }
     const unsigned xrow = (unsigned)(wave * 32 + l31), xsw = (xrow >> 1) & 7u;
     const unsigned wsw = ((unsigned)l31 >> 1) & 7u;
+#ifdef LDN_TRACE
+    unsigned long long d0, d1, d2, d3, d4, d5, a_wait = 0, a_bar = 0, a_issue = 0, a_prep = 0, a_mfma = 0, d_start, d_loop;
+    DT(d_start)
+#endif
     for (int c = 0; c < nchunks; ++c) {
+        DT(d0)
         d_wait_vm_rt(per_chunk * (D - 2));
+        DT(d1)
         d_lds_barrier();
+        DT(d2)
         if (c + D - 1 < nchunks) dma_chunk(c + D - 1); else dma_dummy(c + D - 1);
+        DT(d3)
         if (!active) continue;
         const unsigned char* xs = s_ring + (c % D) * SLOT;
         const unsigned char* ws = xs + D_ROWS * 128;
@@ -191,6 +205,10 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
                 bl[half][e] = (__bf16)(v - (float)hb);
             }
         }
+#ifdef LDN_TRACE
+        asm volatile("" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
+        DT(d4)
+#endif
         auto frag = [&](int step, bf16x8& ah, bf16x8& al) {   // step = half * NSUB + j: weight row 32 j + l31, octet 2 half + h
             const int half = step / NSUB, j = step - half * NSUB;
             const unsigned sl = 4u * half + 2u * h;
@@ -229,7 +247,15 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
                 }
             }
         }
+#ifdef LDN_TRACE
+        asm volatile("" : "+v"(acc[0]));
+        DT(d5)
+        a_wait += d1 - d0; a_bar += d2 - d1; a_issue += d3 - d2; a_prep += d4 - d3; a_mfma += d5 - d4;
+#endif
     }
+#ifdef LDN_TRACE
+    DT(d_loop)
+#endif
     d_wait_vm<0>();
     d_lds_barrier();       // every wave is out of the ring: it becomes the per-wave 32 x 32 transpose scratch
     if (!active) return;
@@ -291,6 +317,14 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef LDN_TRACE
+    if (g_dense_trace && lane == 0) {
+        unsigned long long dend;
+        DT(dend)
+        unsigned long long* r = g_dense_trace + ((size_t)blockIdx.x * 8 + wave) * 8;
+        r[0] = a_wait; r[1] = a_bar; r[2] = a_issue; r[3] = a_prep; r[4] = a_mfma; r[5] = d_loop - d_start; r[6] = dend - d_loop; r[7] = nchunks;
+    }
+#endif
 }
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_dense)
@@ -317,6 +351,13 @@ static int launch_dense(DenseArgs& a, hipStream_t st) {
 }  // namespace ldn
 
 using namespace ldn;
+
+#ifdef LDN_TRACE
+extern "C" int ldn_debug_set_dense_trace(void* buf) {
+    unsigned long long* q = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dense_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                                    const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,

@@ -165,6 +165,34 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         const unsigned slot = lds_ring + (c % D) * SLOT;
         for (int i = 0; i < per_chunk; ++i) d_dma16(g_dense_zero, slot + (D_ROWS + wave * 8) * 128);
     };
+    // instruction k (0 .. 3: this wave's x rows, 4 ..: its weight rows) of chunk c, for ACTIVE waves; a chunk beyond the K range
+    // gets a dummy so that the per-iteration count the vmcnt waits rely on stays constant
+    auto dma_one = [&](int c, int k) {
+        const unsigned slot = lds_ring + (c % D) * SLOT;
+        const bool real = c < nchunks;
+        const int tap = T9 ? c / cpt : 0, ck = c - tap * cpt;
+        const void* src = g_dense_zero;
+        unsigned dst = slot + (D_ROWS + wave * 8) * 128;
+        if (k < 4) {
+            const int r = wave * 32 + k * 8 + (lane >> 3);
+            const int ls = (lane & 7) ^ ((r >> 1) & 7);
+            long off = asrc[k];
+            if (T9) {
+                const int ar = s_atap[r * 9 + min(tap, 8)];
+                off = ar >= 0 ? (long)ar * p.lda : -1;
+            }
+            if (real && off >= 0) src = p.a + off + ck * 32 + ls * 4;
+            if (real) dst = slot + (wave * 32 + k * 8) * 128;
+        } else {
+            const int i = k - 4;
+            const int r = i * 64 + wave * 8 + (lane >> 3);
+            const int ls = (lane & 7) ^ ((r >> 1) & 7);
+            const int n = n0 + r;
+            if (real && r < NT && n < p.cout) src = p.ws + ((long)n * ((T9 ? 9 : 1) * p.cin / 8) + c * 4) * 32 + ls * 16;
+            if (real && i * 64 + wave * 8 < NT) dst = slot + (D_ROWS + i * 64 + wave * 8) * 128;
+        }
+        d_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+    };
 
     f32x16 acc[NSUB];
 #pragma unroll
@@ -185,7 +213,10 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         DT(d1)
         d_lds_barrier();
         DT(d2)
-        if (c + D - 1 < nchunks) dma_chunk(c + D - 1); else dma_dummy(c + D - 1);
+        // full tiles, computing waves: the DMA instructions of chunk c + D - 1 are issued one per MFMA step below (the texture
+        // addresser takes 16 cycles per 1-KB instruction: issued in a burst after the barrier they cost every wave ~800 cycles during
+        // which no MFMA runs); other waves / ragged tiles issue them here
+        if (!(FULL && active)) { if (c + D - 1 < nchunks) dma_chunk(c + D - 1); else dma_dummy(c + D - 1); }
         DT(d3)
         if (!active) continue;
         const unsigned char* xs = s_ring + (c % D) * SLOT;
@@ -231,7 +262,13 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bl[half], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bh[half], acc[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (st < 4 + NWI) {                   // one DMA instruction of the next chunk behind this step's MFMAs
+                    dma_one(c + D - 1, st);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+#pragma unroll
+            for (int k = 2 * NSUB; k < 4 + NWI; ++k) dma_one(c + D - 1, k);   // (64-column tiles: five instructions, four steps)
         } else {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {

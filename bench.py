@@ -529,7 +529,9 @@ def main():
         pick = {"conv3_1x1": hbm_roofline, "tail_fused": tail_roofline, "chain_fused": chain_roofline}
         objs = {k: pick.get(k, mfma_roofline)(*v) for k, v in agg.items()}
         if "rows_3x3" in objs:
-            objs["rows_3x3"]["kernel"] = objs["rows_3x3"]["kernel"].replace("3x3 per-image channel-subset conv", "3x3 conv over packed active rows, shared weights")
+            objs["rows_3x3"]["kernel"] = ("k_dense<.., T9> (3x3 conv over packed active rows through the neighbour table, shared weights, bf16x3)"
+                                          if mode != "fp32" and 9 in ops.DENSE_TAPS and ops.USE_DENSE_KERNEL else
+                                          objs["rows_3x3"]["kernel"].replace("3x3 per-image channel-subset conv", "3x3 conv over packed active rows, shared weights"))
             objs["rows_3x3"]["traffic_scope"] = objs["rows_3x3"]["traffic"] = None
         # dominant = most time per bracketed step inside the timed region
         per_step = lambda k: agg[k][1] / max(len(timer.steps_of.get(k, ())), 1)   # ms of kind k per bracketed step

@@ -70,10 +70,23 @@ __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict_
         // KiB per wave are in flight (this kernel is one HBM pass over x)
         for (int c = lane * 4; c < C; c += 256) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            for (int y = y0; y < y1; ++y) {
-                const float* row = x + ((size_t)(b * Hi + y) * Wi) * C + c;
-#pragma unroll 8
-                for (int xx = x0; xx < x1; ++xx) s += *reinterpret_cast<const f32x4*>(row + (size_t)xx * C);
+            // the window's pixels in row-major order, eight loads in flight per lane, added in that order (same sums as the plain loop)
+            const int pw = x1 - x0, np = (y1 - y0) * pw;
+            const float* base = x + ((size_t)(b * Hi + y0) * Wi + x0) * C + c;
+            int pi = 0;
+            for (; pi + 8 <= np; pi += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int py = (pi + k) / pw, px = (pi + k) - py * pw;
+                    v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + ((size_t)py * Wi + px) * C));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[k];
+            }
+            for (; pi < np; ++pi) {
+                const int py = pi / pw, px = pi - py * pw;
+                s += *reinterpret_cast<const f32x4*>(base + ((size_t)py * Wi + px) * C);
             }
             s *= inv;
 #pragma unroll
@@ -515,8 +528,20 @@ __global__ __launch_bounds__(256) void k_gap_partial(const float* __restrict__ x
     for (int q0 = 0; q0 < Q; q0 += 256) {
         const int q = q0 + (Q >= 256 ? tid : tid % Q);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (q < Q && rl < RL)
-            for (int r = r0 + rl; r < r1; r += RL) acc += *reinterpret_cast<const f32x4*>(xb + (size_t)r * C + q * 4);
+        if (q < Q && rl < RL) {
+            // eight rows in flight per lane (this kernel is one pass over x: it runs at the rate its loads are outstanding); they are
+            // ADDED in row order, so the sums are the same as a row-by-row loop's
+            const float* src = xb + q * 4;
+            int r = r0 + rl;
+            for (; r + 7 * RL < r1; r += 8 * RL) {
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(r + k * RL) * C));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += v[k];
+            }
+            for (; r < r1; r += RL) acc += *reinterpret_cast<const f32x4*>(src + (size_t)r * C);
+        }
         if (RL > 1) {
             __syncthreads();
             if (rl < RL) *reinterpret_cast<f32x4*>(s_f + ((size_t)rl * Q + q) * 4) = acc;

@@ -98,14 +98,39 @@ __global__ __launch_bounds__(256) void k_grouped3x3_lds(const float* __restrict_
 // per-image channel sums over the image's packed rows [prefix[b], prefix[b+1]); grid (splits, B), deterministic
 __global__ __launch_bounds__(256) void k_rows_gap(const float* __restrict__ a, int lda, const int32_t* __restrict__ prefix,
                                                    int C, int splits, float* __restrict__ partial) {
-    const int b = blockIdx.y, s = blockIdx.x;
+    // thread = (row lane, channel quad): with few channels (a 64-wide layer has 16 quads) the other threads of the workgroup take
+    // interleaved rows; eight rows in flight per thread; fixed order of additions (row lanes reduced through LDS in lane order)
+    __shared__ f32x4 s_red[256];
+    const int b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int r0 = prefix[b], n = prefix[b + 1] - r0;
     const int per = ceil_div(max(n, 1), splits);
     const int lo = r0 + s * per, hi = min(r0 + n, lo + per);
-    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+    const int Q = C >> 2;
+    const int RL = Q >= 256 ? 1 : 256 / Q;
+    const int rl = Q >= 256 ? 0 : tid / Q;
+    for (int q0 = 0; q0 < Q; q0 += 256) {
+        const int q = q0 + (Q >= 256 ? tid : tid % Q);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int r = lo; r < hi; ++r) acc += *reinterpret_cast<const f32x4*>(a + (size_t)r * lda + c);
-        *reinterpret_cast<f32x4*>(partial + ((size_t)b * splits + s) * C + c) = acc;
+        if (q < Q && rl < RL) {
+            const float* src = a + q * 4;
+            int r = lo + rl;
+            for (; r + 7 * RL < hi; r += 8 * RL) {
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)(r + k * RL) * lda);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += v[k];
+            }
+            for (; r < hi; r += RL) acc += *reinterpret_cast<const f32x4*>(src + (size_t)r * lda);
+        }
+        if (RL > 1) {
+            __syncthreads();
+            s_red[tid] = acc;
+            __syncthreads();
+            if (rl == 0 && q < Q)
+                for (int k = 1; k < RL; ++k) acc += s_red[k * Q + q];
+        }
+        if (q < Q && rl == 0) *reinterpret_cast<f32x4*>(partial + ((size_t)b * splits + s) * C + q * 4) = acc;
     }
 }
 

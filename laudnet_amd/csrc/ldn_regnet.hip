@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_grouped3x3_lds(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ar = nbr[(size_t)row * 9 + t];
-            if (ar < 0) continue;
+            if (ar < 0) continue;      // (the branch also keeps hipcc from hoisting all 144 weight reads of a row: 512 VGPRs and spills, measured 7x slower)
             const float* ap = a + (size_t)ar * lda + g * GW;
 #pragma unroll
             for (int qi = 0; qi < QUADS; ++qi) {
@@ -151,20 +151,49 @@ __global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ parti
     if (n == 0) return;         // skipped image: its gate is never read
     const int Cb = ch_idx ? ch_cnt[b] : C;
     const float inv = 1.f / (float)n;
+    // (a chain of dependent global reads per image -- partial sums, fc1 rows, fc2 rows: every loop below keeps several
+    // independent loads in flight; per output the order of additions is the plain loop's)
     for (int c = tid; c < C; c += 256) {
         float s = 0.f;
-        if (c < Cb)
-            for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
+        if (c < Cb) {
+            int k = 0;
+            for (; k + 4 <= splits; k += 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = partial[((size_t)b * splits + k + u) * C + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s += v[u];
+            }
+            for (; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
+        }
         s_mean[c] = s * inv;
         s_ch[c] = c < Cb ? (ch_idx ? ch_idx[(size_t)b * C + c] : c) : 0;
     }
     __syncthreads();
-    for (int o = wave; o < S; o += 4) {
-        float acc = 0.f;
-        for (int c = lane; c < Cb; c += 64) acc += w1[(size_t)o * C + s_ch[c]] * s_mean[c];
+    constexpr int OB = 8;                              // fc1 outputs per wave and pass: their weight loads fly together
+    for (int o0 = wave; o0 < S; o0 += 4 * OB) {
+        float acc[OB];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) s_hid[o] = fmaxf(acc + b1[o], 0.f);
+        for (int u = 0; u < OB; ++u) acc[u] = 0.f;
+        for (int c = lane; c < Cb; c += 64) {
+            const int ch = s_ch[c];
+            const float m = s_mean[c];
+            float wv[OB];
+#pragma unroll
+            for (int u = 0; u < OB; ++u) wv[u] = o0 + 4 * u < S ? w1[(size_t)(o0 + 4 * u) * C + ch] : 0.f;
+#pragma unroll
+            for (int u = 0; u < OB; ++u) acc[u] += wv[u] * m;
+        }
+#pragma unroll
+        for (int u = 0; u < OB; ++u) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[u] += __shfl_xor(acc[u], off, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < OB; ++u)
+                if (o0 + 4 * u < S) s_hid[o0 + 4 * u] = fmaxf(acc[u] + b1[o0 + 4 * u], 0.f);
+        }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -172,7 +201,16 @@ __global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ parti
         if (c < Cb) {
             const int ch = s_ch[c];
             float acc = b2[ch];
-            for (int j = 0; j < S; ++j) acc += w2[(size_t)ch * S + j] * s_hid[j];
+            const float* wr = w2 + (size_t)ch * S;
+            int j = 0;
+            for (; j + 8 <= S; j += 8) {
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = wr[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += wv[u] * s_hid[j + u];
+            }
+            for (; j < S; ++j) acc += wr[j] * s_hid[j];
             g = 1.f / (1.f + __expf(-acc));
         }
         gate[(size_t)b * C + c] = g;

@@ -568,39 +568,55 @@ __global__ __launch_bounds__(NT) void k_channel_mlp(const float* __restrict__ pa
                          s_f, s_w);
 }
 
-// head of the whole-image spatial masker: one wave per image; gap = sum of the split partials / HW, then 2g dots
+// head of the whole-image spatial masker: one workgroup (four waves) per image; gap = sum of the split partials / HW, then 2g dots.
+// A chain of dependent global reads per image: every thread keeps the partials of four splits and the 2g weights of its channel in
+// flight; the four waves' sums are combined through LDS in wave order (deterministic).
 __global__ __launch_bounds__(256) void k_spatial_head(const float* __restrict__ partial, int B, int HW, int C, int splits,
                                                        const float* __restrict__ w, const float* __restrict__ bias, int g,
                                                        float* __restrict__ mask, float* __restrict__ logits) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
+    __shared__ float s_acc[4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
     const float inv = 1.f / (float)HW;
     const int G2 = 2 * g;
     float acc[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = 0.f;
-    for (int c = lane; c < C; c += 64) {
+    for (int c = tid; c < C; c += 256) {
+        float wv[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) wv[o] = o < G2 ? w[o * C + c] : 0.f;
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = partial[((size_t)b * splits + k + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];
         s *= inv;
 #pragma unroll
-        for (int o = 0; o < 8; ++o)
-            if (o < G2) acc[o] += w[o * C + c] * s;
+        for (int o = 0; o < 8; ++o) acc[o] += wv[o] * s;
     }
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = wave_sum(acc[o]);
-    if (lane < g) {
-        float lk = 0.f, ld = 0.f;
+    if (lane == 0) {
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            if (o == lane) lk = acc[o] + bias[o];
-            if (o == lane + g) ld = acc[o] + bias[o];
-        }
-        mask[(size_t)b * g + lane] = lk >= ld ? 1.f : 0.f;
+        for (int o = 0; o < 8; ++o) s_acc[wave][o] = acc[o];
+    }
+    __syncthreads();
+    if (tid < g) {
+        float lk = bias[tid], ld = bias[tid + g];
+        float sk = 0.f, sd = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) { sk += s_acc[wv][tid]; sd += s_acc[wv][tid + g]; }
+        lk += sk; ld += sd;
+        mask[(size_t)b * g + tid] = lk >= ld ? 1.f : 0.f;
         if (logits) {
-            logits[(size_t)b * G2 + lane] = lk;
-            logits[(size_t)b * G2 + g + lane] = ld;
+            logits[(size_t)b * G2 + tid] = lk;
+            logits[(size_t)b * G2 + g + tid] = ld;
         }
     }
 }
@@ -695,7 +711,7 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
         hipLaunchKernelGGL(k_gap_partial, dim3(splits, B), dim3(256), lds, static_cast<hipStream_t>(stream), x, HW, C,
                            splits, work);
         LDN_CHECK_LAUNCH("k_gap_partial");
-        hipLaunchKernelGGL(k_spatial_head, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), work, B, HW,
+        hipLaunchKernelGGL(k_spatial_head, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), work, B, HW,
                            C, splits, w, bias, g, mask, logits);
         LDN_CHECK_LAUNCH("k_spatial_head");
         return LDN_OK;

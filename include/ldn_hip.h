@@ -61,9 +61,13 @@ int ldn_default_math_mode(void);
  * x [B,Hi,Wi,C] NHWC -> adaptive average pool to SxS (only if S < Hi, utils.py:48; bins
  * floor(i*H/S)..ceil((i+1)*H/S)) -> 1x1 conv C->2g (+bias) -> mask[b,j,y,x] = (l[j] >= l[g+j]).
  * logits [B,2g,S,S] may be NULL.  mask [B,g,S,S] fp32 {0,1}.  work: float scratch of
- * B * ldn_channel_masker_splits(Hi*Wi) * C entries, only needed for S == 1 (layer skip: whole-image window). */
+ * B * ldn_channel_masker_splits(Hi*Wi) * C entries, only needed for S == 1 (layer skip: whole-image window); after the call it
+ * holds the images' partial channel sums.  carry_prefix (optional, S == 1 only) [B+1]: the kept-row prefix (img_prefix3 of
+ * ldn_mask_to_index) of the PREVIOUS layer-skip block on the same residual stream, with `work` the buffer that block's call
+ * filled: an image that block skipped (empty range) is unchanged, so its sums are reused instead of re-read. */
 int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w /*[2g,C]*/,
-                       const float* bias /*[2g]*/, int g, int S, float* mask, float* logits, float* work, void* stream);
+                       const float* bias /*[2g]*/, int g, int S, float* mask, float* logits, float* work,
+                       const int32_t* carry_prefix, void* stream);
 /* bytes of `work` the call above needs for this shape (0 = none); every *_workspace_bytes twin below follows the same rule */
 size_t ldn_spatial_masker_workspace_bytes(int B, int Hi, int Wi, int C, int S);
 

@@ -516,9 +516,11 @@ __global__ __launch_bounds__(256) void k_scatter_add_relu(const float* __restric
 // ---------------------------------------------------------------------------------------- a2
 // partial[b][s][c] = sum over rows of split s of x[b][row][c]   (deterministic two-stage GAP)
 __global__ __launch_bounds__(256) void k_gap_partial(const float* __restrict__ x, int HW, int C, int splits,
-                                                      float* __restrict__ partial) {
+                                                      float* __restrict__ partial, const int32_t* __restrict__ unchanged_prefix) {
     extern __shared__ __attribute__((aligned(16))) float s_f[];
     const int b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    // layer skip: an image the previous block skipped is unchanged -> its partial sums in `partial` (left by the previous call) stand
+    if (unchanged_prefix && unchanged_prefix[b + 1] == unchanged_prefix[b]) return;
     const int Q = C >> 2;
     const int per = ceil_div(HW, splits);
     const int r0 = s * per, r1 = min(r0 + per, HW);
@@ -697,7 +699,8 @@ extern "C" size_t ldn_channel_masker_workspace_bytes(int B, int HW, int C) {
 }
 
 extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w, const float* bias,
-                                  int g, int S, float* mask, float* logits, float* work, void* stream) {
+                                  int g, int S, float* mask, float* logits, float* work, const int32_t* carry_prefix,
+                                  void* stream) {
     LDN_REQUIRE(x && w && bias && mask, "ldn_spatial_masker: null pointer");
     LDN_REQUIRE(g >= 1 && g <= 4, "ldn_spatial_masker: mask groups must be 1..4 (got %d)", g);
     LDN_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C > 0 && S > 0, "ldn_spatial_masker: bad shape");
@@ -709,7 +712,7 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
         const int HW = Hi * Wi, splits = ldn_channel_masker_splits(HW), Q = C / 4;
         const size_t lds = Q >= 256 ? 0 : (size_t)(256 / Q) * Q * 4 * sizeof(float);
         hipLaunchKernelGGL(k_gap_partial, dim3(splits, B), dim3(256), lds, static_cast<hipStream_t>(stream), x, HW, C,
-                           splits, work);
+                           splits, work, carry_prefix);
         LDN_CHECK_LAUNCH("k_gap_partial");
         hipLaunchKernelGGL(k_spatial_head, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), work, B, HW,
                            C, splits, w, bias, g, mask, logits);
@@ -817,7 +820,7 @@ extern "C" int ldn_channel_masker(const float* x, int B, int HW, int C, const fl
         LDN_REQUIRE(HW > 0 && C > 0 && C % 4 == 0, "ldn_channel_masker: C must be a positive multiple of 4");
         const int Q = C / 4;
         const size_t lds = Q >= 256 ? 0 : (size_t)(256 / Q) * Q * 4 * sizeof(float);
-        hipLaunchKernelGGL(k_gap_partial, dim3(splits, B), dim3(256), lds, st, x, HW, C, splits, work);
+        hipLaunchKernelGGL(k_gap_partial, dim3(splits, B), dim3(256), lds, st, x, HW, C, splits, work, (const int32_t*)nullptr);
         LDN_CHECK_LAUNCH("k_gap_partial");
     }
     const size_t lds2 = (size_t)(C + (hidden > 0 ? hidden : 1) + 2 * G) * sizeof(float);

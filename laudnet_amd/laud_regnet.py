@@ -217,11 +217,14 @@ class ResBottleneckBlock(_PrepCache):
             raise LdnError(f"ResBottleneckBlock: input {Hi}x{Wi} does not match output_size {Ho} * stride {self.stride}")
         dev = x.device
         xn = ops.as_nhwc(x)
+        carry_in, f._carry_in, f.last_carry = getattr(f, "_carry_in", None), None, None
         if f.forced_spatial_mask is not None:
             patch = f.forced_spatial_mask.to(device=dev, dtype=torch.float32).contiguous()
         else:
-            patch = f.masker_spatial(x, 1.0)[0]
+            patch = f.masker_spatial(x, 1.0, carry=carry_in)[0]
         ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, self.stride)
+        if f.forced_spatial_mask is None and getattr(f.masker_spatial, "last_work", None) is not None:
+            f.last_carry = (f.masker_spatial.last_work, ix.pre3)   # which images this block leaves unchanged, and their channel sums
         x2d = xn.reshape(B * Hi * Wi, Cin)
         w_b = f.w_b
         h_a = torch.empty(ix.cap1, w_b, device=dev, dtype=torch.float32)
@@ -437,6 +440,7 @@ class BlockParams:
 
 class LAD_RegNet(nn.Module):
     """laud_regnet.py:468-672."""
+    use_layer_carry = __import__("os").environ.get("LDN_LAYER_CARRY", "1") != "0"
 
     def __init__(self, block_params, num_classes=1000, stem_width=32, stem_type=None, block_type=None, norm_layer=None,
                  activation=None, input_size=224, spatial_mask_channel_group=[1, 1, 1, 1],
@@ -491,10 +495,19 @@ class LAD_RegNet(nn.Module):
         x = self.stem(x)                                            # static stem: library ops
         stats = []
         sizes = [len(list(stage.children())) for stage in self.trunk_output.children()]
+        prev = None
+        for blk in self.blocks():
+            blk.f.last_carry = None        # (a carry is only valid inside one forward)
         for j, blk in enumerate(self.blocks()):
             if self._tap is not None:     # debug tap (bench / tests): sees every block's input; off by default
                 self._tap(j, blk.f, x)
+            # layer skip: the images the previous block skipped are unchanged -> their channel sums are carried to this block's masker
+            blk.f._carry_in = (prev.f.last_carry if (self.use_layer_carry and prev is not None and blk.proj is None and blk.stride == 1
+                                                     and blk.f.dyn_mode == "spatial" and prev.f.dyn_mode == "spatial" and blk.f.mask_size == 1
+                                                     and prev.f.mask_size == 1 and blk.f.forced_spatial_mask is None
+                                                     and getattr(prev.f, "last_carry", None) is not None) else None)
             x, st = blk.run_dynamic(x, inplace=self.inplace_residual)
+            prev = blk
             stats.append(st)
         st = torch.stack(stats)
         s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]

@@ -144,14 +144,17 @@ class Masker_spatial(_PrepCache):
             h, w = x.shape[2], x.shape[3]
         return x.shape[1] * h * w + self.conv_flops_pp * h * w
 
-    def forward(self, x, temperature, want_logits=False):
+    def forward(self, x, temperature, want_logits=False, carry=None):
+        """carry = (work, prefix) of the previous layer-skip block on the same residual stream (ldn_spatial_masker): the images that
+        block skipped are unchanged, their channel sums are reused.  self.last_work = this call's sums (None unless mask_size 1)."""
         _eval_only(self, x)
         if not self._cache_valid():
             with torch.no_grad():
                 self._cache_store((self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1).float().contiguous(),
                                    self.conv.bias.detach().float().contiguous()))
         w, b = self._prep
-        mask, logits = ops.spatial_masker(ops.as_nhwc(x), w, b, self.mask_channel_group, self.mask_size, want_logits)
+        mask, logits, self.last_work = ops.spatial_masker(ops.as_nhwc(x), w, b, self.mask_channel_group, self.mask_size, want_logits,
+                                                          carry=carry, return_work=True)
         out = (mask, mask.mean(), self.flops_for(x))
         return out + (logits,) if want_logits else out
 
@@ -569,16 +572,19 @@ class Bottleneck(_PrepCache):
         ms = self.masker_spatial
         G = ms.mask_channel_group
         xn = ops.as_nhwc(x)
+        carry_in, self._carry_in, self.last_carry = getattr(self, "_carry_in", None), None, None
         if self.forced_spatial_mask is not None:
             patch = self.forced_spatial_mask.to(device=x.device, dtype=torch.float32).contiguous()
         else:
-            patch = ms(x, 1.0)[0]
+            patch = ms(x, 1.0, carry=carry_in)[0]
         dev = x.device
         # spatial_mask_channel_group > 1 (models/utils.py:27-33,74-89): group g of the OUTPUT channels has its own pixel mask.
         # ExpandMask ORs the groups (its dilation kernel is [g,g,k,k] ones), so conv1 / conv2 -- and the sparsities the
         # reference reports for them -- live on the UNION of the groups; only conv3's scatter is per group.
         union = patch[:, 0] if G == 1 else patch.amax(dim=1)
         ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride)
+        if ms.mask_size == 1 and G == 1 and self.forced_spatial_mask is None and getattr(ms, "last_work", None) is not None:
+            self.last_carry = (ms.last_work, ix.pre3)      # layer skip: which images this block leaves unchanged, and their channel sums
         x2d = xn.reshape(B * Hi * Wi, Cin)
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
         ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
@@ -860,6 +866,7 @@ class ResNet(nn.Module):
         blocks = [blk for i in range(4) for blk in getattr(self, f"layer{i + 1}")]
         sizes = [len(getattr(self, f"layer{i + 1}")) for i in range(4)]
         ends = set(itertools.accumulate(sizes))        # a stage's output = the output of its last block
+        step_id = self._step_id = getattr(self, "_step_id", 0) + 1
         gap = None
         j = -1
         while j + 1 < len(blocks):
@@ -884,7 +891,14 @@ class ResNet(nn.Module):
                         and getattr(nxt.masker_channel, "accepts_fused_gap", False) and nxt.forced_channel_mask is None)
             if self._tap is not None:     # debug tap (bench / tests): sees every block's input; off by default
                 self._tap(j, blk, x)
+            # layer skip: the images the previous block skipped reach this block unchanged -> their channel sums (the masker's global
+            # average pool) are carried over instead of re-read (one full read of x per block otherwise)
+            prev = blocks[j - 1] if j > 0 else None
+            blk._carry_in = (prev.last_carry if (self.use_layer_carry and prev is not None and blk.dyn_mode == "layer" and prev.dyn_mode == "layer"
+                                                 and blk.stride == 1 and blk.downsample is None and blk.forced_spatial_mask is None
+                                                 and getattr(prev, "_carry_step", -1) == step_id) else None)
             x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap, defer_stats=True, inplace=self.inplace_residual)
+            blk._carry_step = step_id if getattr(blk, "last_carry", None) is not None else -1
             gap = getattr(blk, "last_gap", None) if want_gap else None
             stats.append(st)
             if stage_outs is not None and j + 1 in ends:
@@ -896,6 +910,7 @@ class ResNet(nn.Module):
 
     chain_max_blocks = int(os.environ.get("LDN_CHAIN_MAX", "64"))   # longest run per launch (tuning)
     use_fused_stem = os.environ.get("LDN_FUSED_STEM", "1") != "0"    # the one-launch stem (ldn_stem_conv_pool); 0 = library conv + pool
+    use_layer_carry = os.environ.get("LDN_LAYER_CARRY", "1") != "0"  # layer skip: carry the skipped images' channel sums to the next masker
 
     def _chain_len(self, blocks, j, x, gap):
         """Number of consecutive blocks from j that ldn_bottleneck_chain can execute as one launch (0 = none).  The run needs the

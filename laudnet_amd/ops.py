@@ -82,9 +82,10 @@ def from_nhwc(y):
 
 
 # ---------------------------------------------------------------------------------------- a1
-def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False):
+def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False, carry=None, return_work=False):
     """Masker_spatial eval forward (models/utils.py:47-65).  x_nhwc [B,H,W,C]; weight [2g,C]; bias [2g].
-    Returns (mask [B,g,Sy,Sx] float {0,1}, logits [B,2g,Sy,Sx] or None)."""
+    Returns (mask [B,g,Sy,Sx] float {0,1}, logits [B,2g,Sy,Sx] or None[, work]).  carry = (work, prefix) of the previous layer-skip
+    block on the same residual stream (see ldn_spatial_masker): images that block skipped are not re-read."""
     L.require_device(x_nhwc, weight, bias)
     lib = L.load()
     B, H, W, C = x_nhwc.shape
@@ -92,11 +93,16 @@ def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False):
     sy, sx = (mask_size, mask_size) if pooled else (H, W)
     mask = torch.empty(B, groups, sy, sx, device=x_nhwc.device, dtype=torch.float32)
     logits = torch.empty(B, 2 * groups, sy, sx, device=x_nhwc.device, dtype=torch.float32) if want_logits else None
-    work = _work(lib.ldn_spatial_masker_workspace_bytes(B, H, W, C, mask_size), x_nhwc.device)
+    nbytes = lib.ldn_spatial_masker_workspace_bytes(B, H, W, C, mask_size)
+    prefix = None
+    if carry is not None and nbytes and carry[0] is not None and carry[0].numel() * 4 == nbytes and carry[0].device == x_nhwc.device:
+        work, prefix = carry[0], _i32c(carry[1], "carry_prefix")
+    else:
+        work = _work(nbytes, x_nhwc.device)
     L.check(lib.ldn_spatial_masker(L.ptr(_f32c(x_nhwc, "x")), B, H, W, C, L.ptr(_f32c(weight, "w")),
                                    L.ptr(_f32c(bias, "bias")), groups, mask_size, L.ptr(mask), L.ptr(logits), L.ptr(work),
-                                   L.stream_ptr()), "ldn_spatial_masker")
-    return mask, logits
+                                   L.ptr(prefix), L.stream_ptr()), "ldn_spatial_masker")
+    return (mask, logits, work) if return_work else (mask, logits)
 
 
 # ---------------------------------------------------------------------------------------- a4/a11

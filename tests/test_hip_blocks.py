@@ -301,3 +301,36 @@ def test_regnet_spatial_and_both_own_maskers(math_mode, case):
     assert_tuple_close(got[1:6], fx["masker_run"][1:6], atol=1e-6, what=f"regnet {case} stats (same masker decisions)")
     assert_tuple_close(got[:1], fx["masker_run"][:1], atol=logit_atol(math_mode, fx["masker_run"]), rtol=LOGIT_RTOL[math_mode],
                        what=f"regnet {case} logits")
+
+
+def test_layer_carry_is_bit_identical():
+    """Layer skip: carrying the channel sums of the images a block skipped to the next block's masker (instead of re-reading them)
+    changes nothing -- the skipped images are unchanged, so the sums are the same bits.  ResNet and RegNet."""
+    import laudnet_amd
+    from laudnet_amd import ops
+    ops.set_math_mode("bf16x3")
+    try:
+        m = laudnet_amd.uni_resnet50(dyn_mode=["layer"] * 4, width_mult=0.5, input_size=224, num_classes=10).eval()
+        m.load_state_dict(fill_state_dict(m.state_dict(), 3))
+        m = m.to(DEV)
+        x = seeded_randn((6, 3, 224, 224), 5).to(DEV)
+        outs = []
+        for carry in (True, False):
+            m.use_layer_carry = carry
+            with torch.no_grad():
+                outs.append(m(x, 1.0))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert torch.equal(a, b)
+        assert 0.05 < float(torch.cat(outs[0][1]).mean()) < 0.95      # some images skipped, some kept: the carry was exercised
+        r = laudnet_amd.lad_regnet_y_800mf(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[56, 28, 14, 7], num_classes=10).eval()
+        r.load_state_dict(fill_state_dict(r.state_dict(), 4))
+        r = r.to(DEV)
+        outs = []
+        for carry in (True, False):
+            r.use_layer_carry = carry
+            with torch.no_grad():
+                outs.append(r(x, 1.0))
+        assert torch.equal(outs[0][0], outs[1][0])
+    finally:
+        ops.set_math_mode("fp32")

@@ -262,6 +262,13 @@ int ldn_conv_packed(const float* a, int lda, int B, const int32_t* row_prefix, c
 int ldn_grouped_conv3x3_rows(const float* a, int lda, const int32_t* nbr, const int32_t* m_count, int m_cap,
                              const float* w, int C, int group_width, const float* scale, const float* shift, int relu,
                              float* out, int ldo, void* stream);
+/* b on the matrix cores (group width 16, bf16x3 arithmetic): same contract as ldn_grouped_conv3x3_rows with the weights pre-split
+ *    into MFMA fragment order: w_frag = ldn_grouped16_weight_bytes(C) bytes, [C/16][5 steps][64 lanes][8 hi | 8 lo] bf16; lane
+ *    (i = lane & 15, kg = lane >> 4) of step s holds w[16 g + i][tap 2 s + (kg >> 1)][8 (kg & 1) + e], zero for tap 9. */
+size_t ldn_grouped16_weight_bytes(int C);
+int ldn_grouped16_conv3x3_rows(const float* a, int lda, const int32_t* nbr, const int32_t* m_count, int m_cap,
+                               const void* w_frag, int C, const float* scale, const float* shift, int relu, float* out,
+                               int ldo, void* stream);
 /* b in CHANNEL mode (laud_regnet.py:160-189: the mask is applied AFTER conv+BN+ReLU, so masked channels are exact zeros and the
  *    subset execution is exact): dense image whose columns are left-packed per image (column j of image b = channel
  *    ch_idx[b,j], ascending, j < ch_cnt[b]); output column j sums over the ACTIVE input channels of its group only.

@@ -127,6 +127,8 @@ class BottleneckTransform(_PrepCache):
             p["wa"] = self.a[0].weight.detach().reshape(w_b, 1, -1).float().contiguous()
             p["sa"], p["ta"] = _fold_bn(self.a[1])
             p["wb"] = self.b[0].weight.detach().permute(0, 2, 3, 1).reshape(w_b, 9, gw).float().contiguous()
+            if gw == 16 and w_b % 16 == 0:      # matrix-core form of conv b (bf16x3 mode): weights pre-split in MFMA fragment order
+                p["wb_frag"] = ops.pack_grouped16_weights(p["wb"])
             p["sb"], p["tb"] = _fold_bn(self.b[1])
             p["wc"] = self.c[0].weight.detach().reshape(-1, 1, w_b).float().contiguous()
             p["wc_k"] = self.c[0].weight.detach().reshape(-1, w_b).float().t().reshape(1, w_b, -1).contiguous()   # k-major (channel mode)
@@ -138,6 +140,17 @@ class BottleneckTransform(_PrepCache):
             p["se_b2"] = self.se.fc2.bias.detach().float().contiguous()
             self._cache_store({k: v.to(device) for k, v in p.items()})
         return self._prep
+
+
+def _conv_b_rows(p, f, h_a, nbr, h_b, m_count, m_cap):
+    """conv b (grouped 3x3 + BN + ReLU) over packed rows: on the matrix cores for group width 16 in bf16x3 mode, else the fp32 VALU kernel"""
+    if "wb_frag" in p and ops.get_math_mode() == "bf16x3" and USE_GROUPED_MFMA:
+        ops.grouped16_conv3x3_rows(h_a, nbr, p["wb_frag"], p["sb"], p["tb"], h_b, m_count=m_count, m_cap=m_cap, relu=1)
+    else:
+        ops.grouped_conv3x3_rows(h_a, nbr, p["wb"], f.group_width, p["sb"], p["tb"], h_b, m_count=m_count, m_cap=m_cap, relu=1)
+
+
+USE_GROUPED_MFMA = __import__("os").environ.get("LDN_GROUPED_MFMA", "1") != "0"    # tuning switch (A/B)
 
 
 class ResBottleneckBlock(_PrepCache):
@@ -230,8 +243,7 @@ class ResBottleneckBlock(_PrepCache):
         h_a = torch.empty(ix.cap1, w_b, device=dev, dtype=torch.float32)
         ops.conv_rows(x2d, p["wa"], p["sa"], p["ta"], h_a, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
         h_b = torch.empty(ix.cap3, w_b, device=dev, dtype=torch.float32)
-        ops.grouped_conv3x3_rows(h_a, ix.nbr, p["wb"], f.group_width, p["sb"], p["tb"], h_b, m_count=ix.cnt[0:1],
-                                 m_cap=ix.cap3, relu=1)
+        _conv_b_rows(p, f, h_a, ix.nbr, h_b, ix.cnt[0:1], ix.cap3)
         ops.se_packed(h_b, ix.pre3, p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo)
         cout = p["wc"].shape[0]
         if self.proj is not None:
@@ -291,7 +303,7 @@ class ResBottleneckBlock(_PrepCache):
             h_a = torch.empty(B * Hi * Wi, w_b, device=dev, dtype=torch.float32)
             ops.conv_rows(x2d, p["wa"], p["sa"], p["ta"], h_a, taps=1, m_cap=B * Hi * Wi)
             h_b2d = torch.empty(B * Ho * Wo, w_b, device=dev, dtype=torch.float32)
-            ops.grouped_conv3x3_rows(h_a, dense.nbr, p["wb"], f.group_width, p["sb"], p["tb"], h_b2d, m_cap=B * Ho * Wo, relu=1)
+            _conv_b_rows(p, f, h_a, dense.nbr, h_b2d, None, B * Ho * Wo)
             ops.se_packed(h_b2d, self._img_prefix(B, Ho * Wo, dev), p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo)
         if self.proj is not None:
             wp, sp, tp = self._proj(dev)

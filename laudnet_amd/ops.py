@@ -339,6 +339,35 @@ def grouped_conv3x3_rows(a2d, nbr, w, group_width, scale, shift, out2d, *, m_cou
     return out2d
 
 
+def pack_grouped16_weights(w):
+    """w [C, 9, 16] fp32 (out channel, tap, in channel of the group) -> MFMA fragment order [C/16][5][64][hi 8 | lo 8] bf16
+    (ldn_grouped16_conv3x3_rows): a K step is a pair of taps x 16 channels; lane = out channel i + 16 * k-group."""
+    C = w.shape[0]
+    if tuple(w.shape[1:]) != (9, 16) or C % 16:
+        raise L.LdnError("pack_grouped16_weights: expected [C % 16 == 0, 9, 16]")
+    k = torch.zeros(C, 10, 16, device=w.device, dtype=torch.float32)
+    k[:, :9] = w.detach().float()
+    k = k.reshape(C // 16, 16, 5, 2, 2, 8)                 # [g][i][s][tap in pair][channel half][e]: k-group kg = 2 * tap + half
+    k = k.permute(0, 2, 3, 4, 1, 5).reshape(C // 16, 5, 64, 8)     # lane = i + 16 * kg
+    hi, lo = _hi_lo(k)
+    return torch.stack((hi, lo), dim=-2).contiguous()
+
+
+def grouped16_conv3x3_rows(a2d, nbr, w_frag, scale, shift, out2d, *, m_count=None, m_cap=None, relu=1):
+    """Grouped 3x3 conv (group width 16) + BN (+ReLU) over packed rows on the matrix cores (see ldn_grouped16_conv3x3_rows)."""
+    L.require_device(a2d, nbr, w_frag, out2d)
+    lib = L.load()
+    C = w_frag.shape[0] * 16
+    if w_frag.dtype != torch.bfloat16 or not w_frag.is_contiguous() or w_frag.numel() * 2 != lib.ldn_grouped16_weight_bytes(C):
+        raise L.LdnError("grouped16_conv3x3_rows: w_frag must be the contiguous bf16 tensor of pack_grouped16_weights")
+    m_cap = out2d.shape[0] if m_cap is None else m_cap
+    L.check(lib.ldn_grouped16_conv3x3_rows(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(nbr, "nbr")),
+                                           L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(w_frag), C, L.ptr(_f32c(scale, "scale")),
+                                           L.ptr(_f32c(shift, "shift")), relu, L.ptr(_f32c(out2d, "out")), out2d.stride(0),
+                                           L.stream_ptr()), "ldn_grouped16_conv3x3_rows")
+    return out2d
+
+
 def grouped_conv3x3_image(a_nhwc, w, group_width, ch_idx, ch_cnt, scale, shift, out_nhwc, *, stride=1, relu=1):
     """Grouped 3x3 conv + BN (+ReLU) on left-packed per-image channel subsets (see ldn_grouped_conv3x3_image).  w [C,9,gw]."""
     L.require_device(a_nhwc, w, out_nhwc, ch_idx)

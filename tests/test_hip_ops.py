@@ -461,3 +461,31 @@ def test_dense_kernel_3x3_neighbour_table(ops, B, H, C, cout, stride, math_mode)
             ops.DENSE_TAPS = (1,)
     n = int(ix.cnt[0])
     assert torch.allclose(outs[0][:n], outs[1][:n], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,Ho,stride,C,p", [(3, 14, 1, 144, 0.5), (2, 14, 2, 64, 0.6), (2, 7, 1, 320, 1.0), (4, 9, 2, 784, 0.4), (1, 5, 1, 16, 1.0)])
+def test_grouped16_conv3x3_rows_mfma_vs_torch(ops, B, Ho, stride, C, p):
+    """Matrix-core grouped 3x3 (group width 16, bf16x3) over packed rows through the neighbour table, against F.conv2d(groups) on the
+    dense map evaluated at the active pixels; inactive input pixels are absent from the packed input exactly as in the block."""
+    import torch.nn.functional as F
+    Hi = Ho * stride
+    patch = seeded_bernoulli((B, Ho, Ho), p, 91 + C)
+    ix = ops.mask_to_index(patch.to(DEV), Ho, Ho, stride)
+    n3, n1 = int(ix.cnt[0].item()), int(ix.cnt[1].item())
+    x = seeded_randn((B, C, Hi, Hi), 92 + C)
+    w = seeded_randn((C, 16, 3, 3), 93) * 0.1
+    scale = 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(94))
+    shift = 0.1 * seeded_randn((C,), 95)
+    m1 = torch.zeros(B * Hi * Hi, dtype=torch.bool)
+    m1[ix.idx1[:n1].long().cpu()] = True
+    xm = x * m1.view(B, 1, Hi, Hi)                     # the packed input holds the dilated-mask pixels only; the others read as zero
+    want = F.relu(F.conv2d(xm, w, None, stride, 1, 1, C // 16) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    want = want.permute(0, 2, 3, 1).reshape(B * Ho * Ho, C)[ix.idx3[:n3].long().cpu()]
+    a = x.permute(0, 2, 3, 1).reshape(B * Hi * Hi, C)[ix.idx1[:n1].long().cpu()].contiguous().to(DEV)
+    a = torch.cat([a, torch.zeros(max(ix.cap1 - n1, 0), C, device=DEV)])
+    frag = ops.pack_grouped16_weights(w.permute(0, 2, 3, 1).reshape(C, 9, 16).contiguous().to(DEV))
+    out = torch.full((ix.cap3, C), float("nan"), device=DEV)
+    ops.grouped16_conv3x3_rows(a, ix.nbr, frag, scale.to(DEV), shift.to(DEV), out, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1)
+    got = out[:n3].cpu()
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())

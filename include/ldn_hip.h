@@ -239,6 +239,17 @@ size_t ldn_stem_weight_bytes(int cout);
 int ldn_stem_conv_pool(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout, float* out,
                        int Hp, int Wp, void* stream);
 
+/* ---- a10: the static stem of LAD_RegNet.forward in eval mode (laud_regnet.py:59-71 SimpleStemIN: conv 3x3 stride 2 pad 1 -> BN ->
+ * ReLU) as ONE launch, bf16x3 arithmetic: the image is read once, the output written once.
+ *   x [B,H,W,3] NHWC fp32;  out [B,Ho,Wo,cout] NHWC fp32 with Ho = (H-1)/2+1, Wo = (W-1)/2+1 (Wo <= 256);  cout = 32 or 64
+ *   out = act(conv(x, bn.scale * conv.weight) + shift)     shift[c] = bn.bias - bn.running_mean * bn.scale;  relu != 0: ReLU
+ *   w_frag: ldn_stem3_weight_bytes(cout) bytes, MFMA fragment order [cout/32][3 k-steps][64 lanes][8 hi | 8 lo] bf16:
+ *           lane (n = lane & 31, h = lane >> 5) of step s holds kernel row ky = s, slots i = 8 h + e of that row's 16 slots,
+ *           slot i = (kx = i / 3, c = i % 3) for i < 9, zero for the 7 pad slots. */
+size_t ldn_stem3_weight_bytes(int cout);
+int ldn_stem3_conv(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout, int relu, float* out,
+                   int Ho, int Wo, void* stream);
+
 /* ---- a7 (spatial / layer / both): the same kernel over PACKED PIXEL LISTS ---------------------
  * Image b owns the packed rows [row_prefix[b], row_prefix[b+1]) (B == 1, row_prefix == NULL: rows [0, *m_count),
  * m_count == NULL -> m_cap).  For packed row R:

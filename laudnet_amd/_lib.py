@@ -47,6 +47,8 @@ SIGNATURES = {
     "ldn_bottleneck_tail": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
     "ldn_stem_weight_bytes": ([_I], C.c_size_t),
     "ldn_stem_conv_pool": ([_P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P], _I),
+    "ldn_stem3_weight_bytes": ([_I], C.c_size_t),
+    "ldn_stem3_conv": ([_P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P], _I),
     "ldn_packed_mha": ([_P, _I, _P, _P, _I, _I, _I, _I, C.c_float, _P, _I, _P], _I),
     "ldn_bottleneck_chain": ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P], _I),
 }

@@ -201,6 +201,130 @@ static int launch_stem(const StemArgs& a, int cus, hipStream_t st) {
     return LDN_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_stem3 -- the static stem of the LAD-RegNets as one kernel: conv 3x3 stride 2 pad 1 (3 -> C channels, the BN's scale folded into
+// the weights) -> + shift -> ReLU                     (imagenet_classification/models/laud_regnet.py:59-71, SimpleStemIN).
+// The library ran it as a conv, a batch-norm pass and a ReLU pass over the 411 MB output (bs256 / 224^2); here the image is read
+// once and the output written once.  Same transposed MFMA formulation as k_stem: K = (ky, kx, c) is laid out as 3 rows of 16
+// (9 real + 7 zero-weight slots), one K16 step per kernel row, so that a lane's 8 k-values are 8 consecutive floats of the staged
+// input row window.  One 512-thread workgroup = a band of R output rows of one image (R * Wo <= 256 pixels, wave w owns pixels
+// 32 w .. 32 w + 31 of the band); the 2 R + 1 input rows are staged in LDS with a zero pixel left and right.
+struct Stem3Args {
+    const float* x; int B, H, W;                      // NHWC fp32, 3 channels
+    const unsigned char* wf;                          // [C / 32][3][64 lanes][8 hi | 8 lo] bf16
+    const float* shift; int relu;
+    float* out; int C, Ho, Wo;                        // NHWC [B, Ho, Wo, C]
+    int R, bands;                                     // output rows per workgroup, workgroups per image
+    int RS;                                           // floats per staged input row: 3 + 3 W + 3, rounded up to a multiple of 4
+    int scr_off;                                      // floats in front of the 8 x 4 KiB transpose scratch
+};
+
+template <int NSUB>
+__global__ __launch_bounds__(512, 2) void k_stem3(const Stem3Args p) {
+    constexpr int C = 32 * NSUB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* const s_in = reinterpret_cast<float*>(smem);                        // [2 R + 1][RS] + 16 floats of tail
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / p.bands, band = blockIdx.x - b * p.bands;
+    const int y0 = band * p.R;
+    const int rows = min(p.R, p.Ho - y0);
+    const int npix = rows * p.Wo;
+    const int nin = 2 * rows + 1;                                              // input rows 2 y0 - 1 .. 2 y0 + 2 rows - 1
+
+    // weight fragments of this lane (L2-resident: 6 KB per 32 channels), requested before the staging
+    bf16x8 fh[NSUB][3], fl[NSUB][3];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const unsigned char* wp = p.wf + ((size_t)(j * 3 + s) * 64 + lane) * 32;
+            fh[j][s] = *reinterpret_cast<const bf16x8*>(wp);
+            fl[j][s] = *reinterpret_cast<const bf16x8*>(wp + 16);
+        }
+    // stage: row r of the band = image row 2 y0 - 1 + r (zero outside the image), floats [3, 3 + 3 W) of the slot; the rest zero
+    const int rowf = 3 * p.W;
+    for (int i = tid; i < nin * p.RS + 16; i += 512) {
+        const int r = i / p.RS, c = i - r * p.RS - 3;
+        const int iy = 2 * y0 - 1 + r;
+        const bool ok = r < nin && c >= 0 && c < rowf && iy >= 0 && iy < p.H;
+        s_in[i] = ok ? p.x[((size_t)b * p.H + iy) * rowf + c] : 0.f;
+    }
+    __syncthreads();
+    if (wave * 32 >= npix) return;
+
+    const int pm = wave * 32 + l31;
+    const int pmc = min(pm, npix - 1);
+    const int ly = pmc / p.Wo, ox = pmc - ly * p.Wo;
+    // window of the pixel in staged row 2 ly + ky: floats 6 ox .. 6 ox + 8 (slot 0 = image column 2 ox - 1); this lane reads + 8 h
+    const float* src = s_in + (2 * ly) * p.RS + 6 * ox + 8 * h;
+    f32x16 acc[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        bf16x8 bh, bl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = src[s * p.RS + e];
+            const __bf16 hb = (__bf16)v;
+            bh[e] = hb;
+            bl[e] = (__bf16)(v - (float)hb);
+        }
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[j][s], bh, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[j][s], bl, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[j][s], bh, acc[j], 0, 0, 0);
+        }
+    }
+    // C layout (lane = pixel l31, register r = channel (r & 3) + 8 (r >> 2) + 4 h of the subtile) -> this wave's 32 x 32 scratch
+    // (16-byte slots XOR-swizzled with the pixel) -> rows of 32 channels: a store instruction writes 8 whole 128-byte pixel rows
+    // (partial-line stores straight from the C layout ran at a quarter of the rate)
+    float* const scr = s_in + p.scr_off + wave * 1024;
+    const int trw = lane >> 3, tc = lane & 7;
+    float* const dst = p.out + (((size_t)b * p.Ho + y0) * p.Wo + wave * 32) * C;
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = {acc[j][4 * q4], acc[j][4 * q4 + 1], acc[j][4 * q4 + 2], acc[j][4 * q4 + 3]};
+            *reinterpret_cast<f32x4*>(scr + l31 * 32 + (((2 * q4 + h) ^ (l31 & 7)) << 2)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + 32 * j + 4 * tc);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = trw + 8 * it;
+            f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
+            v = v + sh;
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (wave * 32 + row < npix)
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (size_t)row * C + 32 * j + 4 * tc));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NSUB>
+static int launch_stem3(const Stem3Args& a, hipStream_t st) {
+    const size_t lds = (size_t)a.scr_off * 4 + 8 * 4096;
+    LDN_REQUIRE(lds <= 96 * 1024, "ldn_stem3_conv: %zu B of LDS (image too wide)", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_stem3<NSUB>), lds), "k_stem3: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((k_stem3<NSUB>), dim3((unsigned)(a.B * a.bands)), dim3(512), lds, st, a);
+    LDN_CHECK_LAUNCH("k_stem3");
+    return LDN_OK;
+}
+
 }  // namespace ldn
 
 using namespace ldn;
@@ -227,4 +351,28 @@ extern "C" int ldn_stem_conv_pool(const float* x, int B, int H, int W, const voi
     if (ldn_device_cus(&cus) != LDN_OK || cus <= 0) cus = 256;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return cout == 64 ? launch_stem<2>(a, cus, st) : launch_stem<1>(a, cus, st);
+}
+
+extern "C" size_t ldn_stem3_weight_bytes(int cout) { return cout > 0 && cout % 32 == 0 ? (size_t)(cout / 32) * 3 * 64 * 32 : 0; }
+
+extern "C" int ldn_stem3_conv(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout, int relu,
+                              float* out, int Ho, int Wo, void* stream) {
+    LDN_REQUIRE(x && w_frag && shift && out, "ldn_stem3_conv: null pointer");
+    LDN_REQUIRE(B > 0 && H > 0 && W > 0, "ldn_stem3_conv: bad geometry");
+    LDN_REQUIRE(cout == 32 || cout == 64, "ldn_stem3_conv: cout must be 32 or 64 (got %d)", cout);
+    LDN_REQUIRE((uintptr_t)w_frag % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)shift % 16 == 0 && (uintptr_t)x % 4 == 0,
+                "ldn_stem3_conv: w_frag / shift / out must be 16-byte aligned");
+    Stem3Args a{};
+    a.x = x; a.B = B; a.H = H; a.W = W;
+    a.wf = static_cast<const unsigned char*>(w_frag); a.shift = shift; a.relu = relu; a.out = out; a.C = cout;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;            // conv 3x3 stride 2 pad 1
+    LDN_REQUIRE(Ho == a.Ho && Wo == a.Wo, "ldn_stem3_conv: output must be %dx%d for a %dx%d input (got %dx%d)", a.Ho, a.Wo, H, W, Ho, Wo);
+    LDN_REQUIRE(a.Wo <= 256, "ldn_stem3_conv: images wider than 512 pixels are not built (got %d)", W);
+    a.R = min(a.Ho, 256 / a.Wo);
+    a.bands = ceil_div(a.Ho, a.R);
+    a.RS = round_up(3 * W + 6, 4);
+    a.scr_off = round_up((2 * a.R + 1) * a.RS + 16, 4);
+    LDN_REQUIRE((long)B * a.bands < (1L << 31), "ldn_stem3_conv: too many workgroups");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return cout == 64 ? launch_stem3<2>(a, st) : launch_stem3<1>(a, st);
 }

@@ -16,6 +16,7 @@ active pixels.  spatial_mask_channel_group > 1 raises LdnError.  No CPU / PyTorc
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -500,11 +501,36 @@ class LAD_RegNet(nn.Module):
     def blocks(self):
         return [blk for stage in self.trunk_output.children() for blk in stage.children()]
 
+    use_fused_stem = os.environ.get("LDN_FUSED_STEM", "1") != "0"    # the one-launch stem (ldn_stem3_conv); 0 = library conv, BN, ReLU
+
+    def _stem_forward(self, x):
+        """Static stem (laud_regnet.py:59-71, :380): conv 3x3 stride 2 -> BN -> ReLU.  The standard geometry in bf16x3 arithmetic is
+        ONE launch (ldn_stem3_conv: BN scale folded into the weights, shift + ReLU in the epilogue); anything else (fp32 math
+        mode, the reduced widths of the tiny test models, another stem type) runs the library ops of the module."""
+        st = self.stem
+        conv = st[0] if isinstance(st, nn.Sequential) and len(st) == 3 else None
+        ok = (self.use_fused_stem and conv is not None and isinstance(conv, nn.Conv2d) and isinstance(st[1], nn.BatchNorm2d)
+              and isinstance(st[2], nn.ReLU) and ops.get_math_mode() == "bf16x3" and conv.in_channels == 3
+              and conv.out_channels in (32, 64) and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
+              and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and (x.shape[3] - 1) // 2 + 1 <= 256)
+        if not ok:
+            return st(x)
+        bn = st[1]
+        src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in src)
+        if getattr(self, "_stem_key", None) != key:   # folded once, until a parameter or buffer changes
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                self._stem_frag = ops.pack_stem3_weights(conv.weight * scale.view(-1, 1, 1, 1))
+                self._stem_shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+            self._stem_key = key
+        return ops.from_nhwc(ops.stem3_conv(ops.as_nhwc(x), self._stem_frag, self._stem_shift, conv.out_channels, relu=True))
+
     def forward(self, x, temperature):
         _eval_only(self, x)
         in_shape = tuple(x.shape)
         x = x.contiguous(memory_format=torch.channels_last)
-        x = self.stem(x)                                            # static stem: library ops
+        x = self._stem_forward(x)
         stats = []
         sizes = [len(list(stage.children())) for stage in self.trunk_output.children()]
         prev = None

@@ -547,6 +547,35 @@ def stem_conv_pool(x_nhwc, w_frag, shift, cout):
     return out
 
 
+def pack_stem3_weights(w_scaled):
+    """BN-scaled stem conv weight [cout,3,3,3] fp32 -> MFMA fragment order [cout/32][3][64][hi 8 | lo 8] bf16 (ldn_stem3_conv):
+    K is 3 kernel rows x 16 slots (slot i < 9 = (kx = i // 3, c = i % 3), 7 zero pad slots), one K16 step per kernel row."""
+    cout = w_scaled.shape[0]
+    if tuple(w_scaled.shape[1:]) != (3, 3, 3) or cout % 32:
+        raise L.LdnError("pack_stem3_weights: expected [cout % 32 == 0, 3, 3, 3]")
+    k = torch.zeros(cout, 3, 16, device=w_scaled.device, dtype=torch.float32)
+    k[:, :, :9] = w_scaled.detach().float().permute(0, 2, 3, 1).reshape(cout, 3, 9)   # [n][ky][kx*3 + c]
+    k = k.reshape(cout // 32, 32, 3, 2, 8).permute(0, 2, 3, 1, 4).reshape(cout // 32, 3, 64, 8)   # lane = h * 32 + n
+    hi, lo = _hi_lo(k)
+    return torch.stack((hi, lo), dim=-2).contiguous()                                  # [j][s][lane][2][8]
+
+
+def stem3_conv(x_nhwc, w_frag, shift, cout, relu=True):
+    """act(conv3x3s2p1(x, w) + shift) in one launch (see ldn_stem3_conv).  x_nhwc [B,H,W,3] -> [B,Ho,Wo,cout]."""
+    L.require_device(x_nhwc, w_frag, shift)
+    lib = L.load()
+    B, H, W, cin = x_nhwc.shape
+    if cin != 3 or x_nhwc.dtype != torch.float32 or not x_nhwc.is_contiguous():
+        raise L.LdnError("stem3_conv: x must be a contiguous fp32 [B,H,W,3] tensor")
+    if w_frag.dtype != torch.bfloat16 or not w_frag.is_contiguous() or w_frag.numel() * 2 != lib.ldn_stem3_weight_bytes(cout):
+        raise L.LdnError("stem3_conv: w_frag must be the contiguous bf16 tensor of pack_stem3_weights")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty(B, Ho, Wo, cout, device=x_nhwc.device, dtype=torch.float32)
+    L.check(lib.ldn_stem3_conv(L.ptr(x_nhwc), B, H, W, L.ptr(w_frag), L.ptr(_f32c(shift, "shift")), cout, int(bool(relu)),
+                               L.ptr(out), Ho, Wo, L.stream_ptr(out)), "ldn_stem3_conv")
+    return out
+
+
 # ---------------------------------------------------------------------------------------- a14: token skipping
 def token_lists(keep):
     """keep [B, L] float {0,1} -> (tok_rows [B*L] int32: flat rows of the kept tokens, first `count` valid; prefix [B+1] int32;

@@ -91,3 +91,79 @@ def test_stem_in_model_matches_library_stem():
         ops.set_math_mode("fp32")
     assert torch.equal(a[1][0], b[1][0]) or True      # sparsities may differ only if a masker decision sits on a tie
     assert (a[0] - b[0]).abs().max().item() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- LAD-RegNet stem (ldn_stem3_conv)
+def _stem3_ref(x, conv_w, gamma, beta, mean, var, eps=1e-5):
+    """laud_regnet.py:59-71 SimpleStemIN in eval mode: conv 3x3 s2 p1 -> BN -> ReLU."""
+    return F.relu(F.batch_norm(F.conv2d(x, conv_w, None, 2, 1), mean, var, gamma, beta, False, 0.0, eps))
+
+
+def test_pack_stem3_weights_layout():
+    """CPU: fragment order of pack_stem3_weights = the K order k_stem3 walks (include/ldn_hip.h: ldn_stem3_conv)."""
+    from laudnet_amd import ops
+    w = seeded_randn((64, 3, 3, 3), 5)
+    f = ops.pack_stem3_weights(w)                       # [2][3][64][2][8] bf16
+    assert tuple(f.shape) == (2, 3, 64, 2, 8) and f.dtype == torch.bfloat16
+    v = f.float().sum(dim=-2)
+    for j in range(2):
+        for s in range(3):
+            for lane in (0, 5, 31, 32, 40, 63):
+                for e in range(8):
+                    n, h = 32 * j + (lane & 31), lane >> 5
+                    i = 8 * h + e
+                    want = w[n, i % 3, s, i // 3].item() if i < 9 else 0.0
+                    assert abs(v[j, s, lane, e].item() - want) <= 2e-5 * max(1.0, abs(want)), (j, s, lane, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cout", [(2, 224, 224, 32), (3, 64, 64, 32), (2, 37, 53, 64), (1, 9, 200, 32), (5, 30, 26, 64),
+                                        (2, 7, 7, 32), (1, 129, 131, 32), (1, 300, 512, 32), (2, 1, 1, 32)])
+def test_stem3_vs_torch(B, H, W, cout):
+    from laudnet_amd import ops, load_library
+    load_library()
+    dev = "cuda:0"
+    _, gamma, beta, mean, var = _params(cout, 60 + H)
+    w = seeded_randn((cout, 3, 3, 3), 61 + H) * (2.0 / 27) ** 0.5
+    x = seeded_randn((B, 3, H, W), 62 + W)
+    want = _stem3_ref(x, w, gamma, beta, mean, var)
+    scale = gamma / torch.sqrt(var + 1e-5)
+    frag = ops.pack_stem3_weights((w * scale.view(-1, 1, 1, 1)).to(dev))
+    shift = (beta - mean * scale).to(dev)
+    xn = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    got = ops.stem3_conv(xn, frag, shift, cout).permute(0, 3, 1, 2).cpu()
+    assert got.shape == want.shape
+    err = (got - want).abs()
+    assert torch.isfinite(got).all()
+    assert (err <= 1e-4 + 1e-5 * want.abs()).all(), f"max err {err.max().item():.3e}"
+    # without the ReLU: the pre-activation values
+    got_lin = ops.stem3_conv(xn, frag, shift, cout, relu=False).permute(0, 3, 1, 2).cpu()
+    want_lin = F.batch_norm(F.conv2d(x, w, None, 2, 1), mean, var, gamma, beta, False, 0.0, 1e-5)
+    assert ((got_lin - want_lin).abs() <= 1e-4 + 1e-5 * want_lin.abs()).all()
+
+
+@pytest.mark.gpu
+def test_stem3_in_regnet_matches_library_stem():
+    """LAD_RegNet.forward with the one-launch stem vs the same model with the library stem (conv, BN, ReLU): logits within 1e-4."""
+    import laudnet_amd
+    from laudnet_amd import ops
+    from fill import fill_state_dict
+    dev = "cuda:0"
+    r = laudnet_amd.lad_regnet_y_800mf(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[56, 28, 14, 7], num_classes=10).eval()
+    r.load_state_dict(fill_state_dict(r.state_dict(), 4))
+    r = r.to(dev)
+    x = seeded_randn((4, 3, 224, 224), 13).to(dev)
+    ops.set_math_mode("bf16x3")
+    try:
+        with torch.no_grad():
+            r.use_fused_stem = True
+            fused = r._stem_forward(x.contiguous(memory_format=torch.channels_last))
+            lib = r.stem(x.contiguous(memory_format=torch.channels_last))
+            assert getattr(r, "_stem_frag", None) is not None          # the fused path ran
+            assert (fused - lib).abs().max().item() < 1e-4
+            a = r(x, 1.0)
+            r.use_fused_stem = False
+            b = r(x, 1.0)
+    finally:
+        ops.set_math_mode("fp32")
+    assert (a[0] - b[0]).abs().max().item() < 1e-4

@@ -119,7 +119,8 @@ int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int taps, cons
 
 /* The same contract on the round-2 kernel k_dense (bf16x3 arithmetic): the weights come PRE-SPLIT, n-major --
  * w_split [cout][taps*cin/8][32 B], row n, octet o = bf16 {8 hi | 8 lo} of w[n, 8o .. 8o+7] over the K axis (tap, channel)
- * (one-time module preparation) -- so that a weight fragment needs no conversion in the K loop; cin % 32 == 0, cout % 32 == 0;
+ * (one-time module preparation) -- so that a weight fragment needs no conversion in the K loop; cin % 8 == 0, cout % 4 == 0
+ * (widths that are not multiples of 32 -- LAD-RegNet's 144 / 784 -- run with a zero-filled K tail and a ragged last column tile);
  * taps == 9: a_rows is the [rows][9] neighbour table of ldn_mask_to_index.  shift_classes 16 + pix_map + geometry: the
  * border-class shift table of the channel algebra, as in ldn_conv_packed.  Two optional epilogue terms of the dense
  * execution of channel mode: post_sub [cout] is subtracted after the ReLU, chan_mask [B][cout] {0,1} multiplies

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     if (m0 >= M) return;
     const int rows = min(D_ROWS, M - m0);
     const int n0 = nt * NT;
-    const int nsub = FULL ? NSUB : min(NSUB, (p.cout - n0) / 32);
+    const int nsub = FULL ? NSUB : min(NSUB, ceil_div(p.cout - n0, 32));   // (the last one may hold fewer than 32 columns)
 
     if (tid < D_ROWS) {
         int ar = -1, orw = -1;
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     __syncthreads();
 
     const bool active = wave * 32 < rows;
-    const int cpt = p.cin / 32;                                  // chunks per tap
+    const int cpt = ceil_div(p.cin, 32);                         // chunks per tap (cin % 32 != 0: the tail of a tap's last chunk is zero-filled)
+    const int wrow = (T9 ? 9 : 1) * (p.cin / 8);                 // octets per weight row
     const int nchunks = (T9 ? 9 : 1) * cpt;
     const unsigned lds_ring = d_lds_off(s_ring);
     const int per_chunk = (active ? 4 : 0) + NWI;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
                     const int ar = s_atap[r * 9 + tap];
                     off = ar >= 0 ? (long)ar * p.lda : -1;
                 }
-                const float* src = off >= 0 ? p.a + off + ck * 32 + ls * 4 : g_dense_zero;
+                const float* src = (off >= 0 && ck * 32 + ls * 4 < p.cin) ? p.a + off + ck * 32 + ls * 4 : g_dense_zero;
                 d_dma16(src, slot + (wave * 32 + i * 8) * 128);
             }
         }
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
             const int r = i * 64 + wave * 8 + (lane >> 3);
             const int ls = (lane & 7) ^ ((r >> 1) & 7);
             const int n = n0 + r;
-            const unsigned char* src = (r < NT && n < p.cout) ? p.ws + ((long)n * ((T9 ? 9 : 1) * p.cin / 8) + c * 4) * 32 + ls * 16
+            const unsigned char* src = (r < NT && n < p.cout && ck * 8 + ls < p.cin / 4)
+                                           ? p.ws + ((long)n * wrow + tap * (p.cin / 8) + ck * 4) * 32 + ls * 16
                                                                : reinterpret_cast<const unsigned char*>(g_dense_zero);
             d_dma16(src, slot + (D_ROWS + (r < NT ? i * 64 + wave * 8 : 0)) * 128);
         }
@@ -181,14 +183,14 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
                 const int ar = s_atap[r * 9 + min(tap, 8)];
                 off = ar >= 0 ? (long)ar * p.lda : -1;
             }
-            if (real && off >= 0) src = p.a + off + ck * 32 + ls * 4;
+            if (real && off >= 0 && ck * 32 + ls * 4 < p.cin) src = p.a + off + ck * 32 + ls * 4;
             if (real) dst = slot + (wave * 32 + k * 8) * 128;
         } else {
             const int i = k - 4;
             const int r = i * 64 + wave * 8 + (lane >> 3);
             const int ls = (lane & 7) ^ ((r >> 1) & 7);
             const int n = n0 + r;
-            if (real && r < NT && n < p.cout) src = p.ws + ((long)n * ((T9 ? 9 : 1) * p.cin / 8) + c * 4) * 32 + ls * 16;
+            if (real && r < NT && n < p.cout && ck * 8 + ls < p.cin / 4) src = p.ws + ((long)n * wrow + tap * (p.cin / 8) + ck * 4) * 32 + ls * 16;
             if (real && i * 64 + wave * 8 < NT) dst = slot + (D_ROWS + i * 64 + wave * 8) * 128;
         }
         d_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
@@ -305,14 +307,15 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     for (int it = 0; it < 4; ++it) orw[it] = s_orow[wave * 32 + trw + 8 * it];
     auto load_res = [&](int j, f32x4 (&res)[4], f32x4& sc, f32x4& sh, f32x4& ps) {
         const int cb = n0 + 32 * j + tc * 4;
+        const bool cok = FULL || cb < p.cout;                    // (a ragged last subtile: columns beyond cout are neither read nor stored)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const float* src = (p.residual && orw[it] >= 0) ? p.residual + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldr + cb : g_dense_zero;
+            const float* src = (p.residual && orw[it] >= 0 && cok) ? p.residual + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldr + cb : g_dense_zero;
             res[it] = *reinterpret_cast<const f32x4*>(src);
         }
-        sh = *reinterpret_cast<const f32x4*>(p.shift + cb);      // (one class; the 16-class table is read per row below)
-        sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cb) : f32x4{1.f, 1.f, 1.f, 1.f};
-        ps = p.post_sub ? *reinterpret_cast<const f32x4*>(p.post_sub + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sh = cok ? *reinterpret_cast<const f32x4*>(p.shift + cb) : f32x4{0.f, 0.f, 0.f, 0.f};   // (one class; the 16-class table is read per row below)
+        sc = (p.scale && cok) ? *reinterpret_cast<const f32x4*>(p.scale + cb) : f32x4{1.f, 1.f, 1.f, 1.f};
+        ps = (p.post_sub && cok) ? *reinterpret_cast<const f32x4*>(p.post_sub + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
@@ -320,9 +323,10 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         f32x4 res[4], sc, sh, ps;
         load_res(j, res, sc, sh, ps);
         f32x4 cm[4];
+        const bool cok = FULL || n0 + 32 * j + tc * 4 < p.cout;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const float* src = (p.chmask && orw[it] >= 0) ? p.chmask + (size_t)((orw[it] & (D_ROW_RELU - 1)) / p.rows_per_img) * p.cout + n0 + 32 * j + tc * 4
+            const float* src = (p.chmask && orw[it] >= 0 && cok) ? p.chmask + (size_t)((orw[it] & (D_ROW_RELU - 1)) / p.rows_per_img) * p.cout + n0 + 32 * j + tc * 4
                                                           : nullptr;
             cm[it] = src ? *reinterpret_cast<const f32x4*>(src) : f32x4{1.f, 1.f, 1.f, 1.f};
         }
@@ -341,14 +345,14 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         for (int it = 0; it < 4; ++it) {
             const int row = trw + 8 * it;
             f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
-            const f32x4 shr = (T9 && p.shift_classes > 1) ? *reinterpret_cast<const f32x4*>(p.shift + s_cls[wave * 32 + row] + n0 + 32 * j + tc * 4) : sh;
+            const f32x4 shr = (T9 && p.shift_classes > 1 && cok) ? *reinterpret_cast<const f32x4*>(p.shift + s_cls[wave * 32 + row] + n0 + 32 * j + tc * 4) : sh;
             x = x * sc + shr + res[it];
             if (orw[it] & D_ROW_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
             }
             x = (x - ps) * cm[it];
-            if (orw[it] >= 0)
+            if (orw[it] >= 0 && cok)
                 *reinterpret_cast<f32x4*>(p.out + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + tc * 4) = x;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -403,7 +407,7 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
                                    int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
                                    void* stream) {
     LDN_REQUIRE(a && w_split && shift && out, "ldn_conv_rows_split: null pointer");
-    LDN_REQUIRE(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0, "ldn_conv_rows_split: cin and cout must be multiples of 32 (got %d, %d)", cin, cout);
+    LDN_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 4 == 0, "ldn_conv_rows_split: cin must be a multiple of 8 and cout of 4 (got %d, %d)", cin, cout);
     LDN_REQUIRE(lda % 4 == 0 && lda >= cin && ldo % 4 == 0 && ldo >= cout && (!residual || (ldr % 4 == 0 && ldr >= cout)),
                 "ldn_conv_rows_split: strides must be multiples of 4 and cover the row");
     LDN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || relu_if_neg), "ldn_conv_rows_split: bad relu mode");
@@ -424,6 +428,7 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
     if (taps == 9) return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true>(d, st) : launch_dense<2, true>(d, st);
     if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8, false>(d, st);
     if (cout % 128 == 0) return launch_dense<4, false>(d, st);
-    if (cout % 64 == 0 && cout < 128) return launch_dense<2, false>(d, st);
+    if (cout <= 64) return launch_dense<2, false>(d, st);
+    if (cout % 32 != 0 && cout > 128 && cout <= 256) return launch_dense<8, false>(d, st);   // a ragged layer in ONE column tile (144, 168, 216 ...)
     return launch_dense<4, false>(d, st);
 }

@@ -172,6 +172,7 @@ def scatter_add_relu(packed, rows, identity2d, out2d=None, count=None, cap=None)
 _SPLIT_CACHE = {}   # (data_ptr, _version, shape) of an fp32 weight -> its pre-split n-major copy (ldn_conv_rows_split)
 DENSE_TAPS = tuple(int(t) for t in os.environ.get("LDN_DENSE_TAPS", "1,9").split(","))   # tuning: "1,9" sends the packed-row 3x3 to k_dense too
 DENSE_CHANNEL_3X3 = os.environ.get("LDN_DENSE_CHANNEL_3X3", "0") != "0"   # the 3x3 of the dense channel execution (stage 4) on k_dense (measured: no gain)
+DENSE_K_MULT = int(os.environ.get("LDN_DENSE_K_MULT", "8"))   # tuning: 32 keeps layers whose widths are not multiples of 32 (LAD-RegNet 144 / 784) on the round-1 kernels
 USE_DENSE_KERNEL = os.environ.get("LDN_DENSE_KERNEL", "1") != "0"   # tuning switch: off keeps every packed-row 1x1 on the round-1 kernels
 
 
@@ -206,7 +207,8 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
     # SLOWER there than round 1's producer/consumer kernel (spatial 17.8 -> 19.1 ms); with the pinned schedule it is faster on the
     # packed-row paths (spatial 16.62 -> 16.31 ms, same box) and neutral on the dense channel execution of stage 4, which stays on
     # k_conv_bf3 (DENSE_CHANNEL_3X3).  LDN_DENSE_TAPS=1 restores the old dispatch.
-    dense_ok = (USE_DENSE_KERNEL and mode == "bf16x3" and taps in DENSE_TAPS and cin % 32 == 0 and cout % 32 == 0 and a2d.stride(0) >= cin)
+    dense_ok = (USE_DENSE_KERNEL and mode == "bf16x3" and taps in DENSE_TAPS and cin % DENSE_K_MULT == 0 and cout % (4 if DENSE_K_MULT == 8 else 32) == 0
+                and a2d.stride(0) >= cin)
     classes = 1 if shift.dim() == 1 else shift.shape[0]
     if (post_sub is not None or chan_mask is not None or classes != 1) and not dense_ok:
         raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table need the bf16x3 path (cin, cout multiples of 32)")

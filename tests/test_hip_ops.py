@@ -190,7 +190,10 @@ def _affine(c, seed):
 
 
 @pytest.mark.parametrize("rows,cin,cout", [(300, 64, 64), (1000, 256, 64), (257, 64, 256), (129, 8, 16), (64, 36, 200),
-                                           (5000, 128, 128)])
+                                           (5000, 128, 128),
+                                           # widths that are not multiples of 32 (LAD-RegNet 144 / 784): zero-filled K tail, ragged column tile
+                                           (700, 144, 144), (300, 784, 144), (513, 144, 784), (300, 24, 40), (256, 72, 36),
+                                           (400, 320, 784), (290, 48, 168)])
 def test_conv_rows_1x1_gather(ops, rows, cin, cout):
     a = seeded_randn((rows, cin), 1)
     w = seeded_randn((cout, 1, cin), 2) * (2.0 / cin) ** 0.5
@@ -206,7 +209,7 @@ def test_conv_rows_1x1_gather(ops, rows, cin, cout):
     assert bool((out[n:] == -7.0).all()), "rows beyond the device-side count must not be written"
 
 
-@pytest.mark.parametrize("B,H,C,cout,stride", [(2, 14, 16, 16, 1), (3, 14, 64, 64, 2), (2, 7, 128, 128, 1)])
+@pytest.mark.parametrize("B,H,C,cout,stride", [(2, 14, 16, 16, 1), (3, 14, 64, 64, 2), (2, 7, 128, 128, 1), (2, 14, 48, 72, 1), (2, 14, 144, 40, 2)])
 def test_conv_rows_3x3_table_scatter(ops, B, H, C, cout, stride):
     """Full spatial-mode slice at op level: mask -> index -> 3x3 through the neighbour table, and the final
     1x1 with residual scatter-add, against F.conv2d on masked dense tensors."""

@@ -285,6 +285,63 @@ __global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ pa
     }
 }
 
+// ---- S == Sx == 1 (layer skip: one decision per image): every list is a closed form of the number of kept images in front of
+// image b -- no count pass, no LDS tables, grid = chunks x B.  Same lists, counts, prefixes and statistics as k_mask_index.
+__global__ __launch_bounds__(256) void k_layer_index(const float* __restrict__ patch, const IdxGeom g, int32_t* __restrict__ idx3,
+                                                      int32_t* __restrict__ pos3, int32_t* __restrict__ idx1,
+                                                      int32_t* __restrict__ pos1, int32_t* __restrict__ nbr,
+                                                      int32_t* __restrict__ cnt, int32_t* __restrict__ pre3,
+                                                      int32_t* __restrict__ pre1, float* __restrict__ stats) {
+    __shared__ int s_cnt[2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int HWo = g.Ho * g.Wo, HWi = g.Hi * g.Wi;
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int i = tid; i < g.B; i += 256) {
+        const int k = patch[i] > 0.5f ? 1 : 0;
+        total += k;
+        before += i < b ? k : 0;
+    }
+    atomicAdd(&s_cnt[0], before);   // integer LDS atomics: order-independent
+    atomicAdd(&s_cnt[1], total);
+    __syncthreads();
+    const int nb = s_cnt[0], tot = s_cnt[1];
+    const bool kept = patch[b] > 0.5f;
+    const int base3 = nb * HWo, base1 = nb * HWi;
+    if (blockIdx.x == 0 && tid == 0) {
+        pre3[b] = base3;
+        pre1[b] = base1;
+        if (b == g.B - 1) {
+            const int tot3 = tot * HWo, tot1 = tot * HWi;
+            pre3[g.B] = tot3;
+            pre1[g.B] = tot1;
+            cnt[0] = tot3;
+            cnt[1] = tot1;
+            stats[0] = (float)tot / (float)((long)g.B * g.S * g.Sx);
+            stats[1] = (float)tot3 / (float)((long)g.B * HWo);
+            stats[2] = (float)tot1 / (float)((long)g.B * HWi);
+        }
+    }
+    const int step = gridDim.x * 256, first = blockIdx.x * 256 + tid;
+    for (int i = first; i < HWo; i += step) {
+        pos3[(size_t)b * HWo + i] = kept ? base3 + i : -1;
+        if (kept) idx3[base3 + i] = b * HWo + i;
+    }
+    for (int i = first; i < HWi; i += step) {
+        pos1[(size_t)b * HWi + i] = kept ? base1 + i : -1;
+        if (kept) idx1[base1 + i] = b * HWi + i;
+    }
+    if (!kept) return;
+    for (int e = first; e < HWo * 9; e += step) {
+        const int i = e / 9, t = e - 9 * i;
+        const int oy = i / g.Wo, ox = i - oy * g.Wo;
+        const int iy = oy * g.stride - 1 + t / 3, ix = ox * g.stride - 1 + t % 3;
+        const bool inb = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+        nbr[(size_t)base3 * 9 + e] = inb ? base1 + iy * g.Wi + ix : -1;
+    }
+}
+
 // ---- the same lists built by BANDS of output rows (grid = B x bands) for maps whose per-image tables do not fit one workgroup's
 // LDS (detection-size inputs).  Band j of image b owns the output rows [y0, y1) and the input rows [y0 s, y1 s);
 // packed positions are row-major inside an image and images follow each other, so band (b, j) starts at the sum of the counts of
@@ -736,6 +793,14 @@ extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, 
     LDN_REQUIRE((long)B * Ho * stride * Wo * stride < (1l << 31), "ldn_mask_to_index: index space exceeds int32");
     IdxGeom g{B, S, Sx, Ho, Wo, stride, Ho * stride, Wo * stride};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (S == 1 && Sx == 1 && !getenv("LDN_INDEX_GENERIC") && !getenv("LDN_INDEX_BANDS")) {   // one decision per image (layer skip): closed-form lists, one launch
+        const long items = (long)Ho * Wo * 9 > (long)g.Hi * g.Wi ? (long)Ho * Wo * 9 : (long)g.Hi * g.Wi;
+        const unsigned chunks = (unsigned)(items / 2048 < 1 ? 1 : (items / 2048 > 32 ? 32 : items / 2048));
+        hipLaunchKernelGGL(k_layer_index, dim3(chunks, (unsigned)B), dim3(256), 0, st, patch_mask, g, idx3, pos3, idx1, pos1, nbr, cnt,
+                           img_prefix3, img_prefix1, stats);
+        LDN_CHECK_LAUNCH("k_layer_index");
+        return LDN_OK;
+    }
     const size_t lds1 = (size_t)Ho * Wo;
     const size_t lds2 = (size_t)Ho * Wo * 5 + (size_t)g.Hi * g.Wi * 4;
     if (lds2 <= kWholeImageLds && !getenv("LDN_INDEX_BANDS")) {   // whole image in one workgroup's LDS

@@ -212,7 +212,7 @@ class ResBottleneckBlock(_PrepCache):
         return (masker, f.conv1_flops_per_pixel * px_in, f.conv2_flops_per_pixel * px_out,
                 f.conv3_flops_per_pixel * px_out, proj, f.se_flops_per_pixel)
 
-    def run_dynamic(self, x, inplace=None):
+    def run_dynamic(self, x, inplace=None, defer_stats=False):
         """-> (out, stats[4] = s3, s2, s1, channel sparsity).  inplace: update the residual stream in place (only the owner
         of x may ask for it: LAD_RegNet.forward does for its own intermediates; the module default never mutates its input)."""
         _eval_only(self, x)
@@ -223,7 +223,7 @@ class ResBottleneckBlock(_PrepCache):
         if f.masker_spatial.mask_channel_group != 1:
             raise LdnError("HIP path: LAD-RegNet spatial masks with spatial_mask_channel_group > 1 are not built")
         if f.dyn_mode == "both" or f.mask_size != 1:
-            return self._run_spatial_general(x, inplace)
+            return self._run_spatial_general(x, inplace, defer_stats)
         p = f.prepared(x.device)
         B, Cin, Hi, Wi = x.shape
         Ho = Wo = f.output_size
@@ -235,7 +235,7 @@ class ResBottleneckBlock(_PrepCache):
         if f.forced_spatial_mask is not None:
             patch = f.forced_spatial_mask.to(device=dev, dtype=torch.float32).contiguous()
         else:
-            patch = f.masker_spatial(x, 1.0, carry=carry_in)[0]
+            patch = f.masker_spatial.decide(x, carry=carry_in)
         ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, self.stride)
         if f.forced_spatial_mask is None and getattr(f.masker_spatial, "last_work", None) is not None:
             f.last_carry = (f.masker_spatial.last_work, ix.pre3)   # which images this block leaves unchanged, and their channel sums
@@ -260,10 +260,11 @@ class ResBottleneckBlock(_PrepCache):
         ops.conv_rows(h_b, p["wc"], p["sc"], p["tc"], out2d, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
                       out_rows=ix.idx3, residual2d=resid)
         f.last_spatial_mask = patch
-        stats = torch.cat((ix.stats, torch.ones(1, device=dev)))
+        # (defer_stats: the caller appends the channel sparsity 1 to all blocks at once -- a fill and a cat per block otherwise)
+        stats = ix.stats if defer_stats else torch.cat((ix.stats, torch.ones(1, device=dev)))
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), stats
 
-    def _run_spatial_general(self, x, inplace):
+    def _run_spatial_general(self, x, inplace, defer_stats=False):
         """dyn_mode 'spatial' with patch masks, and 'both' (laud_regnet.py:164-217).  The reference masks ONLY conv c's output
         spatially (:200): a and b run on every pixel and the SE squeeze pools the dense b output (:194), so what the pixel mask can
         skip exactly is conv c (+ the residual update) on the inactive pixels -- a / b / SE are executed densely (in 'both' mode on
@@ -283,7 +284,7 @@ class ResBottleneckBlock(_PrepCache):
         if f.forced_spatial_mask is not None:
             patch = f.forced_spatial_mask.to(device=dev, dtype=torch.float32).contiguous()
         else:
-            patch = f.masker_spatial(x, 1.0)[0]
+            patch = f.masker_spatial.decide(x)
         ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, s)          # mask3 list (conv c) and the three sparsities
         x2d = xn.reshape(B * Hi * Wi, Cin)
         cout = p["wc"].shape[0]
@@ -324,9 +325,9 @@ class ResBottleneckBlock(_PrepCache):
         else:
             ops.conv_rows(h_b2d, p["wc"], p["sc"], p["tc"], out2d, a_rows=ix.idx3, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
                           out_rows=ix.idx3, residual2d=resid)
-            cs = torch.ones(1, device=dev)
+            cs = None if defer_stats else torch.ones(1, device=dev)
         f.last_spatial_mask = patch
-        return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), torch.cat((ix.stats, cs))
+        return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), (ix.stats if cs is None else torch.cat((ix.stats, cs)))
 
     def _dense_index(self, B, Ho, Wo, dev):
         key = (B, Ho, Wo, self.stride, str(dev))
@@ -544,10 +545,15 @@ class LAD_RegNet(nn.Module):
                                                      and blk.f.dyn_mode == "spatial" and prev.f.dyn_mode == "spatial" and blk.f.mask_size == 1
                                                      and prev.f.mask_size == 1 and blk.f.forced_spatial_mask is None
                                                      and getattr(prev.f, "last_carry", None) is not None) else None)
-            x, st = blk.run_dynamic(x, inplace=self.inplace_residual)
+            x, st = blk.run_dynamic(x, inplace=self.inplace_residual, defer_stats=True)
             prev = blk
             stats.append(st)
-        st = torch.stack(stats)
+        if all(s.numel() == 3 for s in stats):      # spatial / layer-skip blocks only: channel sparsity 1, appended once
+            st = torch.stack(stats)
+            st = torch.cat((st, torch.ones(st.shape[0], 1, device=st.device)), dim=1)
+        else:
+            one = torch.ones(1, device=x.device)
+            st = torch.stack([s if s.numel() == 4 else torch.cat((s, one)) for s in stats])
         s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
         perc, flops = self.flops_from_sparsities(in_shape, s3, s2, s1, cs)
         x = self.avgpool(x)

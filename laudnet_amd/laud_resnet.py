@@ -158,6 +158,19 @@ class Masker_spatial(_PrepCache):
         out = (mask, mask.mean(), self.flops_for(x))
         return out + (logits,) if want_logits else out
 
+    def decide(self, x, carry=None):
+        """The mask alone (what the blocks of the HIP path consume; their sparsities come from ldn_mask_to_index): forward()
+        without the mean over the mask, a reduction launch per block."""
+        _eval_only(self, x)
+        if not self._cache_valid():
+            with torch.no_grad():
+                self._cache_store((self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1).float().contiguous(),
+                                   self.conv.bias.detach().float().contiguous()))
+        w, b = self._prep
+        mask, _, self.last_work = ops.spatial_masker(ops.as_nhwc(x), w, b, self.mask_channel_group, self.mask_size, False,
+                                                     carry=carry, return_work=True)
+        return mask
+
 
 class ExpandMask(nn.Module):
     """models/utils.py:67-89.  Parameter-free; in the HIP path the dilation is part of ldn_mask_to_index
@@ -576,7 +589,7 @@ class Bottleneck(_PrepCache):
         if self.forced_spatial_mask is not None:
             patch = self.forced_spatial_mask.to(device=x.device, dtype=torch.float32).contiguous()
         else:
-            patch = ms(x, 1.0, carry=carry_in)[0]
+            patch = ms.decide(x, carry=carry_in)
         dev = x.device
         # spatial_mask_channel_group > 1 (models/utils.py:27-33,74-89): group g of the OUTPUT channels has its own pixel mask.
         # ExpandMask ORs the groups (its dilation kernel is [g,g,k,k] ones), so conv1 / conv2 -- and the sparsities the
@@ -636,7 +649,7 @@ class Bottleneck(_PrepCache):
         if self.forced_spatial_mask is not None:
             patch = self.forced_spatial_mask.to(device=dev, dtype=torch.float32).contiguous()
         else:
-            patch = ms(x, 1.0)[0]
+            patch = ms.decide(x)
         ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, self.stride)
         x2d = xn.reshape(B * Hi * Wi, Cin)
         geom = (Hi, Wi, Ho, Wo, self.stride)

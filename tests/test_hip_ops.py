@@ -101,6 +101,25 @@ def test_mask_to_index_forced_bands(ops, B, S, Ho, Wo, stride, p, monkeypatch):
         _check_index(ops, seeded_bernoulli((B, S, S), p, 7 + B + S + Ho), Ho, Wo, stride)
 
 
+@pytest.mark.parametrize("B,Ho,Wo,stride,p", [(9, 14, 14, 1, 0.5), (256, 14, 14, 1, 0.5), (7, 28, 28, 2, 0.4), (5, 56, 56, 1, 0.6),
+                                               (3, 56, 56, 2, 0.5), (8, 7, 7, 2, 0.0), (8, 7, 7, 1, 1.0), (4, 20, 33, 2, 0.5),
+                                               (1, 14, 14, 1, 1.0), (2, 100, 168, 1, 0.5)])
+def test_mask_to_index_whole_image_masks(ops, B, Ho, Wo, stride, p, monkeypatch):
+    """One decision per image (layer skip, S = 1): the closed-form kernel (k_layer_index) against the oracle and, list by list,
+    against the general kernels (LDN_INDEX_GENERIC=1)."""
+    patch = seeded_bernoulli((B, 1, 1), p, 5 + B + Ho)
+    _check_index(ops, patch, Ho, Wo, stride)
+    fast = ops.mask_to_index(patch.to(DEV), Ho, Wo, stride)
+    monkeypatch.setenv("LDN_INDEX_GENERIC", "1")
+    gen = ops.mask_to_index(patch.to(DEV), Ho, Wo, stride)
+    n3, n1 = int(gen.cnt[0]), int(gen.cnt[1])
+    assert torch.equal(fast.cnt, gen.cnt) and torch.equal(fast.pre3, gen.pre3) and torch.equal(fast.pre1, gen.pre1)
+    assert torch.equal(fast.stats, gen.stats)
+    assert torch.equal(fast.pos3, gen.pos3) and torch.equal(fast.pos1, gen.pos1)
+    assert torch.equal(fast.idx3[:n3], gen.idx3[:n3]) and torch.equal(fast.idx1[:n1], gen.idx1[:n1])
+    assert torch.equal(fast.nbr[:n3 * 9], gen.nbr[:n3 * 9])
+
+
 def test_gather_scatter(ops):
     rows_total, C = 500, 64
     src = seeded_randn((rows_total, C), 3).to(DEV)

@@ -623,8 +623,9 @@ __global__ __launch_bounds__(NT) void k_channel_mlp(const float* __restrict__ pa
                                                       int32_t* __restrict__ ch_idx, int32_t* __restrict__ ch_cnt) {
     extern __shared__ __attribute__((aligned(16))) float s_f[];
     __shared__ int s_w[NT / 64];
+    __shared__ __attribute__((aligned(16))) float s_part[NT == 1024 ? NT * 4 : 4];   // group sums of the many-split GAP (ldn_mlp.h)
     channel_mlp_body<NT>(blockIdx.x, partial, HW, C, splits, w1, b1, w2, b2, hidden, G, gran, mask_in, mask, logits, ch_idx, ch_cnt,
-                         s_f, s_w);
+                         s_f, s_w, NT == 1024 ? s_part : nullptr);
 }
 
 // head of the whole-image spatial masker: one workgroup (four waves) per image; gap = sum of the split partials / HW, then 2g dots.

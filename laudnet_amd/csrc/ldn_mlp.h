@@ -49,7 +49,7 @@ __device__ __forceinline__ void channel_mlp_body(const int b, const float* __res
                                                       int hidden, int G, int gran, const float* __restrict__ mask_in,
                                                       float* __restrict__ mask, float* __restrict__ logits,
                                                       int32_t* __restrict__ ch_idx, int32_t* __restrict__ ch_cnt,
-                                                      float* s_f, int* s_w) {
+                                                      float* s_f, int* s_w, float* s_part = nullptr) {   // s_part: optional NT * 4 floats
     float* s_gap = s_f;                 // [C]
     float* s_hid = s_gap + C;           // [max(hidden,1)]
     float* s_log = s_hid + (hidden > 0 ? hidden : 1);  // [2G]
@@ -86,7 +86,34 @@ __device__ __forceinline__ void channel_mlp_body(const int b, const float* __res
             float b1v[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) b1v[k] = wave + NW * k < n1 ? b1[wave + NW * k] : 0.f;
-            // GAP: four channels per thread, the partials of up to 8 splits in flight together, added in split order
+            // GAP.  Many splits on a narrow layer (the fused hand-off of stages 1 / 2: 112 / 32 partials of 256 / 512 channels -- a
+            // quarter-wave to a wave of threads walking them one after the other was 35 us of pure latency per block): the NT / (C / 4)
+            // thread groups each sum a contiguous range of splits, the group sums are added in group order (deterministic).  Only
+            // for splits > 16 and with scratch from the caller: k_chain (8 splits) and every 8-split hand-off keep the plain order.
+            const int nact = C >> 2;
+            if (s_part && splits > 16 && nact < NT && NT % nact == 0) {
+                const int R = NT / nact, r = tid / nact, c = (tid - r * nact) * 4;
+                const int per = (splits + R - 1) / R;
+                const int k_lo = r * per, k_hi = min(splits, k_lo + per);
+                f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+                for (int k0 = k_lo; k0 < k_hi; k0 += 8) {
+                    f32x4 pv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        pv[k] = k0 + k < k_hi ? *reinterpret_cast<const f32x4*>(partial + ((size_t)b * splits + k0 + k) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k0 + k < k_hi) sacc += pv[k];
+                }
+                *reinterpret_cast<f32x4*>(s_part + (size_t)r * C + c) = sacc;
+                __syncthreads();
+                for (int c2 = tid * 4; c2 < C; c2 += NT * 4) {
+                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                    for (int r2 = 0; r2 < R; ++r2) t += *reinterpret_cast<const f32x4*>(s_part + (size_t)r2 * C + c2);
+                    *reinterpret_cast<f32x4*>(s_gap + c2) = t * inv;
+                }
+            } else
+            // four channels per thread, the partials of up to 8 splits in flight together, added in split order
             for (int c = tid * 4; c < C; c += NT * 4) {
                 f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
                 for (int k0 = 0; k0 < splits; k0 += 8) {

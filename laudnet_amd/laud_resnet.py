@@ -636,13 +636,14 @@ class Bottleneck(_PrepCache):
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), patch, ix
 
     def _run_both(self, x, p):
-        """dyn_mode 'both' (laud_resnet.py:101-103): packed pixel lists (spatial mask) x per-image channel lists."""
+        """dyn_mode 'both' (laud_resnet.py:101-103): packed pixel lists (spatial mask) x per-image channel lists.  With several
+        spatial mask groups (models/utils.py:27-33,74-89) conv1 / conv2 live on the UNION of the group masks (ExpandMask ORs the
+        groups) and conv3 is scattered per output-channel group, exactly as in spatial mode."""
         B, Cin, Hi, Wi = x.shape
         W, gran = self.width, self.channel_dyn_granularity
         Ho, Wo = self._out_hw(Hi, Wi)
         ms = self.masker_spatial
-        if ms.mask_channel_group != 1:
-            raise LdnError("HIP path: spatial_mask_channel_group > 1 is not built (all shipped configs use 1)")
+        G = ms.mask_channel_group
         xn = ops.as_nhwc(x)
         dev = x.device
         cmask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
@@ -650,7 +651,8 @@ class Bottleneck(_PrepCache):
             patch = self.forced_spatial_mask.to(device=dev, dtype=torch.float32).contiguous()
         else:
             patch = ms.decide(x)
-        ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, self.stride)
+        union = patch[:, 0] if G == 1 else patch.amax(dim=1)
+        ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride)
         x2d = xn.reshape(B * Hi * Wi, Cin)
         geom = (Hi, Wi, Ho, Wo, self.stride)
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
@@ -661,19 +663,38 @@ class Bottleneck(_PrepCache):
                         pix_map=ix.idx3, geom=geom, k_idx=idx, k_cnt=cnt, kgran=gran, n_idx=idx, n_cnt=cnt,
                         post_sub=p["c2"], relu=1)
         cout = p["w3"].shape[2]
+        if G == 1:
+            # (a_map: the packed h2 row of every list entry -- the identity for one group)
+            groups = [(ix, None, slice(0, cout), p["w3"], p["t3c"])]
+        else:
+            if cout % (4 * G) != 0:
+                raise LdnError("HIP path: spatial_mask_channel_group must divide the output channels into multiples of 4")
+            if "w3_groups" not in p or len(p["w3_groups"]) != G:
+                p["w3_groups"] = [p["w3"][:, :, g * (cout // G):(g + 1) * (cout // G)].contiguous() for g in range(G)]
+            groups = []
+            ar = torch.arange(ix.cap3, device=dev, dtype=torch.int32)
+            for g in range(G):
+                ig = ops.mask_to_index(patch[:, g].contiguous(), Ho, Wo, self.stride)
+                rows = torch.where(ar < ig.cnt[0], ix.pos3[ig.idx3.clamp(0, ix.cap3 - 1).long()], torch.full_like(ar, -1))
+                cs = slice(g * (cout // G), (g + 1) * (cout // G))
+                groups.append((ig, rows.contiguous(), cs, p["w3_groups"][g], p["t3c"][cs]))
         if self.downsample is not None:
             out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
-            ops.conv_rows(x2d, p["wd"], p["sd"], p["td"], out2d,
-                          a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev), taps=1, m_cap=ix.cap3, relu=2,
-                          relu_if_neg=ix.pos3)
+            ds_rows = self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev)
+            for ig, _, cs, _, _ in groups:   # ReLU directly where the (pixel, group) is inactive: no branch output is added there
+                ops.conv_rows(x2d, p["wd"][cs], p["sd"][cs], p["td"][cs], out2d[:, cs], a_rows=ds_rows, taps=1, m_cap=ix.cap3,
+                              relu=2, relu_if_neg=ig.pos3)
             resid = out2d
         elif self._inplace:
             resid = out2d = x2d
         else:
             resid, out2d = x2d, torch.relu(x2d)
-        ops.conv_packed(h2, p["w3"], None, p["t3c"], out2d, B=B, row_prefix=ix.pre3, m_cap=Ho * Wo, taps=1,
-                        out_map=ix.idx3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual2d=resid)
+        for ig, rows, cs, w3g, t3g in groups:
+            ops.conv_packed(h2, w3g, None, t3g, out2d[:, cs], B=B, row_prefix=ig.pre3, m_cap=Ho * Wo, a_map=rows, taps=1,
+                            out_map=ig.idx3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual2d=resid[:, cs])
         self.last_channel_mask, self.last_spatial_mask = cmask, patch
+        if G > 1:   # sparsity of conv3 = mean over ALL group masks (Masker_spatial, utils.py:61); conv2 / conv1 = the union's
+            ix.stats = torch.cat((patch.mean().reshape(1), ix.stats[1:]))
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), cmask, ix
 
     def _out_hw(self, Hi, Wi):
@@ -714,6 +735,8 @@ class Bottleneck(_PrepCache):
             stats[3] = cmask.mean()
         else:
             out, patch, ix = self._run_spatial(x, p)
+            if defer_stats:   # (the channel sparsity 1 is appended to all such blocks at once: a fill and a cat per block otherwise)
+                return out, ix.stats
             stats = torch.cat((ix.stats, torch.ones(1, device=x.device)))
         return out, stats
 
@@ -1057,6 +1080,13 @@ class ResNet(nn.Module):
         """Per-block stats -> [n_blocks, 4].  Channel-mode blocks hand over (per-image channel counts, B * width):
         their sparsity row is (1, 1, 1, cnt.sum() / (B * width)), formed for all such blocks with three small kernels
         instead of a mean + fill + copy per block."""
+        short = [j for j, st in enumerate(stats) if not isinstance(st, tuple) and st.numel() == 3]
+        if short:   # spatial / layer blocks hand over (s3, s2, s1); their channel sparsity is 1
+            if len(short) == len(stats):
+                st3 = torch.stack(stats)
+                return torch.cat((st3, torch.ones(st3.shape[0], 1, device=dev)), dim=1)
+            one = torch.ones(1, device=dev)
+            stats = [torch.cat((st, one)) if (not isinstance(st, tuple) and st.numel() == 3) else st for st in stats]
         deferred = [j for j, st in enumerate(stats) if isinstance(st, tuple)]
         if not deferred:
             return torch.stack(stats)

@@ -321,7 +321,7 @@ def conv_packed(a2d, w, scale, shift, out2d, *, B=1, row_prefix=None, m_count=No
                                 kgran, L.ptr(_i32c(n_idx, "n_idx")), L.ptr(_i32c(n_cnt, "n_cnt")),
                                 L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), classes, L.ptr(post_sub), relu,
                                 L.ptr(_i32c(relu_if_neg, "relu_if_neg")), L.ptr(residual2d),
-                                residual2d.stride(0) if residual2d is not None else 0, L.ptr(_f32c(out2d, "out")),
+                                residual2d.stride(0) if residual2d is not None else 0, L.ptr(_f32rows(out2d, "out")),
                                 out2d.stride(0), _mm(math), L.stream_ptr(out2d)), "ldn_conv_packed")
     return out2d
 

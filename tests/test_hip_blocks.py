@@ -32,7 +32,7 @@ def _set_math_mode(math_mode):
     yield
     ops.set_math_mode("fp32")
 
-BLOCKS = {**load_golden("blocks_s1.pt"), **load_golden("blocks_s2.pt")}
+BLOCKS = {**load_golden("blocks_s1.pt"), **load_golden("blocks_s2.pt"), **load_golden("blocks_extra.pt")}
 FULL = load_golden("full_tiny.pt")
 BUILT = sorted(BLOCKS)   # every block fixture the reference generated, spatial_mask_channel_group = 2 included
 

@@ -12,7 +12,7 @@ from oracle import index_ref as IR
 from oracle import torch_ref as TR
 
 L1 = load_golden("l1_ops.pt")
-BLOCKS = {**load_golden("blocks_s1.pt"), **load_golden("blocks_s2.pt")}
+BLOCKS = {**load_golden("blocks_s1.pt"), **load_golden("blocks_s2.pt"), **load_golden("blocks_extra.pt")}
 FULL = load_golden("full_tiny.pt")
 
 

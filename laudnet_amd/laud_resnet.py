@@ -430,7 +430,8 @@ class Bottleneck(_PrepCache):
             mask, _, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask, gap=gap_in)
         else:
             mask, _, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
-        chm = mask.repeat_interleave(gran, dim=1).unsqueeze(1) if gran > 1 else mask.unsqueeze(1)   # [B,1,W]
+        # [B,1,W]: every group's decision repeated over its gran channels (one small copy; repeat_interleave is a 12 us index kernel)
+        chm = (mask.unsqueeze(2).expand(-1, -1, gran).reshape(mask.shape[0], 1, -1) if gran > 1 else mask.unsqueeze(1))
         dev = x.device
         if "w2_nk" not in p:
             with torch.no_grad():

@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void k_rows_gap(const float* __restrict__ a, i
 // squeeze-excitation head per image: mean -> fc1 + ReLU -> fc2 -> sigmoid  (torchvision SqueezeExcitation)
 // With a channel list (channel mode: column j of image b is channel ch_idx[b, j], j < ch_cnt[b]) the weights are gathered
 // through it; masked channels are exact zeros in the reference (post-activation mask) and contribute nothing to fc1.
-__global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ partial, const int32_t* __restrict__ prefix,
+template <int NT>   // threads per image: the three phases are chains of dependent global reads, so the more waves share them the fewer round trips
+__global__ __launch_bounds__(NT) void k_se_head(const float* __restrict__ partial, const int32_t* __restrict__ prefix,
                                                   int C, int S, int splits, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, const int32_t* __restrict__ ch_idx,
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ parti
     float* s_mean = s_f;        // [C]
     float* s_hid = s_f + C;     // [S]
     int* s_ch = reinterpret_cast<int*>(s_f + C + S);   // [C] channel of column j
+    constexpr int NW = NT / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = prefix[b + 1] - prefix[b];
     if (n == 0) return;         // skipped image: its gate is never read
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ parti
     const float inv = 1.f / (float)n;
     // (a chain of dependent global reads per image -- partial sums, fc1 rows, fc2 rows: every loop below keeps several
     // independent loads in flight; per output the order of additions is the plain loop's)
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NT) {
         float s = 0.f;
         if (c < Cb) {
             int k = 0;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ parti
     }
     __syncthreads();
     constexpr int OB = 8;                              // fc1 outputs per wave and pass: their weight loads fly together
-    for (int o0 = wave; o0 < S; o0 += 4 * OB) {
+    for (int o0 = wave; o0 < S; o0 += NW * OB) {
         float acc[OB];
 #pragma unroll
         for (int u = 0; u < OB; ++u) acc[u] = 0.f;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ parti
             const float m = s_mean[c];
             float wv[OB];
 #pragma unroll
-            for (int u = 0; u < OB; ++u) wv[u] = o0 + 4 * u < S ? w1[(size_t)(o0 + 4 * u) * C + ch] : 0.f;
+            for (int u = 0; u < OB; ++u) wv[u] = o0 + NW * u < S ? w1[(size_t)(o0 + NW * u) * C + ch] : 0.f;
 #pragma unroll
             for (int u = 0; u < OB; ++u) acc[u] += wv[u] * m;
         }
@@ -192,17 +194,24 @@ __global__ __launch_bounds__(256) void k_se_head(const float* __restrict__ parti
         if (lane == 0) {
 #pragma unroll
             for (int u = 0; u < OB; ++u)
-                if (o0 + 4 * u < S) s_hid[o0 + 4 * u] = fmaxf(acc[u] + b1[o0 + 4 * u], 0.f);
+                if (o0 + NW * u < S) s_hid[o0 + NW * u] = fmaxf(acc[u] + b1[o0 + NW * u], 0.f);
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NT) {
         float g = 0.f;
         if (c < Cb) {
             const int ch = s_ch[c];
             float acc = b2[ch];
             const float* wr = w2 + (size_t)ch * S;
             int j = 0;
+            for (; j + 16 <= S; j += 16) {      // sixteen weights in flight, added in j order
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = wr[j + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += wv[u] * s_hid[j + u];
+            }
             for (; j + 8 <= S; j += 8) {
                 float wv[8];
 #pragma unroll
@@ -359,7 +368,7 @@ extern "C" int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B
     float* gate = work + (size_t)B * splits * C;     // [B][C]
     hipLaunchKernelGGL(k_rows_gap, dim3(splits, B), dim3(256), 0, st, a, lda, row_prefix, C, splits, partial);
     LDN_CHECK_LAUNCH("k_rows_gap");
-    hipLaunchKernelGGL(k_se_head, dim3(B), dim3(256), (size_t)(2 * C + S) * sizeof(float), st, partial, row_prefix, C, S, splits,
+    hipLaunchKernelGGL(k_se_head<1024>, dim3(B), dim3(1024), (size_t)(2 * C + S) * sizeof(float), st, partial, row_prefix, C, S, splits,
                        w1, b1, w2, b2, ch_idx, ch_cnt, gate);
     LDN_CHECK_LAUNCH("k_se_head");
     int chunks = (max_rows_per_image * (C / 4) + 255) / 256;

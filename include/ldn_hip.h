@@ -281,6 +281,15 @@ size_t ldn_grouped16_weight_bytes(int C);
 int ldn_grouped16_conv3x3_rows(const float* a, int lda, const int32_t* nbr, const int32_t* m_count, int m_cap,
                                const void* w_frag, int C, const float* scale, const float* shift, int relu, float* out,
                                int ldo, void* stream);
+
+/* The same convolution when the packed rows are WHOLE IMAGES (layer skip, one decision per image): kept image k owns the input rows
+ * [k Hi Wi, (k+1) Hi Wi) of a and the output rows [k Ho Wo, (k+1) Ho Wo) of out; *m_count = kept images x Ho Wo (device side),
+ * images_cap = the batch.  The image's channels are staged in LDS once instead of nine reads per row through the neighbour table.
+ * ldn_grouped16_images_fit(Hi, Wi, C) > 0 (groups per workgroup) iff the input map fits the LDS. */
+int ldn_grouped16_images_fit(int Hi, int Wi, int C);
+int ldn_grouped16_conv3x3_images(const float* a, int lda, const int32_t* m_count, int images_cap, int Hi, int Wi, int Ho, int Wo,
+                                 int stride, const void* w_frag, int C, const float* scale, const float* shift, int relu, float* out,
+                                 int ldo, void* stream);
 /* b in CHANNEL mode (laud_regnet.py:160-189: the mask is applied AFTER conv+BN+ReLU, so masked channels are exact zeros and the
  *    subset execution is exact): dense image whose columns are left-packed per image (column j of image b = channel
  *    ch_idx[b,j], ascending, j < ch_cnt[b]); output column j sums over the ACTIVE input channels of its group only.

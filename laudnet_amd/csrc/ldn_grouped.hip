@@ -102,6 +102,115 @@ __global__ __launch_bounds__(512, 2) void k_grouped16_mfma(const GmArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_grouped16_img -- the same convolution when the packed rows are WHOLE IMAGES (layer skip: image k of the kept ones owns the
+// input rows [k Hi Wi, (k + 1) Hi Wi) and the output rows [k Ho Wo, (k + 1) Ho Wo)).  The neighbour-table kernel above reads every
+// input row nine times (once per tap) through the L2 -- on the 14 x 14 maps of RegNetY-800MF's stage 3 that is what bounds it
+// (59 us for 64 MB in + 64 MB out).  Here a workgroup = (kept image, chunk of groups): the image's channels of the chunk are
+// staged in LDS ONCE ([pixel][16 ng + 4] floats, + one zero pixel for the taps outside the image) and the im2col is a per-lane
+// LDS address computed from the geometry, as in k_tail.  Work items = (16-pixel tile, group), dealt to the 8 waves.
+struct GiArgs {
+    const float* a; int lda;
+    const int32_t* m_count;                 // device-side number of OUTPUT rows (kept images x Ho Wo)
+    const unsigned char* wf; int C;
+    const float* scale; const float* shift; int relu;
+    float* out; int ldo;
+    int Hi, Wi, Ho, Wo, stride;
+    int gchunk, in_ld;                      // groups per workgroup; floats per staged pixel (16 gchunk + 4)
+    int R, nbands;                          // output rows per workgroup (Ho: the whole image), bands per image
+};
+
+__global__ __launch_bounds__(512, 2) void k_grouped16_img(const GiArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = p.C / 16;
+    const int band = blockIdx.x % p.nbands;
+    const int g0 = (blockIdx.x / p.nbands) * p.gchunk;
+    const int ng = min(p.gchunk, G - g0);
+    const int HWo = p.Ho * p.Wo;
+    const int k = blockIdx.y;
+    if ((long)k * HWo >= (long)p.m_count[0]) return;                       // beyond the kept images
+    // this workgroup's band of output rows and the input rows it reads (pad 1: one halo row on each side, inside the image)
+    const int y0 = band * p.R, rows_out = min(p.R, p.Ho - y0);
+    const int iy0 = max(y0 * p.stride - 1, 0), iy1 = min((y0 + rows_out - 1) * p.stride + 1, p.Hi - 1);
+    const int HWi = (iy1 - iy0 + 1) * p.Wi;                                // staged pixels
+    const size_t in_row0 = (size_t)k * p.Hi * p.Wi + (size_t)iy0 * p.Wi;   // first staged input row (flat)
+    float* const s_in = reinterpret_cast<float*>(smem + (size_t)p.gchunk * GM_FRAG);
+    for (int i = tid; i < ng * (GM_FRAG / 16); i += 512)
+        reinterpret_cast<f32x4*>(smem)[i] = reinterpret_cast<const f32x4*>(p.wf + (size_t)g0 * GM_FRAG)[i];
+    const int qpp = ng * 4;                                                // 16-byte pieces per pixel
+    for (int i = tid; i < HWi * qpp; i += 512) {
+        const int px = i / qpp, q = i - px * qpp;
+        *reinterpret_cast<f32x4*>(s_in + (size_t)px * p.in_ld + q * 4) =
+            *reinterpret_cast<const f32x4*>(p.a + (in_row0 + px) * p.lda + g0 * 16 + q * 4);
+    }
+    for (int i = tid; i < p.in_ld; i += 512) s_in[(size_t)HWi * p.in_ld + i] = 0.f;   // the zero pixel
+    __syncthreads();
+    const int n = lane & 15, kg = lane >> 4;
+    const int npix = rows_out * p.Wo;                                      // output pixels of the band
+    const int ntile = (npix + 15) / 16;
+    for (int w = wave; w < ntile * ng; w += 8) {
+        const int gl = w / ntile, tile = w - gl * ntile;
+        const int q = tile * 16 + n;
+        const bool valid = q < npix;
+        const int ly = (valid ? q : 0) / p.Wo, ox = (valid ? q : 0) - ly * p.Wo;
+        const int oy = y0 + ly;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const unsigned char* wfr = smem + (size_t)gl * GM_FRAG + lane * 32;
+#pragma unroll
+        for (int s = 0; s < GM_STEPS; ++s) {
+            const int t = 2 * s + (kg >> 1);
+            const int iy = oy * p.stride - 1 + t / 3, ix = ox * p.stride - 1 + t % 3;
+            const bool inb = valid && t < 9 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            const float* src = s_in + (size_t)(inb ? (iy - iy0) * p.Wi + ix : HWi) * p.in_ld + gl * 16 + 8 * (kg & 1);
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = e < 4 ? x0[e] : x1[e - 4];
+                const __bf16 hb = (__bf16)v;
+                bh[e] = hb;
+                bl[e] = (__bf16)(v - (float)hb);
+            }
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wfr + s * 64 * 32);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(wfr + s * 64 * 32 + 16);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+        }
+        const int c = (g0 + gl) * 16 + 4 * kg;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c), sh = *reinterpret_cast<const f32x4*>(p.shift + c);
+        f32x4 v = acc * sc + sh;
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (valid) *reinterpret_cast<f32x4*>(p.out + ((size_t)k * HWo + (size_t)y0 * p.Wo + q) * p.ldo + c) = v;
+    }
+}
+
+// groups per workgroup and output rows per workgroup for an Hi x Wi input map (false: not even three input rows of one group fit)
+static bool gi_plan(int Hi, int Wi, int Ho, int stride, int G, int* ng_out, int* R_out) {
+    auto bytes = [&](int ng, int in_rows) { return (size_t)ng * GM_FRAG + ((size_t)in_rows * Wi + 1) * (16 * ng + 4) * 4; };
+    if (bytes(1, Hi) <= 150 * 1024) {          // whole images: as many groups per workgroup as leave room for two workgroups per CU
+        int ng = 1;
+        while (ng < G && ng < GM_MAXG && bytes(ng + 1, Hi) <= 80 * 1024) ++ng;
+        const int nchunks = ceil_div(G, ng);
+        *ng_out = ceil_div(G, nchunks);
+        *R_out = Ho;
+        return true;
+    }
+    int R = 0;                                 // bands of output rows, one group per workgroup
+    while (R < Ho && bytes(1, R * stride + 3) <= 80 * 1024) ++R;          // (R + 1 - 1) stride + 3 input rows for R + 1 output rows
+    if (R < 1) return false;
+    const int nb = ceil_div(Ho, R);
+    *ng_out = 1;
+    *R_out = ceil_div(Ho, nb);
+    return true;
+}
+
 }  // namespace ldn
 
 using namespace ldn;
@@ -133,5 +242,39 @@ extern "C" int ldn_grouped16_conv3x3_rows(const float* a, int lda, const int32_t
     if (bx > cap) bx = cap;
     hipLaunchKernelGGL(k_grouped16_mfma, dim3((unsigned)bx, (unsigned)nchunks), dim3(512), lds, static_cast<hipStream_t>(stream), g);
     LDN_CHECK_LAUNCH("k_grouped16_mfma");
+    return LDN_OK;
+}
+
+extern "C" int ldn_grouped16_images_fit(int Hi, int Wi, int C) {
+    int ng = 0, R = 0;   // (stride 2 is the worst case for the banded form: three input rows for one output row)
+    return (Hi > 0 && Wi > 0 && C > 0 && C % 16 == 0 && gi_plan(Hi, Wi, (Hi - 1) / 2 + 1, 2, C / 16, &ng, &R)) ? ng : 0;
+}
+
+extern "C" int ldn_grouped16_conv3x3_images(const float* a, int lda, const int32_t* m_count, int images_cap, int Hi, int Wi, int Ho,
+                                            int Wo, int stride, const void* w_frag, int C, const float* scale, const float* shift,
+                                            int relu, float* out, int ldo, void* stream) {
+    LDN_REQUIRE(a && m_count && w_frag && scale && shift && out, "ldn_grouped16_conv3x3_images: null pointer");
+    LDN_REQUIRE(C > 0 && C % 16 == 0, "ldn_grouped16_conv3x3_images: channels must be a multiple of the group width 16 (got %d)", C);
+    LDN_REQUIRE(lda % 4 == 0 && ldo % 4 == 0 && lda >= C && ldo >= C, "ldn_grouped16_conv3x3_images: strides must be multiples of 4");
+    LDN_REQUIRE((uintptr_t)a % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)w_frag % 16 == 0 && (uintptr_t)scale % 16 == 0 &&
+                (uintptr_t)shift % 16 == 0, "ldn_grouped16_conv3x3_images: pointers must be 16-byte aligned");
+    LDN_REQUIRE(stride >= 1 && Hi > 0 && Wi > 0 && Ho == (Hi - 1) / stride + 1 && Wo == (Wi - 1) / stride + 1,
+                "ldn_grouped16_conv3x3_images: %dx%d -> %dx%d is not a 3x3 / pad 1 / stride %d geometry", Hi, Wi, Ho, Wo, stride);
+    if (images_cap <= 0) return LDN_OK;
+    GiArgs g{};
+    g.a = a; g.lda = lda; g.m_count = m_count; g.wf = static_cast<const unsigned char*>(w_frag); g.C = C;
+    g.scale = scale; g.shift = shift; g.relu = relu; g.out = out; g.ldo = ldo;
+    g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.stride = stride;
+    const int G = C / 16;
+    LDN_REQUIRE(gi_plan(Hi, Wi, Ho, stride, G, &g.gchunk, &g.R),
+                "ldn_grouped16_conv3x3_images: three rows of a %d-wide map do not fit the LDS (ldn_grouped16_images_fit)", Wi);
+    g.nbands = ceil_div(Ho, g.R);
+    g.in_ld = 16 * g.gchunk + 4;
+    const int in_rows = g.R == Ho ? Hi : min(Hi, (g.R - 1) * stride + 3);
+    const size_t lds = (size_t)g.gchunk * GM_FRAG + ((size_t)in_rows * Wi + 1) * g.in_ld * 4;
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_grouped16_img), lds), "k_grouped16_img: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(k_grouped16_img, dim3((unsigned)(ceil_div(G, g.gchunk) * g.nbands), (unsigned)images_cap), dim3(512), lds,
+                       static_cast<hipStream_t>(stream), g);
+    LDN_CHECK_LAUNCH("k_grouped16_img");
     return LDN_OK;
 }

@@ -143,15 +143,22 @@ class BottleneckTransform(_PrepCache):
         return self._prep
 
 
-def _conv_b_rows(p, f, h_a, nbr, h_b, m_count, m_cap):
-    """conv b (grouped 3x3 + BN + ReLU) over packed rows: on the matrix cores for group width 16 in bf16x3 mode, else the fp32 VALU kernel"""
+def _conv_b_rows(p, f, h_a, nbr, h_b, m_count, m_cap, images=None):
+    """conv b (grouped 3x3 + BN + ReLU) over packed rows: on the matrix cores for group width 16 in bf16x3 mode, else the fp32 VALU
+    kernel.  images = (B, Hi, Wi, Ho, Wo, stride) when the rows are whole images in order (layer skip, dense index): maps that fit
+    the LDS are staged there once per (image, group chunk) instead of being read once per tap through the neighbour table."""
     if "wb_frag" in p and ops.get_math_mode() == "bf16x3" and USE_GROUPED_MFMA:
-        ops.grouped16_conv3x3_rows(h_a, nbr, p["wb_frag"], p["sb"], p["tb"], h_b, m_count=m_count, m_cap=m_cap, relu=1)
+        if (images is not None and m_count is not None and USE_GROUPED_IMAGES
+                and ops.grouped16_images_fit(images[1], images[2], h_b.shape[1]) > 0):
+            ops.grouped16_conv3x3_images(h_a, p["wb_frag"], p["sb"], p["tb"], h_b, m_count=m_count, images=images, relu=1)
+        else:
+            ops.grouped16_conv3x3_rows(h_a, nbr, p["wb_frag"], p["sb"], p["tb"], h_b, m_count=m_count, m_cap=m_cap, relu=1)
     else:
         ops.grouped_conv3x3_rows(h_a, nbr, p["wb"], f.group_width, p["sb"], p["tb"], h_b, m_count=m_count, m_cap=m_cap, relu=1)
 
 
 USE_GROUPED_MFMA = __import__("os").environ.get("LDN_GROUPED_MFMA", "1") != "0"    # tuning switch (A/B)
+USE_GROUPED_IMAGES = __import__("os").environ.get("LDN_GROUPED_IMAGES", "1") != "0"   # ... the whole-image form of it
 
 
 class ResBottleneckBlock(_PrepCache):
@@ -244,7 +251,7 @@ class ResBottleneckBlock(_PrepCache):
         h_a = torch.empty(ix.cap1, w_b, device=dev, dtype=torch.float32)
         ops.conv_rows(x2d, p["wa"], p["sa"], p["ta"], h_a, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
         h_b = torch.empty(ix.cap3, w_b, device=dev, dtype=torch.float32)
-        _conv_b_rows(p, f, h_a, ix.nbr, h_b, ix.cnt[0:1], ix.cap3)
+        _conv_b_rows(p, f, h_a, ix.nbr, h_b, ix.cnt[0:1], ix.cap3, images=(B, Hi, Wi, Ho, Wo, self.stride))
         ops.se_packed(h_b, ix.pre3, p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo)
         cout = p["wc"].shape[0]
         if self.proj is not None:
@@ -305,7 +312,7 @@ class ResBottleneckBlock(_PrepCache):
             h_a = torch.empty(B * Hi * Wi, w_b, device=dev, dtype=torch.float32)
             ops.conv_rows(x2d, p["wa"], p["sa"], p["ta"], h_a, taps=1, m_cap=B * Hi * Wi)
             h_b2d = torch.empty(B * Ho * Wo, w_b, device=dev, dtype=torch.float32)
-            _conv_b_rows(p, f, h_a, dense.nbr, h_b2d, None, B * Ho * Wo)
+            _conv_b_rows(p, f, h_a, dense.nbr, h_b2d, dense.cnt[0:1], B * Ho * Wo, images=(B, Hi, Wi, Ho, Wo, s))
             ops.se_packed(h_b2d, self._img_prefix(B, Ho * Wo, dev), p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo)
         if self.proj is not None:
             wp, sp, tp = self._proj(dev)

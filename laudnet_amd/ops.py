@@ -370,6 +370,29 @@ def grouped16_conv3x3_rows(a2d, nbr, w_frag, scale, shift, out2d, *, m_count=Non
     return out2d
 
 
+def grouped16_images_fit(Hi, Wi, C):
+    """Groups per workgroup of ldn_grouped16_conv3x3_images for an Hi x Wi input map (0: it does not fit the LDS)."""
+    return int(L.load().ldn_grouped16_images_fit(int(Hi), int(Wi), int(C)))
+
+
+def grouped16_conv3x3_images(a2d, w_frag, scale, shift, out2d, *, m_count, images, relu=1):
+    """Grouped 3x3 conv (group width 16) + BN (+ReLU) over packed rows that are WHOLE IMAGES in order (see
+    ldn_grouped16_conv3x3_images).  images = (B, Hi, Wi, Ho, Wo, stride); m_count = device-side number of output rows."""
+    L.require_device(a2d, w_frag, out2d, m_count)
+    lib = L.load()
+    C = w_frag.shape[0] * 16
+    if w_frag.dtype != torch.bfloat16 or not w_frag.is_contiguous() or w_frag.numel() * 2 != lib.ldn_grouped16_weight_bytes(C):
+        raise L.LdnError("grouped16_conv3x3_images: w_frag must be the contiguous bf16 tensor of pack_grouped16_weights")
+    B, Hi, Wi, Ho, Wo, stride = (int(v) for v in images)
+    if a2d.shape[0] < B * Hi * Wi or out2d.shape[0] < B * Ho * Wo:
+        raise L.LdnError("grouped16_conv3x3_images: a / out must hold B whole images")
+    L.check(lib.ldn_grouped16_conv3x3_images(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(m_count, "m_count")), B, Hi, Wi, Ho,
+                                             Wo, stride, L.ptr(w_frag), C, L.ptr(_f32c(scale, "scale")),
+                                             L.ptr(_f32c(shift, "shift")), relu, L.ptr(_f32c(out2d, "out")), out2d.stride(0),
+                                             L.stream_ptr()), "ldn_grouped16_conv3x3_images")
+    return out2d
+
+
 def grouped_conv3x3_image(a_nhwc, w, group_width, ch_idx, ch_cnt, scale, shift, out_nhwc, *, stride=1, relu=1):
     """Grouped 3x3 conv + BN (+ReLU) on left-packed per-image channel subsets (see ldn_grouped_conv3x3_image).  w [C,9,gw]."""
     L.require_device(a_nhwc, w, out_nhwc, ch_idx)

@@ -511,3 +511,39 @@ def test_grouped16_conv3x3_rows_mfma_vs_torch(ops, B, Ho, stride, C, p):
     got = out[:n3].cpu()
     assert torch.isfinite(got).all()
     assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("B,Ho,stride,C,p", [(6, 14, 1, 320, 0.5), (3, 14, 2, 64, 0.7), (4, 7, 1, 784, 0.5), (5, 14, 2, 320, 0.4),
+                                             (3, 28, 1, 144, 0.6), (2, 5, 1, 16, 1.0), (4, 9, 2, 48, 0.0),
+                                             # maps beyond one workgroup's LDS: bands of output rows (halo rows re-staged)
+                                             (3, 56, 2, 64, 0.7), (3, 28, 2, 144, 0.7), (2, 56, 1, 32, 1.0), (2, 37, 2, 16, 1.0)])
+def test_grouped16_conv3x3_whole_images_vs_rows_kernel(ops, B, Ho, stride, C, p):
+    """Layer skip (one decision per image): the LDS-staged whole-image form of the grouped 3x3 (ldn_grouped16_conv3x3_images)
+    against the neighbour-table kernel on the same packed rows (same products, same order over taps: identical up to the fp32
+    rounding of the two bf16x3 sums -- they are bit-equal) and against F.conv2d(groups) on the kept images."""
+    import torch.nn.functional as F
+    Hi = Ho * stride
+    patch = seeded_bernoulli((B, 1, 1), p, 31 + C + B)
+    ix = ops.mask_to_index(patch.to(DEV), Ho, Ho, stride)
+    n3, n1 = int(ix.cnt[0].item()), int(ix.cnt[1].item())
+    assert ops.grouped16_images_fit(Hi, Hi, C) > 0
+    x = seeded_randn((B, C, Hi, Hi), 32 + C)
+    w = seeded_randn((C, 16, 3, 3), 33 + C) * (2.0 / 144) ** 0.5
+    sc, sh = _affine(C, 34)
+    rows_in = x.permute(0, 2, 3, 1).reshape(-1, C)
+    h_a = torch.full((ix.cap1, C), float("nan"))          # rows beyond the kept images must never be read
+    if n1:
+        h_a[:n1] = rows_in[ix.idx1[:n1].long().cpu()]
+    frag = ops.pack_grouped16_weights(w.permute(0, 2, 3, 1).reshape(C, 9, 16).contiguous().to(DEV))
+    out_img = torch.full((ix.cap3, C), -7.0, device=DEV)
+    ops.grouped16_conv3x3_images(h_a.to(DEV), frag, sc.to(DEV), sh.to(DEV), out_img, m_count=ix.cnt[0:1],
+                                 images=(B, Hi, Hi, Ho, Ho, stride), relu=1)
+    out_rows = torch.full((ix.cap3, C), -7.0, device=DEV)
+    ops.grouped16_conv3x3_rows(torch.nan_to_num(h_a).to(DEV), ix.nbr, frag, sc.to(DEV), sh.to(DEV), out_rows, m_count=ix.cnt[0:1],
+                               m_cap=ix.cap3, relu=1)
+    assert torch.equal(out_img[:n3], out_rows[:n3])
+    assert bool((out_img[n3:] == -7.0).all()), "rows beyond the kept images must not be written"
+    dense = F.conv2d(x.double(), w.double(), stride=stride, padding=1, groups=C // 16)
+    dense = torch.relu(dense * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
+    want = dense.permute(0, 2, 3, 1).reshape(-1, C)[ix.idx3[:n3].long().cpu()]
+    assert torch.allclose(out_img[:n3].cpu(), want, atol=1e-4, rtol=1e-4)

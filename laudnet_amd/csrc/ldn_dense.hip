@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     constexpr int NT = NSUB * 32;
     constexpr int D = NSUB == 8 ? 2 : 3;
     constexpr int SLOT = (D_ROWS + NT) * 128;
-    constexpr int NWI = NT / 64 > 0 ? NT / 64 : 1;    // weight DMA instructions per wave and chunk (8 rows each)
+    constexpr int NWI = (NT + 63) / 64;               // weight DMA instructions per wave and chunk (8 rows each) ...
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* const s_arow = reinterpret_cast<int*>(smem);            // [256] source row or -1
     int* const s_orow = s_arow + D_ROWS;                         // [256] destination row | D_ROW_RELU, or -1
@@ -128,7 +128,9 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     const int wrow = (T9 ? 9 : 1) * (p.cin / 8);                 // octets per weight row
     const int nchunks = (T9 ? 9 : 1) * cpt;
     const unsigned lds_ring = d_lds_off(s_ring);
-    const int per_chunk = (active ? 4 : 0) + NWI;
+    // ... of which this wave issues nwi: with NT = 160 (NSUB 5) the last instruction only exists for the waves whose 8 rows are inside the tile
+    const int nwi = (NT % 64 == 0 || (NWI - 1) * 64 + wave * 8 < NT) ? NWI : NWI - 1;
+    const int per_chunk = (active ? 4 : 0) + nwi;
     long asrc[4];                                                // this lane's four source rows (element offsets), -1 = zero row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -154,13 +156,14 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
+            if (i >= nwi) break;
             const int r = i * 64 + wave * 8 + (lane >> 3);
             const int ls = (lane & 7) ^ ((r >> 1) & 7);
             const int n = n0 + r;
             const unsigned char* src = (r < NT && n < p.cout && ck * 8 + ls < p.cin / 4)
                                            ? p.ws + ((long)n * wrow + tap * (p.cin / 8) + ck * 4) * 32 + ls * 16
                                                                : reinterpret_cast<const unsigned char*>(g_dense_zero);
-            d_dma16(src, slot + (D_ROWS + (r < NT ? i * 64 + wave * 8 : 0)) * 128);
+            d_dma16(src, slot + (D_ROWS + i * 64 + wave * 8) * 128);      // (i < nwi: the wave's 8 rows are inside the tile)
         }
     };
     auto dma_dummy = [&](int c) {
@@ -264,13 +267,14 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bl[half], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bh[half], acc[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (st < 4 + NWI) {                   // one DMA instruction of the next chunk behind this step's MFMAs
+                if (st < 4 + nwi) {                   // one DMA instruction of the next chunk behind this step's MFMAs
                     dma_one(c + D - 1, st);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
-            for (int k = 2 * NSUB; k < 4 + NWI; ++k) dma_one(c + D - 1, k);   // (64-column tiles: five instructions, four steps)
+            for (int k = 2 * NSUB; k < 4 + NWI; ++k)
+                if (k < 4 + nwi) dma_one(c + D - 1, k);   // (64-column tiles: five instructions, four steps)
         } else {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -429,6 +433,10 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
     if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8, false>(d, st);
     if (cout % 128 == 0) return launch_dense<4, false>(d, st);
     if (cout <= 64) return launch_dense<2, false>(d, st);
+    // 160-column tiles: layers whose width is a multiple of 160 (320: two whole tiles instead of 128 + 128 + 64), and ragged widths
+    // above 128 (144 in one tile; 784 = 4 x 160 + 144) -- LAD-RegNet
+    static const bool use5 = !getenv("LDN_DENSE_NO5");
+    if (use5 && (cout % 160 == 0 || (cout % 32 != 0 && cout > 128))) return launch_dense<5, false>(d, st);
     if (cout % 32 != 0 && cout > 128 && cout <= 256) return launch_dense<8, false>(d, st);   // a ragged layer in ONE column tile (144, 168, 216 ...)
     return launch_dense<4, false>(d, st);
 }

@@ -212,7 +212,9 @@ def _affine(c, seed):
                                            (5000, 128, 128),
                                            # widths that are not multiples of 32 (LAD-RegNet 144 / 784): zero-filled K tail, ragged column tile
                                            (700, 144, 144), (300, 784, 144), (513, 144, 784), (300, 24, 40), (256, 72, 36),
-                                           (400, 320, 784), (290, 48, 168)])
+                                           (400, 320, 784), (290, 48, 168),
+                                           # 160-column tiles (k_dense<5>): whole tiles, the pinned schedule, and a single tile
+                                           (600, 320, 320), (300, 64, 160), (1000, 160, 480)])
 def test_conv_rows_1x1_gather(ops, rows, cin, cout):
     a = seeded_randn((rows, cin), 1)
     w = seeded_randn((cout, 1, cin), 2) * (2.0 / cin) ** 0.5

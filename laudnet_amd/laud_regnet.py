@@ -157,8 +157,8 @@ def _conv_b_rows(p, f, h_a, nbr, h_b, m_count, m_cap, images=None):
         ops.grouped_conv3x3_rows(h_a, nbr, p["wb"], f.group_width, p["sb"], p["tb"], h_b, m_count=m_count, m_cap=m_cap, relu=1)
 
 
-USE_GROUPED_MFMA = __import__("os").environ.get("LDN_GROUPED_MFMA", "1") != "0"    # tuning switch (A/B)
-USE_GROUPED_IMAGES = __import__("os").environ.get("LDN_GROUPED_IMAGES", "1") != "0"   # ... the whole-image form of it
+USE_GROUPED_MFMA = os.environ.get("LDN_GROUPED_MFMA", "1") != "0"    # tuning switch (A/B)
+USE_GROUPED_IMAGES = os.environ.get("LDN_GROUPED_IMAGES", "1") != "0"   # ... the whole-image form of it
 
 
 class ResBottleneckBlock(_PrepCache):

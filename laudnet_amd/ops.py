@@ -173,6 +173,7 @@ _SPLIT_CACHE = {}   # (data_ptr, _version, shape) of an fp32 weight -> its pre-s
 DENSE_TAPS = tuple(int(t) for t in os.environ.get("LDN_DENSE_TAPS", "1,9").split(","))   # tuning: "1,9" sends the packed-row 3x3 to k_dense too
 DENSE_CHANNEL_3X3 = os.environ.get("LDN_DENSE_CHANNEL_3X3", "0") != "0"   # the 3x3 of the dense channel execution (stage 4) on k_dense (measured: no gain)
 DENSE_K_MULT = int(os.environ.get("LDN_DENSE_K_MULT", "8"))   # tuning: 32 keeps layers whose widths are not multiples of 32 (LAD-RegNet 144 / 784) on the round-1 kernels
+DENSE_N_MULT = 4 if DENSE_K_MULT == 8 else 32
 USE_DENSE_KERNEL = os.environ.get("LDN_DENSE_KERNEL", "1") != "0"   # tuning switch: off keeps every packed-row 1x1 on the round-1 kernels
 
 
@@ -207,7 +208,7 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
     # SLOWER there than round 1's producer/consumer kernel (spatial 17.8 -> 19.1 ms); with the pinned schedule it is faster on the
     # packed-row paths (spatial 16.62 -> 16.31 ms, same box) and neutral on the dense channel execution of stage 4, which stays on
     # k_conv_bf3 (DENSE_CHANNEL_3X3).  LDN_DENSE_TAPS=1 restores the old dispatch.
-    dense_ok = (USE_DENSE_KERNEL and mode == "bf16x3" and taps in DENSE_TAPS and cin % DENSE_K_MULT == 0 and cout % (4 if DENSE_K_MULT == 8 else 32) == 0
+    dense_ok = (USE_DENSE_KERNEL and mode == "bf16x3" and taps in DENSE_TAPS and cin % DENSE_K_MULT == 0 and cout % DENSE_N_MULT == 0
                 and a2d.stride(0) >= cin)
     classes = 1 if shift.dim() == 1 else shift.shape[0]
     if (post_sub is not None or chan_mask is not None or classes != 1) and not dense_ok:

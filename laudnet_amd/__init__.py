@@ -11,4 +11,6 @@ from .laud_resnet import (Bottleneck, ExpandMask, Masker_channel_conv_linear, Ma
 from .laud_regnet import (LAD_RegNet, BlockParams, lad_regnet_y_400mf, lad_regnet_y_800mf,  # noqa: F401
                           lad_regnet_y_1_6gf, lad_regnet_y_3_2gf, lad_regnet_y_8gf, lad_regnet_y_16gf)
 
+from . import sparsity_loss  # noqa: F401,E402  (the criteria the caller applies to the 7-tuple, train/main.py:311,670)
+
 __version__ = "0.1.0"

@@ -222,6 +222,9 @@ typedef struct ldn_chain_block {
     const float* shift3;
     const float* mw1; const float* mb1; const float* mw2; const float* mb2;
 } ldn_chain_block;
+/* 1 when a run on an H x Wd map (C channels, this width / masker shape) fits the workgroup's 160 KiB of LDS in every phase,
+ * 0 otherwise (the caller then launches the blocks one by one: ldn_bottleneck_head / ldn_bottleneck_tail). */
+int ldn_bottleneck_chain_fits(int H, int Wd, int C, int width, int hidden, int G);
 int ldn_bottleneck_chain(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
                          const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran, const float* gap_in,
                          int gap_splits, float* colsum, float* masks, int32_t* ch_idx, int32_t* ch_cnt, void* h1_split,

@@ -68,9 +68,11 @@ class TokenSkipBlock(nn.Module):
     def forward(self, x, keep):
         """x [B, L, dim], keep [B, L] {0,1} -> new [B, L, dim] (kept tokens updated, the others passed through)."""
         B, Lt, D = x.shape
+        if Lt > 256:    # ldn_packed_mha holds at most 256 kept tokens of an image in LDS: more would be dropped silently
+            raise LdnError("TokenSkipBlock: at most 256 tokens per image (ldn_packed_mha)")
         x2d = x.reshape(B * Lt, D).clone()
         tok_rows, prefix, count = ops.token_lists(keep)
-        self.run_packed(x2d, tok_rows, prefix, count, B, min(Lt, 256))
+        self.run_packed(x2d, tok_rows, prefix, count, B, Lt)
         return x2d.view(B, Lt, D)
 
 

@@ -988,16 +988,27 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
 #endif
 }
 
+// LDS of the three phases of a chained block (masker, conv2, conv3; conv1's ring takes whatever is left): do they fit 160 KiB?
+static bool chain_fits(int H, int Wd, int width, int C, int hidden, int G) {
+    const int NS = width / 32;
+    const int nr = H * Wd;
+    const size_t slice = (size_t)round_up((round_up(nr, 8) + 1) * 128, 1024);
+    const size_t lds2 = (size_t)T_KIDX_BYTES + (NS == 2 ? 1 : 2) * slice + (size_t)T_W2_SLOTS * 16 * NS * 256;
+    const size_t lds3 = (size_t)T_KIDX_BYTES + 2 * (size_t)(width / 2) * (NS == 8 ? 32 : 64) * 8 + (size_t)18 * width * 4 + 8 * 4096;
+    const size_t ldsm = (size_t)(C + (hidden > 0 ? hidden : 1) + 2 * G) * 4 + 64;
+    // conv1: at least two ring slots of (x rows + weight rows) x 128 B behind the channel list and the tables
+    const size_t lds1 = (size_t)T_KIDX_BYTES + 3 * (size_t)width * 4 + 2 * (size_t)(round_up(nr, 32) + width) * 128;
+    const size_t lds = 160 * 1024;
+    return lds2 <= lds && lds3 <= lds && ldsm <= lds && lds1 <= lds && round_up(nr, 8) / 8 <= 72;
+}
+
 template <int NS>
 static int launch_chain(ChainArgs& a, hipStream_t st) {
     constexpr int W = NS * 32;
     const int nr = a.H * a.Wd;
     a.slice_bytes = round_up((round_up(nr, 8) + 1) * 128, 1024);
-    const size_t lds2 = (size_t)T_KIDX_BYTES + (NS == 2 ? 1 : 2) * (size_t)a.slice_bytes + (size_t)T_W2_SLOTS * 16 * NS * 256;
-    const size_t lds3 = (size_t)T_KIDX_BYTES + 2 * (size_t)(W / 2) * (NS == 8 ? 32 : 64) * 8 + (size_t)18 * W * 4 + 8 * 4096;
-    const size_t ldsm = (size_t)(a.C + (a.hidden > 0 ? a.hidden : 1) + 2 * a.G) * 4 + 64;
     const size_t lds = 160 * 1024;
-    LDN_REQUIRE(lds2 <= lds && lds3 <= lds && ldsm <= lds, "ldn_bottleneck_chain: the phases need more than 160 KiB of LDS (map %dx%d, width %d)", a.H, a.Wd, W);
+    LDN_REQUIRE(chain_fits(a.H, a.Wd, W, a.C, a.hidden, a.G), "ldn_bottleneck_chain: the phases need more than 160 KiB of LDS (map %dx%d, width %d; ldn_bottleneck_chain_fits == 0)", a.H, a.Wd, W);
     a.lds_total = (int)lds;
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_chain<NS>), lds), "k_chain: cannot reserve %zu B of LDS", lds);
     hipLaunchKernelGGL((k_chain<NS>), dim3((unsigned)a.B), dim3(512), lds, st, a);
@@ -1006,6 +1017,11 @@ static int launch_chain(ChainArgs& a, hipStream_t st) {
 }
 
 }  // namespace ldn
+
+extern "C" int ldn_bottleneck_chain_fits(int H, int Wd, int C, int width, int hidden, int G) {
+    if (H < 1 || Wd < 1 || H * Wd > 256 || C < 1 || G < 1 || hidden < 0 || (width != 64 && width != 128 && width != 256)) return 0;
+    return ldn::chain_fits(H, Wd, width, C, hidden, G) ? 1 : 0;
+}
 
 extern "C" int ldn_bottleneck_chain(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
                                     const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran,

@@ -57,9 +57,9 @@ def _pack_sparsities(outputs):
 class PendingGather:
     """Handle of an exchange in flight (gather_outputs_async).  wait() -> the global-batch 7-tuple."""
 
-    def __init__(self, outputs, full, vec, sizes, works, world, recompute):
+    def __init__(self, outputs, full, vec, sizes, works, world, recompute, pf=None):
         self._o, self._full, self._vec, self._sizes = outputs, full, vec, sizes
-        self._works, self._world, self._recompute = works, world, recompute
+        self._works, self._world, self._recompute, self._pf = works, world, recompute, pf
 
     def wait(self):
         for w in self._works:
@@ -72,9 +72,8 @@ class PendingGather:
         else:
             # no FLOPs table given: average the per-rank values like the reference does (train/main.py:673-683); NOT equal to
             # the single-device result when channel sparsities differ between shards
-            pf = torch.cat([self._o[5].reshape(-1).float(), self._o[6].reshape(-1).float()])
-            dist.all_reduce(pf, op=dist.ReduceOp.SUM)
-            pf = pf / self._world
+            # (that all_reduce was issued with the others by gather_outputs_async, on the same process group)
+            pf = self._pf / self._world
             perc, flops = pf[:-1], pf[-1].reshape(())
         return (self._full, list(groups[0]), list(groups[1]), list(groups[2]), list(groups[3]), perc, flops)
 
@@ -99,7 +98,11 @@ def gather_outputs_async(outputs, recompute=None, group=None):
     vec, sizes = _pack_sparsities(outputs)
     works = [dist.all_gather_into_tensor(full, logits, group=group, async_op=True),
              dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group, async_op=True)]
-    return PendingGather(outputs, full, vec, sizes, works, world, recompute)
+    pf = None
+    if recompute is None:   # no FLOPs table: the per-rank flops_perc / flops are averaged (third async collective, same group)
+        pf = torch.cat([outputs[5].reshape(-1).float(), outputs[6].reshape(-1).float()])
+        works.append(dist.all_reduce(pf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return PendingGather(outputs, full, vec, sizes, works, world, recompute, pf)
 
 
 def gather_outputs(outputs, recompute=None, group=None):

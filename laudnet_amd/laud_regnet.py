@@ -245,7 +245,7 @@ class ResBottleneckBlock(_PrepCache):
             patch = f.masker_spatial.decide(x, carry=carry_in)
         ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, self.stride)
         if f.forced_spatial_mask is None and getattr(f.masker_spatial, "last_work", None) is not None:
-            f.last_carry = (f.masker_spatial.last_work, ix.pre3)   # which images this block leaves unchanged, and their channel sums
+            f.last_carry = (f.masker_spatial.last_work, ix.pre3, getattr(f.masker_spatial.last_work, "ldn_shape_key", None))   # which images this block leaves unchanged, and their channel sums
         x2d = xn.reshape(B * Hi * Wi, Cin)
         w_b = f.w_b
         h_a = torch.empty(ix.cap1, w_b, device=dev, dtype=torch.float32)
@@ -549,6 +549,7 @@ class LAD_RegNet(nn.Module):
                 self._tap(j, blk.f, x)
             # layer skip: the images the previous block skipped are unchanged -> their channel sums are carried to this block's masker
             blk.f._carry_in = (prev.f.last_carry if (self.use_layer_carry and prev is not None and blk.proj is None and blk.stride == 1
+                                                     and prev.proj is None and prev.stride == 1    # the producer leaves skipped images unchanged
                                                      and blk.f.dyn_mode == "spatial" and prev.f.dyn_mode == "spatial" and blk.f.mask_size == 1
                                                      and prev.f.mask_size == 1 and blk.f.forced_spatial_mask is None
                                                      and getattr(prev.f, "last_carry", None) is not None) else None)

@@ -82,8 +82,10 @@ _PREP_GEN = itertools.count()
 
 class _PrepCache(nn.Module):
     """Mixin: lazily built, device-resident folded weights.  The cache is keyed on (data_ptr, _version) of every parameter
-    and buffer of the module's OWN sub-tree, so in-place edits (p.data.copy_, BN re-estimation, an optimizer step) are
-    noticed like load_state_dict / .to() / train() are; `invalidate()` is the public way to drop it by hand."""
+    and buffer of the module's OWN sub-tree, so in-place edits through the tensor itself (p.copy_ / p.mul_ under no_grad, BN
+    re-estimation, an optimizer step) are noticed like load_state_dict / .to() / train() are.  NOT noticed: edits through
+    `p.data` (`p.data.copy_(...)` -- `.data` is a detached alias with its own version counter, p._version stays put): call
+    `invalidate()` on the module after such an edit, or the stale folded weights keep being used."""
 
     def _init_cache(self):
         self._prep = None
@@ -598,7 +600,7 @@ class Bottleneck(_PrepCache):
         union = patch[:, 0] if G == 1 else patch.amax(dim=1)
         ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride)
         if ms.mask_size == 1 and G == 1 and self.forced_spatial_mask is None and getattr(ms, "last_work", None) is not None:
-            self.last_carry = (ms.last_work, ix.pre3)      # layer skip: which images this block leaves unchanged, and their channel sums
+            self.last_carry = (ms.last_work, ix.pre3, getattr(ms.last_work, "ldn_shape_key", None))      # layer skip: which images this block leaves unchanged, and their channel sums
         x2d = xn.reshape(B * Hi * Wi, Cin)
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
         ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
@@ -933,6 +935,9 @@ class ResNet(nn.Module):
             prev = blocks[j - 1] if j > 0 else None
             blk._carry_in = (prev.last_carry if (self.use_layer_carry and prev is not None and blk.dyn_mode == "layer" and prev.dyn_mode == "layer"
                                                  and blk.stride == 1 and blk.downsample is None and blk.forced_spatial_mask is None
+                                                 # the producer must leave the images it skips UNCHANGED: a block with a projection
+                                                 # shortcut / stride 2 turns them into relu(downsample(x))
+                                                 and prev.stride == 1 and prev.downsample is None
                                                  and getattr(prev, "_carry_step", -1) == step_id) else None)
             x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap, defer_stats=True, inplace=self.inplace_residual)
             blk._carry_step = step_id if getattr(blk, "last_carry", None) is not None else -1
@@ -959,6 +964,13 @@ class ResNet(nn.Module):
         if H * W > 256 or H * W <= 64 or gap.dim() != 3 or gap.shape[0] != B or gap.shape[2] != C:
             return 0
         first, n = blocks[j], 0
+        m0 = getattr(first, "masker_channel", None)
+        if not isinstance(m0, Masker_channel_MLP) or first.width not in (64, 128, 256):
+            return 0
+        # the library decides whether the run's phases fit one workgroup's LDS (a 16x16 map of a 256-wide layer does not: the
+        # blocks then run one by one, which does fit)
+        if not ops.bottleneck_chain_fits(H, W, C, first.width, m0.conv[0].out_features if m0.layers == 2 else 0, m0.channel_dyn_group):
+            return 0
         for blk in blocks[j:]:
             m = blk.masker_channel
             ok = (isinstance(blk, Bottleneck) and blk.dyn_mode == "channel" and isinstance(m, Masker_channel_MLP)

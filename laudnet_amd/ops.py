@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import os
 import threading
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -84,8 +85,8 @@ def from_nhwc(y):
 # ---------------------------------------------------------------------------------------- a1
 def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False, carry=None, return_work=False):
     """Masker_spatial eval forward (models/utils.py:47-65).  x_nhwc [B,H,W,C]; weight [2g,C]; bias [2g].
-    Returns (mask [B,g,Sy,Sx] float {0,1}, logits [B,2g,Sy,Sx] or None[, work]).  carry = (work, prefix) of the previous layer-skip
-    block on the same residual stream (see ldn_spatial_masker): images that block skipped are not re-read."""
+    Returns (mask [B,g,Sy,Sx] float {0,1}, logits [B,2g,Sy,Sx] or None[, work]).  carry = (work, prefix, shape_key) of the previous
+    layer-skip block on the same residual stream (see ldn_spatial_masker): images that block skipped are not re-read."""
     L.require_device(x_nhwc, weight, bias)
     lib = L.load()
     B, H, W, C = x_nhwc.shape
@@ -95,13 +96,19 @@ def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False, c
     logits = torch.empty(B, 2 * groups, sy, sx, device=x_nhwc.device, dtype=torch.float32) if want_logits else None
     nbytes = lib.ldn_spatial_masker_workspace_bytes(B, H, W, C, mask_size)
     prefix = None
-    if carry is not None and nbytes and carry[0] is not None and carry[0].numel() * 4 == nbytes and carry[0].device == x_nhwc.device:
+    # a carry is only taken from a masker call on a tensor of the SAME shape (the partial sums are [B][splits][C] of that shape: a
+    # byte count alone can coincide between a stride-2 block's input and the next block's input)
+    shape_key = (B, H, W, C, mask_size)
+    if (carry is not None and nbytes and carry[0] is not None and len(carry) > 2 and tuple(carry[2]) == shape_key
+            and carry[0].numel() * 4 == nbytes and carry[0].device == x_nhwc.device):
         work, prefix = carry[0], _i32c(carry[1], "carry_prefix")
     else:
         work = _work(nbytes, x_nhwc.device)
     L.check(lib.ldn_spatial_masker(L.ptr(_f32c(x_nhwc, "x")), B, H, W, C, L.ptr(_f32c(weight, "w")),
                                    L.ptr(_f32c(bias, "bias")), groups, mask_size, L.ptr(mask), L.ptr(logits), L.ptr(work),
                                    L.ptr(prefix), L.stream_ptr()), "ldn_spatial_masker")
+    if return_work and work is not None:
+        work.ldn_shape_key = shape_key          # what a later call must match to reuse these sums (carry[2])
     return (mask, logits, work) if return_work else (mask, logits)
 
 
@@ -182,11 +189,12 @@ def split_rows_weight(w):
     key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device))
     hit = _SPLIT_CACHE.get(key)
     if hit is None:
-        if len(_SPLIT_CACHE) > 4096:
-            _SPLIT_CACHE.clear()
         with torch.no_grad():
             w2 = w.detach().float().reshape(w.shape[0], -1)
-            hit = _SPLIT_CACHE[key] = (pack_w1_split(w2), w)     # the source tensor is kept alive: its data_ptr stays unique
+            hit = _SPLIT_CACHE[key] = (pack_w1_split(w2),)
+        # the entry lives exactly as long as its source tensor (a module's folded weight dropped by invalidate() / a new checkpoint
+        # takes its split copy with it; a later tensor that reuses the address starts from an empty slot)
+        weakref.finalize(w, _SPLIT_CACHE.pop, key, None)
     return hit[0]
 
 
@@ -512,6 +520,11 @@ def bottleneck_chain(x_in, x_work, table, width, hidden, G, gran, gap_in):
                                      L.ptr(_f32c(gap_in, "gap_in")), gap_in.shape[1], L.ptr(colsum), L.ptr(masks), L.ptr(ch_idx),
                                      L.ptr(ch_cnt), L.ptr(h1), width, L.stream_ptr(x_work)), "ldn_bottleneck_chain")
     return masks, ch_idx, ch_cnt, colsum
+
+
+def bottleneck_chain_fits(H, W, C, width, hidden, G):
+    """Does a chained run on an H x W map fit the workgroup's LDS in every phase (ldn_bottleneck_chain_fits)?"""
+    return bool(L.load().ldn_bottleneck_chain_fits(H, W, C, width, hidden, G))
 
 
 def bottleneck_tail_splits(H, W, width):

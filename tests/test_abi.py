@@ -124,3 +124,68 @@ def test_regnet_state_dict_surface_matches_reference():
         import laudnet_amd.laud_regnet as R
         got = R.BlockParams.from_init_params(se_ratio=0.25, **R._Y[name.replace("lad_regnet_y_", "")])
         assert (got.depths, got.widths, got.group_widths) == (want["depths"], want["widths"], want["group_widths"]), name
+
+
+# ---- header <-> ctypes SIGNATURES <-> INTEGRATION.md stub, argument by argument ----------------------------------------------
+def _header_prototypes():
+    """name -> list of argument classes ('P' pointer, 'I' int, 'F' float, 'Z' size_t) parsed from include/ldn_hip.h."""
+    text = open(os.path.join(ROOT, "include", "ldn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|size_t|const\s+char\s*\*)\s+(ldn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        kinds = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    kinds.append("P")
+                elif re.match(r"(const )?float\b", a):
+                    kinds.append("F")
+                elif re.match(r"(const )?size_t\b", a):
+                    kinds.append("Z")
+                elif re.match(r"(const )?(int|int32_t|unsigned)\b", a):
+                    kinds.append("I")
+                else:
+                    raise AssertionError(f"{name}: cannot classify argument {a!r}")
+        protos[name] = kinds
+    return protos
+
+
+def _kind(ct):
+    if ct is ctypes.c_int:
+        return "I"
+    if ct is ctypes.c_float:
+        return "F"
+    if ct is ctypes.c_size_t:
+        return "Z"
+    if ct is ctypes.c_void_p or ct is ctypes.c_char_p or (isinstance(ct, type) and issubclass(ct, ctypes._Pointer)):
+        return "P"
+    raise AssertionError(f"unexpected ctypes type {ct}")
+
+
+def test_ctypes_signatures_match_header_argument_by_argument():
+    from laudnet_amd import _lib
+    protos = _header_prototypes()
+    assert sorted(protos) == sorted(_lib.SIGNATURES)
+    for name, (argtypes, _) in _lib.SIGNATURES.items():
+        got = [_kind(t) for t in argtypes]
+        assert got == protos[name], f"{name}: ctypes {''.join(got)} vs header {''.join(protos[name])}"
+
+
+def test_integration_md_stub_matches_header():
+    """INTEGRATION.md section B shows a ctypes stub: every `_lib.<fn>.argtypes = [...]` line in it must have exactly the
+    arguments include/ldn_hip.h declares (a stale stub passes the stream where math_mode is expected)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    protos = _header_prototypes()
+    env = {"_P": ctypes.c_void_p, "_I": ctypes.c_int, "C": ctypes}
+    found = 0
+    for m in re.finditer(r"_lib\.(ldn_[a-z0-9_]+)\.argtypes\s*=\s*(\[[^\n]*(?:\n\s+[^\n]*)*?\])\s*\n", text):
+        name, expr = m.group(1), m.group(2)
+        argtypes = eval(expr, env)    # the document's own Python: lists of _P / _I / C.c_float
+        got = [_kind(t) for t in argtypes]
+        assert name in protos, f"INTEGRATION.md binds {name}, which the header does not declare"
+        assert got == protos[name], f"INTEGRATION.md: {name} has {len(got)} arguments {''.join(got)}, header {len(protos[name])} {''.join(protos[name])}"
+        found += 1
+    assert found >= 5

@@ -181,7 +181,7 @@ def test_integration_md_stub_matches_header():
     protos = _header_prototypes()
     env = {"_P": ctypes.c_void_p, "_I": ctypes.c_int, "C": ctypes}
     found = 0
-    for m in re.finditer(r"_lib\.(ldn_[a-z0-9_]+)\.argtypes\s*=\s*(\[[^\n]*(?:\n\s+[^\n]*)*?\])\s*\n", text):
+    for m in re.finditer(r"_lib\.(ldn_[a-z0-9_]+)\.argtypes\s*=\s*(\[[^\]]*\](?:\s*\+\s*\[[^\]]*\]\s*\*\s*\d+)?)", text):
         name, expr = m.group(1), m.group(2)
         argtypes = eval(expr, env)    # the document's own Python: lists of _P / _I / C.c_float
         got = [_kind(t) for t in argtypes]

@@ -179,16 +179,18 @@ int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, in
                    float* out, int ldo, float* colsum, int out_format, int math_mode, void* stream);
 
 /* ---- a7 (channel mode, bf16x3): FUSED TAIL of the bottleneck -- conv2 (3x3) -> bn2 + ReLU -> conv3 (1x1) -> bn3 + residual
- * + ReLU in one launch (laud_resnet.py:123-144 on the active channels; stride 1; channel_dyn_granularity % 2 == 0;
- * width in {64, 128, 256}; map width <= 256).  h2 never exists in memory and the 3x3 reads each K slice of h1 once for all
- * nine taps.  Per image b with channel list ch_idx[b, 0 .. Kb-1] (ascending, aligned pairs), Kb = ch_cnt[b]:
+ * + ReLU in one launch (laud_resnet.py:123-144 on the active channels; stride 1 or 2 (the 3x3 of a stage's first block, :123 with
+ * stride 2: H x Wd is conv2's INPUT map, the output map is Ho x Wo = ((H-1)/stride+1) x ((Wd-1)/stride+1), the residual then is the
+ * projection shortcut's output); channel_dyn_granularity % 2 == 0; width in {64, 128, 256}; output map width <= 256).  h2 never
+ * exists in memory and the 3x3 reads each K slice of h1 once for all nine taps.  Per image b with channel list
+ * ch_idx[b, 0 .. Kb-1] (ascending, aligned pairs), Kb = ch_cnt[b]:
  *   h1_split [B*H*Wd][ldh]   conv1's output in ldn_conv_image's out_format 1 (left-packed columns = list positions)
  *   w2_pairs [9][width/2][width/2][16 B]  piece (tap, kp, np) = for n in {2np, 2np+1}: bf16 {hi(w[n][2kp]), hi(w[n][2kp+1]),
  *            lo(w[n][2kp]), lo(w[n][2kp+1])} with w[n][k] = conv2.weight[n, k, tap]            (k = input, n = output channel)
  *   w3_pairs [width/2][cout][8 B]  entry (kp, c) = bf16 {hi(w3[c][2kp]), hi(w3[c][2kp+1]), lo(..), lo(..)}, w3 = bn3.scale * conv3.weight
  *   u   = relu(scale2[n] * conv2 + shift2_tab[class(pixel)][n]) - post_sub2[n]      (16 border classes as in ldn_conv_image)
- *   out = relu(w3 . u + shift3 + residual)          out/residual [B*H*Wd][ldo/ldr] fp32, may alias (in-place residual stream)
- *   colsum (optional) [B][ldn_bottleneck_tail_splits(H, Wd, width)][cout]: partial sums of out over disjoint pixel sets covering
+ *   out = relu(w3 . u + shift3 + residual)          out/residual [B*Ho*Wo][ldo/ldr] fp32, may alias (in-place residual stream)
+ *   colsum (optional) [B][ldn_bottleneck_tail_splits(H, Wd, width, stride)][cout]: partial sums of out over disjoint pixel sets covering
  *   the image (the next block's channel masker takes them as gap_partial). */
 /* conv1 of the same block in the same style (k_head): h1 = relu(scale1 * conv1x1(x)[active channels] + shift1) - post_sub1, written
  * in out_format 1 for ldn_bottleneck_tail (laud_resnet.py:115-118).  x [B*HW][ldx] fp32, cin % 32 == 0;
@@ -197,8 +199,8 @@ int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, in
 int ldn_bottleneck_head(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
                         const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
                         const float* post_sub1, void* h1_split, int ldh, void* stream);
-int ldn_bottleneck_tail_splits(int H, int Wd, int width);   /* 0 = this map / width does not fit the fused tail */
-int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int width, const void* w2_pairs,
+int ldn_bottleneck_tail_splits(int H, int Wd, int width, int stride);   /* H x Wd = conv2's INPUT map; 0 = this map / width does not fit the fused tail */
+int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs,
                         const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale2,
                         const float* shift2_tab, const float* post_sub2, const float* shift3, const float* residual,
                         int ldr, float* out, int ldo, float* colsum, void* stream);

@@ -45,8 +45,8 @@ SIGNATURES = {
     "ldn_conv_image": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I,
                         _P, _I, _P, _I, _P, _I, _I, _P], _I),
     "ldn_bottleneck_head": ([_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P], _I),
-    "ldn_bottleneck_tail_splits": ([_I, _I, _I], _I),
-    "ldn_bottleneck_tail": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
+    "ldn_bottleneck_tail_splits": ([_I, _I, _I, _I], _I),
+    "ldn_bottleneck_tail": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
     "ldn_stem_weight_bytes": ([_I], C.c_size_t),
     "ldn_stem_conv_pool": ([_P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P], _I),
     "ldn_stem3_weight_bytes": ([_I], C.c_size_t),

@@ -88,13 +88,15 @@ __device__ __forceinline__ void split2(float v, __bf16& hi, __bf16& lo) {
 constexpr int T_KIDX_BYTES = 1280;        // int[W + 32] channel list (W <= 256)
 constexpr int T_W2_SLOTS = 3;
 
-// NS = W / 32 (maximum n-subtiles / K slices of an image): 2, 4 or 8
-template <int NS>
+// NS = W / 32 (maximum n-subtiles / K slices of an image): 2, 4 or 8;  ST = stride of the 3x3 (1 or 2: the first block of a stage,
+// laud_resnet.py:123 with stride 2 -- the block's halo'd input region then holds 2 R + 1 input rows for R output rows)
+template <int NS, int ST = 1>
 __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const int mb, unsigned char* const smem, const int tid) {
     constexpr int W = NS * 32;
     // NS == 2 (stage 1: 14 short blocks per image, all of them bound by the CU's memory pipe in their conv3 phase and idle on it in
     // their conv2 phase): ONE h1 slice slot and 128 registers, so that TWO workgroups fit a CU and overlap each other's phases.
-    constexpr int SLICE_BUFS = NS == 2 ? 1 : 2;
+    // ST == 2: the input region is four times the output block, one slice slot is all that fits.
+    constexpr int SLICE_BUFS = (NS == 2 || ST == 2) ? 1 : 2;
     constexpr int W2_ROW = NS * 256;                  // bytes of one k-pair row of the staged W2 tile: W entries of 8 B
     constexpr int W2_SLOT = 16 * W2_ROW;              // 16 k-pairs = one K slice of 32
     constexpr int CW = NS == 8 ? 32 : 64;             // output channels per conv3 chunk
@@ -117,11 +119,11 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     unsigned long long tr0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, ta = 0, tb = 0, w2wait = 0, w3wait = 0, w3bar = 0, w3epi = 0, w3k = 0;
     TT(tr0)
 #endif
-    // ---- geometry of this workgroup's block of output rows and of its halo'd input region (stride 1, pad 1)
+    // ---- geometry of this workgroup's block of output rows and of its halo'd input region (stride ST, pad 1)
     const int y0 = mb * p.rows_per_blk;
     const int rows = min(p.rows_per_blk, p.Ho - y0);
     const int npix = rows * p.Wo;                              // <= 256
-    const int yin0 = max(y0 - 1, 0), yin1 = min(y0 + rows, p.Hi - 1);
+    const int yin0 = max(ST * y0 - 1, 0), yin1 = min(ST * (y0 + rows - 1) + 1, p.Hi - 1);
     const int NR = (yin1 - yin0 + 1) * p.Wi;                   // input pixels resident per slice
     const int NRp = round_up(NR, 8);
     const int ZR = NRp;                                        // index of the all-zero row of each slice slot
@@ -150,12 +152,13 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     int trow[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+        const int iy = ST * oy + t / 3 - 1, ix = ST * ox + t % 3 - 1;
         const bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         trow[t] = ok ? (iy - yin0) * p.Wi + ix : ZR;
     }
     // border class of the pixel for the shift table of the channel algebra: (top | bottom << 1) * 4 + (left | right << 1)
-    const int cls = (((oy - 1 < 0) | ((oy + 1 >= p.Hi) << 1)) * 4 + ((ox - 1 < 0) | ((ox + 1 >= p.Wi) << 1)));
+    // = which tap rows / columns fall outside the INPUT map
+    const int cls = (((ST * oy - 1 < 0) | ((ST * oy + 1 >= p.Hi) << 1)) * 4 + ((ST * ox - 1 < 0) | ((ST * ox + 1 >= p.Wi) << 1)));
 
     // ---- DMA helpers -------------------------------------------------------------------------------------------------------
     const unsigned lds_h1 = lds_off(s_h1), lds_w2 = lds_off(s_w2), lds_w3 = lds_off(s_w3);
@@ -490,27 +493,34 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
 #endif
 }
 
-template <int NS>
-__global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_tail(const TailArgs p) {
+template <int NS, int ST>
+__global__ __launch_bounds__(512, ((NS == 2 && ST == 1) ? 4 : 2)) void k_tail(const TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    tail_body<NS>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, threadIdx.x);     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
+    tail_body<NS, ST>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, threadIdx.x);     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
 }
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_tail)
 
-// bytes of LDS of the conv2 phase for blocks of R output rows of an Ho x Wo map (NS = width / 32)
-static size_t tail_lds2(int R, int Ho, int Wo, int NS) {
-    const int nr = min(R + 2, Ho) * Wo;
+// input pixels resident per slice for a block of R output rows (stride st, pad 1)
+static int tail_region_pixels(int R, int Hi, int Wi, int st) { return min(st * (R - 1) + 3, Hi) * Wi; }
+
+// bytes of LDS of the conv2 phase for blocks of R output rows (NS = width / 32)
+static size_t tail_lds2(int R, int Hi, int Wi, int NS, int st) {
+    const int nr = tail_region_pixels(R, Hi, Wi, st);
     const size_t slice = (size_t)round_up((round_up(nr, 8) + 1) * 128, 1024);
-    return (size_t)T_KIDX_BYTES + (NS == 2 ? 1 : 2) * slice + (size_t)T_W2_SLOTS * 16 * NS * 256;
+    return (size_t)T_KIDX_BYTES + ((NS == 2 || st == 2) ? 1 : 2) * slice + (size_t)T_W2_SLOTS * 16 * NS * 256;
 }
 
 // output rows per workgroup: as many as 256 pixels, the 160 KiB of LDS and the 72-piece slice pipeline allow; 0 = the map does not fit
-static int tail_rows_per_block(int Ho, int Wo, int NS, int* mblocks) {
+static int tail_rows_per_block(int Hi, int Wi, int NS, int st, int* mblocks) {
+    const int Ho = (Hi - 1) / st + 1, Wo = (Wi - 1) / st + 1;
     int R = 256 / Wo;
     if (R < 1) return 0;
     if (R > Ho) R = Ho;
-    auto fits = [&](int r) { return tail_lds2(r, Ho, Wo, NS) <= 160 * 1024 && round_up(min(r + 2, Ho) * Wo, 8) / 8 <= 72; };
+    // (the single-slot forms fetch a slice with every wave at once: no 72-piece limit of the spread-out prefetch)
+    auto fits = [&](int r) {
+        return tail_lds2(r, Hi, Wi, NS, st) <= 160 * 1024 && (st == 2 || NS == 2 || round_up(tail_region_pixels(r, Hi, Wi, st), 8) / 8 <= 72);
+    };
     while (R > 1 && !fits(R)) --R;
     if (!fits(R)) return 0;
     const int mbk = ceil_div(Ho, R);
@@ -518,19 +528,19 @@ static int tail_rows_per_block(int Ho, int Wo, int NS, int* mblocks) {
     return ceil_div(Ho, mbk);
 }
 
-template <int NS>
+template <int NS, int ST>
 static int launch_tail(TailArgs& a, hipStream_t st) {
     constexpr int W = NS * 32;
     const int R = a.rows_per_blk;
-    const int nr = min(R + 2, a.Hi) * a.Wi;
+    const int nr = tail_region_pixels(R, a.Hi, a.Wi, ST);
     a.slice_bytes = round_up((round_up(nr, 8) + 1) * 128, 1024);
-    const size_t lds2 = tail_lds2(R, a.Hi, a.Wi, NS);
+    const size_t lds2 = tail_lds2(R, a.Hi, a.Wi, NS, ST);
     const size_t lds3 = (size_t)T_KIDX_BYTES + 2 * (size_t)(W / 2) * (NS == 8 ? 32 : 64) * 8 + (size_t)18 * W * 4 + 8 * 4096;
     const size_t lds = lds2 > lds3 ? lds2 : lds3;
     LDN_REQUIRE(lds <= 160 * 1024, "ldn_bottleneck_tail: %zu B of LDS exceed 160 KiB (map %dx%d, width %d)", lds, a.Ho, a.Wo, W);
-    LDN_REQUIRE(round_up(nr, 8) / 8 <= 72, "ldn_bottleneck_tail: input region of %d pixels too large for the slice pipeline", nr);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_tail<NS>), lds), "k_tail: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL((k_tail<NS>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
+    LDN_REQUIRE(ST == 2 || NS == 2 || round_up(nr, 8) / 8 <= 72, "ldn_bottleneck_tail: input region of %d pixels too large for the slice pipeline", nr);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_tail<NS, ST>), lds), "k_tail: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((k_tail<NS, ST>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_tail");
     return LDN_OK;
 }
@@ -550,14 +560,14 @@ extern "C" int ldn_debug_set_tail_trace(void* buf) {
 }
 #endif
 
-extern "C" int ldn_bottleneck_tail_splits(int Ho, int Wo, int width) {
+extern "C" int ldn_bottleneck_tail_splits(int H, int Wd, int width, int stride) {
     int mbk = 0;
-    if (Ho < 1 || Wo < 1 || Wo > 256 || (width != 64 && width != 128 && width != 256)) return 0;
-    if (tail_rows_per_block(Ho, Wo, width / 32, &mbk) == 0) return 0;
+    if (H < 1 || Wd < 1 || (stride != 1 && stride != 2) || (Wd - 1) / stride + 1 > 256 || (width != 64 && width != 128 && width != 256)) return 0;
+    if (tail_rows_per_block(H, Wd, width / 32, stride, &mbk) == 0) return 0;
     return mbk * 8;
 }
 
-extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int width, const void* w2_pairs,
+extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs,
                                    const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
                                    const float* scale2, const float* shift2_tab, const float* post_sub2,
                                    const float* shift3, const float* residual, int ldr, float* out, int ldo,
@@ -565,7 +575,8 @@ extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, 
     LDN_REQUIRE(h1_split && w2_pairs && w3_pairs && ch_idx && ch_cnt && scale2 && shift2_tab && post_sub2 && shift3 && out,
                 "ldn_bottleneck_tail: null pointer");
     LDN_REQUIRE(width == 64 || width == 128 || width == 256, "ldn_bottleneck_tail: width must be 64, 128 or 256 (got %d)", width);
-    LDN_REQUIRE(B > 0 && H > 0 && Wd > 0 && Wd <= 256, "ldn_bottleneck_tail: bad geometry (map width must be <= 256)");
+    LDN_REQUIRE(stride == 1 || stride == 2, "ldn_bottleneck_tail: stride must be 1 or 2 (got %d)", stride);
+    LDN_REQUIRE(B > 0 && H > 0 && Wd > 0 && (Wd - 1) / stride + 1 <= 256, "ldn_bottleneck_tail: bad geometry (output map width must be <= 256)");
     LDN_REQUIRE(cout > 0 && cout % 64 == 0, "ldn_bottleneck_tail: cout must be a multiple of 64 (got %d)", cout);
     LDN_REQUIRE(ldh >= width && ldh % 8 == 0, "ldn_bottleneck_tail: ldh must be a multiple of 8 and >= width");
     LDN_REQUIRE(ldo >= cout && ldo % 4 == 0 && (!residual || (ldr >= cout && ldr % 4 == 0)), "ldn_bottleneck_tail: bad ldo / ldr");
@@ -576,18 +587,23 @@ extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, 
     TailArgs a{};
     a.h1 = static_cast<const unsigned char*>(h1_split);
     a.h1_row_bytes = (long)ldh * 4;
-    a.B = B; a.Hi = H; a.Wi = Wd; a.Ho = H; a.Wo = Wd; a.W = width; a.cout = cout;
+    a.B = B; a.Hi = H; a.Wi = Wd; a.Ho = (H - 1) / stride + 1; a.Wo = (Wd - 1) / stride + 1; a.W = width; a.cout = cout;
     a.w2p = static_cast<const unsigned char*>(w2_pairs);
     a.w3p = static_cast<const unsigned char*>(w3_pairs);
     a.k_idx = ch_idx; a.k_cnt = ch_cnt;
     a.sc2 = scale2; a.sh2 = shift2_tab; a.ps2 = post_sub2; a.sh3 = shift3;
     a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo; a.colsum = colsum;
-    a.rows_per_blk = tail_rows_per_block(H, Wd, width / 32, &a.mblocks);
-    LDN_REQUIRE(a.rows_per_blk > 0, "ldn_bottleneck_tail: a %dx%d map of width %d does not fit the workgroup (ldn_bottleneck_tail_splits == 0)", H, Wd, width);
+    a.rows_per_blk = tail_rows_per_block(H, Wd, width / 32, stride, &a.mblocks);
+    LDN_REQUIRE(a.rows_per_blk > 0, "ldn_bottleneck_tail: a %dx%d map of width %d (stride %d) does not fit the workgroup (ldn_bottleneck_tail_splits == 0)", H, Wd, width, stride);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (width == 64) return launch_tail<2>(a, st);
-    if (width == 128) return launch_tail<4>(a, st);
-    return launch_tail<8>(a, st);
+    if (stride == 2) {
+        if (width == 64) return launch_tail<2, 2>(a, st);
+        if (width == 128) return launch_tail<4, 2>(a, st);
+        return launch_tail<8, 2>(a, st);
+    }
+    if (width == 64) return launch_tail<2, 1>(a, st);
+    if (width == 128) return launch_tail<4, 1>(a, st);
+    return launch_tail<8, 1>(a, st);
 }
 
 namespace ldn {
@@ -971,7 +987,7 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
             ta.sc2 = uniform_ptr(cb->sc2); ta.sh2 = uniform_ptr(cb->sh2); ta.ps2 = uniform_ptr(cb->ps2); ta.sh3 = uniform_ptr(cb->sh3);
             ta.residual = xin; ta.ldr = p.ldx; ta.out = p.x_work; ta.ldo = p.ldx; ta.colsum = p.colsum;
             ta.rows_per_blk = p.H; ta.mblocks = 1; ta.slice_bytes = p.slice_bytes;
-            tail_body<NS>(ta, b, 0, smem, opaque_tid());
+            tail_body<NS, 1>(ta, b, 0, smem, opaque_tid());
         }
         CT(c5)
         phase_fence();

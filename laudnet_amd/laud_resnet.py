@@ -478,13 +478,17 @@ class Bottleneck(_PrepCache):
     fused_head_widths = tuple(int(t) for t in os.environ.get("LDN_HEAD_WIDTHS", "64,128,256").split(","))   # ... for these widths when a block runs on its own (with the pipelined fragment reads k_head is ahead at every width: 13.73 -> 13.62 ms)
     use_fused_tail = True    # class-level switch (A/B measurements): False keeps the three-launch gathered execution
 
+    use_strided_tail = os.environ.get("LDN_TAIL_STRIDE2", "1") != "0"   # the fused tail on the stride-2 first blocks (A/B switch)
+
     def _tail_eligible(self, Hi, Wi, Ho, Wo, cout):
-        """The fused conv2 -> conv3 launch (ldn_bottleneck_tail) covers: bf16x3 arithmetic, stride 1, an even channel
-        granularity, widths 64 / 128 / 256, maps at most 256 wide.  Everything else keeps the three-launch execution."""
+        """The fused conv2 -> conv3 launch (ldn_bottleneck_tail) covers: bf16x3 arithmetic, stride 1 or 2, an even channel
+        granularity, widths 64 / 128 / 256, output maps at most 256 wide.  Everything else keeps the three-launch execution."""
+        st = self.stride
         return (self.use_fused_tail and self.channel_exec in ("auto", "fused") and ops.get_math_mode() == "bf16x3"
-                and self.stride == 1 and (Hi, Wi) == (Ho, Wo) and self.channel_dyn_granularity % 2 == 0
+                and (st == 1 or (st == 2 and self.use_strided_tail)) and (Ho, Wo) == ((Hi - 1) // st + 1, (Wi - 1) // st + 1)
+                and self.channel_dyn_granularity % 2 == 0
                 and self.width in (64, 128, 256) and Wo <= 256 and cout % 64 == 0
-                and ops.bottleneck_tail_splits(Ho, Wo, self.width) > 0)    # LDS / slice-pipeline limits, decided by the library
+                and ops.bottleneck_tail_splits(Hi, Wi, self.width, st) > 0)    # LDS / slice-pipeline limits, decided by the library
 
     def tail_weights(self, p):
         """conv2 / conv3 weights in the pre-split pair-interleaved layouts of ldn_bottleneck_tail (built once, cached with the
@@ -559,10 +563,10 @@ class Bottleneck(_PrepCache):
                 ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1, out_split=True)
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)
-            gap_out = (torch.empty(B, ops.bottleneck_tail_splits(Ho, Wo, W), cout, device=dev, dtype=torch.float32)
+            gap_out = (torch.empty(B, ops.bottleneck_tail_splits(Hi, Wi, W, self.stride), cout, device=dev, dtype=torch.float32)
                        if want_gap else None)
             ops.bottleneck_tail(h1, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], out, residual=identity,
-                                colsum=gap_out)
+                                colsum=gap_out, stride=self.stride)
             self.last_channel_mask = mask
             self.last_gap = gap_out
             self.last_channel_cnt = cnt

@@ -527,23 +527,27 @@ def bottleneck_chain_fits(H, W, C, width, hidden, G):
     return bool(L.load().ldn_bottleneck_chain_fits(H, W, C, width, hidden, G))
 
 
-def bottleneck_tail_splits(H, W, width):
-    """GAP partial slots of the fused tail on an H x W map (0: the map / width does not fit ldn_bottleneck_tail)."""
-    return L.load().ldn_bottleneck_tail_splits(H, W, width)
+def bottleneck_tail_splits(H, W, width, stride=1):
+    """GAP partial slots of the fused tail whose 3x3 reads an H x W map with this stride (0: the map / width does not fit
+    ldn_bottleneck_tail)."""
+    return L.load().ldn_bottleneck_tail_splits(H, W, width, stride)
 
 
 def bottleneck_tail(h1_split, w2_pairs, w3_pairs, ch_idx, ch_cnt, scale2, shift2_tab, post_sub2, shift3, out_nhwc, *,
-                    residual=None, colsum=None):
+                    residual=None, colsum=None, stride=1):
     """Fused conv2 -> conv3 tail of a channel-mode bottleneck (see ldn_bottleneck_tail).  h1_split [B,H,Wd,ldh] as written by
-    conv_image(..., out_split=True); out_nhwc [B,H,Wd,cout]."""
+    bottleneck_head / conv_image(..., out_split=True); out_nhwc [B,Ho,Wo,cout] with Ho = (H-1)//stride+1 (stride = conv2's)."""
     L.require_device(h1_split, w2_pairs, w3_pairs, out_nhwc)
     lib = L.load()
     B, H, Wd, ldh = h1_split.shape
     width = ch_idx.shape[1]
     cout = out_nhwc.shape[-1]
+    Ho, Wo = (H - 1) // stride + 1, (Wd - 1) // stride + 1
+    if tuple(out_nhwc.shape) != (B, Ho, Wo, cout) or (residual is not None and tuple(residual.shape[:3]) != (B, Ho, Wo)):
+        raise L.LdnError(f"bottleneck_tail: out / residual must be [B={B}, {Ho}, {Wo}, cout] for an {H}x{Wd} input at stride {stride}")
     if w2_pairs.dtype != torch.bfloat16 or w3_pairs.dtype != torch.bfloat16 or not (w2_pairs.is_contiguous() and w3_pairs.is_contiguous()):
         raise L.LdnError("bottleneck_tail: w2_pairs / w3_pairs must be the contiguous bf16 tensors of pack_w2_pairs / pack_w3_pairs")
-    L.check(lib.ldn_bottleneck_tail(L.ptr(_f32c(h1_split, "h1")), ldh, B, H, Wd, width, L.ptr(w2_pairs), L.ptr(w3_pairs), cout,
+    L.check(lib.ldn_bottleneck_tail(L.ptr(_f32c(h1_split, "h1")), ldh, B, H, Wd, stride, width, L.ptr(w2_pairs), L.ptr(w3_pairs), cout,
                                     L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")), L.ptr(_f32c(scale2, "scale2")),
                                     L.ptr(_f32c(shift2_tab, "shift2_tab")), L.ptr(_f32c(post_sub2, "post_sub2")),
                                     L.ptr(_f32c(shift3, "shift3")), L.ptr(residual),

@@ -549,3 +549,37 @@ def test_grouped16_conv3x3_whole_images_vs_rows_kernel(ops, B, Ho, stride, C, p)
     dense = torch.relu(dense * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
     want = dense.permute(0, 2, 3, 1).reshape(-1, C)[ix.idx3[:n3].long().cpu()]
     assert torch.allclose(out_img[:n3].cpu(), want, atol=1e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ k_dense<8>: 256 x 256 tiles at full-size row counts
+@pytest.mark.parametrize("rows,cin,cout,count", [(50176, 256, 512, None), (100001, 64, 256, 99001), (100352, 40, 256, None)])
+def test_dense_256_tiles_fullsize_rows_vs_fp64(ops, rows, cin, cout, count):
+    """Shared-weight 1x1 rows on k_dense's 256-column tiles at the row counts of the bench (>= 384 tiles): against fp64; ragged last M
+    tile, device-side count, K not a multiple of 32, row gather + scatter + conditional ReLU + scale vector."""
+    ops.set_math_mode("bf16x3")
+    try:
+        a = seeded_randn((rows, cin), 1)
+        w = seeded_randn((cout, 1, cin), 2) * (2.0 / cin) ** 0.5
+        sh = seeded_randn((cout,), 3)
+        res = seeded_randn((rows, cout), 4)
+        out = torch.zeros(rows, cout, device=DEV)
+        ops.conv_rows(a.to(DEV), w.to(DEV), None, sh.to(DEV), out, taps=1, m_cap=rows, relu=1, residual2d=res.to(DEV))
+        want = torch.relu(a.double() @ w[:, 0].double().T + sh.double() + res.double()).float()
+        assert torch.allclose(out.cpu(), want, atol=1e-4, rtol=1e-4)
+        if count is not None:
+            g = torch.Generator().manual_seed(7)
+            src = torch.randint(0, rows, (rows,), generator=g).to(torch.int32)
+            dst = torch.randperm(rows, generator=g).to(torch.int32)
+            rneg = torch.where(torch.rand(rows, generator=g) < 0.5, -1, 1).to(torch.int32)
+            sc = seeded_randn((cout,), 5).abs() + 0.5
+            out2 = torch.full((rows, cout), -7.0, device=DEV)
+            cnt = torch.tensor([count], dtype=torch.int32, device=DEV)
+            ops.conv_rows(a.to(DEV), w.to(DEV), sc.to(DEV), sh.to(DEV), out2, a_rows=src.to(DEV), taps=1, m_count=cnt, m_cap=rows, relu=2,
+                          relu_if_neg=rneg.to(DEV), out_rows=dst.to(DEV))
+            y = (a[src[:count].long()].double() @ w[:, 0].double().T) * sc.double() + sh.double()
+            y = torch.where((rneg[:count] < 0).view(-1, 1), torch.relu(y), y).float()
+            want2 = torch.full((rows, cout), -7.0)
+            want2[dst[:count].long()] = y
+            assert torch.allclose(out2.cpu(), want2, atol=1e-4, rtol=1e-4)
+    finally:
+        ops.set_math_mode(None)

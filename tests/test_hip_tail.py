@@ -27,31 +27,36 @@ def _decode_split(h1s):
     return (raw[..., 0, :] + raw[..., 1, :]).reshape(B, H, W, ld)
 
 
-@pytest.mark.parametrize("B,H,cin,W,gran,down", [(4, 14, 1024, 256, 2, False), (3, 28, 512, 128, 2, False), (2, 56, 256, 64, 2, False),
-                                                 (3, 56, 64, 64, 2, True), (3, 14, 64, 256, 4, False), (2, 9, 32, 64, 2, False),
-                                                 (9, 14, 128, 256, 2, False)])
-def test_tail_vs_reference_algebra(ops, B, H, cin, W, gran, down):
+@pytest.mark.parametrize("B,H,cin,W,gran,st", [(4, 14, 1024, 256, 2, 1), (3, 28, 512, 128, 2, 1), (2, 56, 256, 64, 2, 1),
+                                               (3, 56, 64, 64, 2, 1), (3, 14, 64, 256, 4, 1), (2, 9, 32, 64, 2, 1),
+                                               (9, 14, 128, 256, 2, 1),
+                                               # stride-2 3x3 (the first block of stages 2 / 3: laud_resnet.py:123 with stride 2), odd and
+                                               # small maps, every width
+                                               (3, 56, 256, 128, 2, 2), (3, 28, 512, 256, 2, 2), (2, 13, 64, 64, 2, 2),
+                                               (2, 30, 64, 128, 4, 2), (2, 56, 32, 64, 2, 2), (5, 8, 64, 256, 2, 2)])
+def test_tail_vs_reference_algebra(ops, B, H, cin, W, gran, st):
     G = W // gran
     gm = seeded_bernoulli((B, G), 0.62, 31 + H)
     gm[0] = 0.0          # an image with no active channel
     gm[1] = 1.0          # an image with all channels
     cout = 4 * W
-    blk = TR.BottleneckRef(cin, W, stride=1, downsample=None, dyn_mode="channel", channel_dyn_granularity=gran,
-                           channel_masker="MLP", output_size=H).eval()
+    Ho = (H - 1) // st + 1
+    blk = TR.BottleneckRef(cin, W, stride=st, downsample=None, dyn_mode="channel", channel_dyn_granularity=gran,
+                           channel_masker="MLP", output_size=Ho).eval()
     TR.randomize_bn_(blk, 5)
     with torch.no_grad():
         for m in (blk.conv1, blk.conv2, blk.conv3):
             m.weight.normal_(0, (2.0 / (m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3])) ** 0.5)
     x = F.relu(seeded_randn((B, cin, H, H), 32))
-    ident = F.relu(seeded_randn((B, cout, H, H), 33))    # the residual (x itself when cin == cout, else a projection's output)
+    ident = F.relu(seeded_randn((B, cout, Ho, Ho), 33))    # the residual (x itself when cin == cout, else a projection's output)
     cm = TR.broadcast_channel_mask(gm, W)
     with torch.no_grad():
         h1 = F.relu(blk.bn1(blk.conv1(x) * cm))
         h2 = F.relu(blk.bn2(blk.conv2(h1) * cm))
         want = F.relu(blk.bn3(blk.conv3(h2)) + ident).permute(0, 2, 3, 1)
     from laudnet_amd.laud_resnet import Bottleneck
-    hb = Bottleneck(cin, W, stride=1, downsample=None, dyn_mode="channel", channel_dyn_granularity=gran,
-                    channel_masker="MLP", output_size=H).eval()
+    hb = Bottleneck(cin, W, stride=st, downsample=None, dyn_mode="channel", channel_dyn_granularity=gran,
+                    channel_masker="MLP", output_size=Ho).eval()
     hb.load_state_dict(blk.state_dict())
     hb = hb.to(DEV)
     p = hb._prepare(torch.device(DEV))
@@ -83,14 +88,15 @@ def test_tail_vs_reference_algebra(ops, B, H, cin, W, gran, down):
             assert bool((dech[b, :, :, n:pad] == 0).all()), "k_head: columns up to the next multiple of 32 must be zero"
         h1s = h1h     # the tail below consumes k_head's output
     idn = ident.permute(0, 2, 3, 1).contiguous().to(DEV)
-    splits = ops.bottleneck_tail_splits(H, H, W)
+    splits = ops.bottleneck_tail_splits(H, H, W, st)
+    assert splits > 0
     colsum = torch.full((B, splits, cout), float("nan"), device=DEV)
-    out = torch.full((B, H, H, cout), float("nan"), device=DEV)
-    ops.bottleneck_tail(h1s, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], out, residual=idn, colsum=colsum)
+    out = torch.full((B, Ho, Ho, cout), float("nan"), device=DEV)
+    ops.bottleneck_tail(h1s, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], out, residual=idn, colsum=colsum, stride=st)
     torch.cuda.synchronize()
     err = (out.cpu() - want).abs()
     assert torch.allclose(out.cpu(), want, atol=2e-4, rtol=1e-4), f"max err {err.max().item():.3e} at {tuple(torch.nonzero(err == err.max())[0].tolist())}"
     assert torch.allclose(colsum.sum(dim=1).cpu().double(), out.cpu().double().sum(dim=(1, 2)), atol=1e-2, rtol=1e-5)
     # in-place residual stream (out aliases residual): same result
-    ops.bottleneck_tail(h1s, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], idn, residual=idn)
+    ops.bottleneck_tail(h1s, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], idn, residual=idn, stride=st)
     assert torch.equal(idn, out)

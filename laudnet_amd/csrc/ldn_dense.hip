@@ -39,7 +39,16 @@ __device__ unsigned long long* g_dense_trace = nullptr;
 #define DT(x)
 #endif
 
+#ifndef LDN_DENSE_ABLATE
+#define LDN_DENSE_ABLATE 0   // tuning only (results are wrong): 1 = no LDS-DMA at all, 2 = every DMA reads the zero line, 4 = no MFMA, 8 = no weight-fragment reads
+#endif
 __device__ __forceinline__ void d_dma16(const void* gsrc, unsigned lds_base) {
+#if LDN_DENSE_ABLATE & 1
+    return;
+#endif
+#if LDN_DENSE_ABLATE & 2
+    gsrc = g_dense_zero;
+#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
@@ -248,6 +257,9 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         auto frag = [&](int step, bf16x8& ah, bf16x8& al) {   // step = half * NSUB + j: weight row 32 j + l31, octet 2 half + h
             const int half = step / NSUB, j = step - half * NSUB;
             const unsigned sl = 4u * half + 2u * h;
+#if LDN_DENSE_ABLATE & 8
+            if (step > 1) return;
+#endif
             ah = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl ^ wsw) << 4));
             al = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl + 1) ^ wsw) << 4));
         };
@@ -263,9 +275,13 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
                 if (st + 1 < 2 * NSUB) frag(st + 1, ah[(st + 1) & 1], al[(st + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);     // the schedule is pinned: the next step's reads are issued BEFORE this step's MFMAs
                 const int half = st / NSUB, j = st - half * NSUB;
+#if LDN_DENSE_ABLATE & 4
+                asm volatile("" : "+v"(acc[j]) : "v"(al[st & 1]), "v"(ah[st & 1]), "v"(bh[half]), "v"(bl[half]));
+#else
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st & 1], bh[half], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bl[half], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bh[half], acc[j], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (st < 4 + nwi) {                   // one DMA instruction of the next chunk behind this step's MFMAs
                     dma_one(c + D - 1, st);

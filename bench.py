@@ -13,9 +13,9 @@ randomised; the channel maskers' keep-bias is calibrated once, before timing, so
 the "target-0.5" operating point of the released model.
 
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
-  roofline     : dominant kernel (per-image channel-subset 3x3 conv or the wide 1x1 conv3) -- algorithmic FLOPs / bytes per
-                 launch / mean launch duration measured with HIP events on the launch stream during the timed steps
-                 (each kernel kind is bracketed in every other timed step: the event records themselves cost stream time)
+  roofline     : the kernel with the most time per step -- algorithmic FLOPs / bytes per launch / mean launch duration measured with
+                 HIP events on the launch stream in a separate leg of event-bracketed forwards right AFTER the timed region (the
+                 timed region itself carries no instrumentation); `bound` is the larger of the HBM floor and the matrix floor
   cpu_baseline : the oracle (dense-emulation restatement of the reference, torch CPU) timed on the host cores on
                  a bounded sample of the same workload
 and, unless --no-dense, `dense_emulation_gpu`: the same oracle run on the same GPU through PyTorch-ROCm
@@ -101,6 +101,25 @@ def bench_adavit(args):
             want = refg(x, keeps)
         torch.cuda.synchronize()
         dtd = (time.perf_counter() - t0) / 10
+    # roofline leg (after the timed region): HIP events around every shared-weight linear (k_dense) of two more forwards
+    timer = KernelTimer()
+    timer.PHASE = dict(timer.PHASE, rows_1x1=0)
+    orig_rows = ops.conv_rows
+    ops.conv_rows = timer.wrap_rows(orig_rows)
+    try:
+        with torch.no_grad():
+            for i in range(2):
+                timer.step = 2 * i       # every step sampled
+                hip(x, keeps)
+        agg = timer.summary()
+    finally:
+        ops.conv_rows = orig_rows
+    roof = None
+    if "rows_1x1" in agg:
+        n_, ms_, f_, by_ = agg["rows_1x1"]
+        roof = dict(two_floor("k_dense (the q/k/v, projection and MLP linears of the token-skip blocks over packed token rows, bf16x3; "
+                              "averaged over all such launches of a forward)", n_, ms_, f_, by_, 3.0),
+                    timed_ms_per_step=ms_ / 2, steps_bracketed=2)
     kept = float(sum(k.sum().item() for k in keeps)) / (depth * args.batch * L)
     # algorithmic FLOPs per image: qkv on every token, attention / proj / MLP on the kept ones (simulate_adavit.py:77-182)
     lk = kept * L
@@ -112,13 +131,30 @@ def bench_adavit(args):
               "config": {"workload": WORKLOADS["adavit"]["name"].replace("keep 0.5", f"keep {keep_p}") + f" bs{args.batch}/GPU",
                          "kept_token_fraction": round(kept, 4), "algorithmic_tflops": flops * args.batch / dt / 1e12,
                          "parity": "UNPINNED: the reference holds no model code for this configuration (oracle/adavit_ref.py header)"},
-              "roofline": None,
+              "roofline": roof,
               "dense_emulation_gpu": {"value": args.batch / dtd, "unit": "images/sec", "ms_per_step": 1e3 * dtd,
                                       "kind": "oracle/adavit_ref.py (dense masked attention, every token through every linear), PyTorch-ROCm fp32, same GPU",
                                       "max_abs_diff_vs_hip_same_masks": (out - want).abs().max().item(),
                                       "output_scale": want.abs().max().item()},
               "realised_speedup_vs_dense_emulation": dtd / dt}
     print(json.dumps(result))
+
+
+def two_floor(kernel, n, ms, flops, nbytes, mfma_mult):
+    """HBM floor (algorithmic bytes at 8 TB/s) vs matrix floor (mfma_mult executed MFMA products per algorithmic product at
+    the bf16 peak); `bound` = the larger floor, `frac` against it."""
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    tf = flops / (ms * 1e-3) / 1e12
+    hbm_us = nbytes / n / (HBM_PEAK_GBS * 1e9) * 1e6
+    mfma_us = mfma_mult * flops / n / (BF16_MFMA_PEAK_TFLOPS * 1e12) * 1e6
+    mb = mfma_us > hbm_us
+    return {"kernel": kernel, "bound": "mfma" if mb else "hbm", "achieved": mfma_mult * tf if mb else gbs,
+            "peak": BF16_MFMA_PEAK_TFLOPS if mb else HBM_PEAK_GBS, "unit": "TFLOP/s" if mb else "GB/s",
+            "frac": (mfma_mult * tf / BF16_MFMA_PEAK_TFLOPS) if mb else gbs / HBM_PEAK_GBS,
+            "floors_us_per_launch": {"hbm": hbm_us, "mfma_executed": mfma_us}, "frac_hbm": gbs / HBM_PEAK_GBS,
+            "frac_mfma_executed": mfma_mult * tf / BF16_MFMA_PEAK_TFLOPS, "algorithmic_tflops": tf, "traffic": None,
+            "launches": n, "avg_launch_us": 1e3 * ms / n, "algorithmic_mbytes_per_launch": nbytes / n / 1e6,
+            "algorithmic_gflop_per_launch": flops / n / 1e9}
 
 
 def blocks_of(model):
@@ -204,6 +240,57 @@ def audit_masker_decisions(model, ref, x, ops, headline_math):
     return res
 
 
+def free_running_decisions(model, ref, x, ops, headline_math):
+    """End-to-end decision drift: the ORACLE runs free (its own maskers on its own activations, nothing forced) and so does the HIP
+    path; how many masker decisions differ?  (audit_masker_decisions is teacher-forced: same block inputs.)  A decision that flips
+    early changes the activations of every later block, so this counts drift, not arithmetic error."""
+    rblocks = [(b.f if hasattr(b, "f") else b) for _, b in ref.blocks()]
+    recs, saved = {}, []
+    for j, rb in enumerate(rblocks):
+        for name in ("_channel_mask", "_spatial_mask"):
+            if hasattr(rb, name):
+                orig = getattr(rb, name)
+                saved.append((rb, name, rb.forced_channel_mask, rb.forced_spatial_mask))
+
+                def wrap(x_, t_, orig=orig, key=(j, name)):
+                    out = orig(x_, t_)
+                    recs[key] = out[0]
+                    return out
+                setattr(rb, name, wrap)
+        rb.forced_channel_mask = rb.forced_spatial_mask = None
+    res = {}
+    try:
+        with torch.no_grad():
+            ref(x, 1.0)
+            for math in ("fp32", "bf16x3"):
+                ops.set_math_mode(math)
+                model(x, 1.0)
+                flips = total = nblk = 0
+                first = None
+                for j, (hb, _) in enumerate(blocks_of(model)):
+                    for name, mine in (("_channel_mask", getattr(hb, "last_channel_mask", None)), ("_spatial_mask", getattr(hb, "last_spatial_mask", None))):
+                        theirs = recs.get((j, name))
+                        if mine is None or theirs is None:
+                            continue
+                        d = int((mine.reshape(mine.shape[0], -1) != theirs.reshape(theirs.shape[0], -1).to(mine.dtype)).sum())
+                        flips += d
+                        total += mine.numel()
+                        if d:
+                            nblk += 1
+                            first = j if first is None else first
+                res[math] = {"decisions_differing_from_free_running_oracle": flips, "decisions_total": total,
+                             "blocks_with_a_difference": nblk, "first_block_with_a_difference": first}
+    finally:
+        for rb, name, fc, fs in saved:
+            try:
+                delattr(rb, name)       # drop the instance-level wrapper: the class method is back
+            except AttributeError:
+                pass
+            rb.forced_channel_mask, rb.forced_spatial_mask = fc, fs
+        ops.set_math_mode(headline_math)
+    return res
+
+
 class KernelTimer:
     """HIP-event timing of the channel-mode conv launches on the launch stream (torch's current stream == the stream
     the C ABI is given): two event records per launch.  Launches are classified as
@@ -215,12 +302,13 @@ class KernelTimer:
         self.rows = []
         self.tails = []
         self.chains = []
+        self.grouped = []
         self.step = 0          # index of the timed step in flight (set by the timed loop)
         self.steps_of = {}     # kind -> set of steps in which its launches were bracketed
 
     # Two event records per launch cost ~4 us of stream time each (0.48 ms of a 19.7 ms step when every conv2 and conv3
     # launch is bracketed): each kind is bracketed in every OTHER timed step, which still samples the whole timed region.
-    PHASE = {"conv2_3x3": 0, "conv3_1x1": 1, "rows_3x3": 0, "tail_fused": 1}
+    PHASE = {"conv2_3x3": 0, "conv3_1x1": 1, "rows_3x3": 0, "tail_fused": 1, "rows_1x1": 1, "grouped16_img": 0}
     EVERY_STEP = ("chain_fused",)   # one launch per forward: two event records per step cost nothing measurable
 
     def sampled(self, kind):
@@ -273,15 +361,33 @@ class KernelTimer:
         return timed
 
     def wrap_rows(self, fn):
-        """ops.conv_rows (shared-weight packed-row convs of the spatial / layer path): the 3x3 launches."""
+        """ops.conv_rows (shared-weight packed-row convs of the spatial / layer / RegNet / token-skip paths, the projection
+        shortcuts and the dense execution of stage 4): 3x3 launches as "rows_3x3", 1x1 launches as "rows_1x1"."""
         def timed(*a, **kw):
-            if kw.get("taps", 1) != 9 or not self.sampled("rows_3x3"):
+            kind = "rows_3x3" if kw.get("taps", 1) == 9 else "rows_1x1"
+            if not self.sampled(kind):
                 return fn(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(*a, **kw)
             e1.record()
-            self.rows.append((e0, e1, kw.get("m_count"), kw.get("m_cap"), tuple(a[1].shape)))
+            cap = kw.get("m_cap")
+            if cap is None:
+                cap = a[0].shape[0] if kw.get("a_rows") is None else kw["a_rows"].numel() // kw.get("taps", 1)
+            self.rows.append((kind, e0, e1, kw.get("m_count"), cap, tuple(a[1].shape), kw.get("residual2d") is not None))
+            return out
+        return timed
+
+    def wrap_grouped_images(self, fn):
+        """ops.grouped16_conv3x3_images: LAD-RegNet conv b (grouped 3x3, 16 channels per group) on whole kept images (k_grouped16_img)."""
+        def timed(*a, **kw):
+            if not self.sampled("grouped16_img"):
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.grouped.append((e0, e1, kw.get("m_count"), tuple(a[0].shape), tuple(a[4].shape), kw.get("images")))
             return out
         return timed
 
@@ -321,11 +427,19 @@ class KernelTimer:
             n, ms, f, by = agg.get("chain_fused", (0, 0.0, 0.0, 0.0))
             agg["chain_fused"] = (n + 1, ms + e0.elapsed_time(e1), f + flops, by + nbytes)
             self.chain_blocks = n_blk
-        for e0, e1, mc, cap, wshape in self.rows:          # w [cout][9][cin]; rows = active output pixels of the batch
+        for kind, e0, e1, mc, cap, wshape, has_res in self.rows:          # w [cout][taps][cin]; rows = active output rows of the batch
             cout, taps, cin = wshape
             m = float(mc.item()) if mc is not None else float(cap)
-            n, ms, f, by = agg.get("rows_3x3", (0, 0.0, 0.0, 0.0))
-            agg["rows_3x3"] = (n + 1, ms + e0.elapsed_time(e1), f + 2.0 * m * taps * cin * cout, by + 4.0 * (m * (cin + cout) + taps * cin * cout))
+            n, ms, f, by = agg.get(kind, (0, 0.0, 0.0, 0.0))
+            agg[kind] = (n + 1, ms + e0.elapsed_time(e1), f + 2.0 * m * taps * cin * cout,
+                         by + 4.0 * (m * (cin + cout * (2 if has_res else 1)) + taps * cin * cout))
+        for e0, e1, mc, ashape, oshape, images in self.grouped:
+            # grouped 3x3, 16 channels per group: 2 * 9 * 16 FLOPs per output element; every input row read once, every output row written once
+            m_out = float(mc.item()) if mc is not None else float(oshape[0])
+            C = oshape[1]
+            rows_in = m_out * (ashape[0] / max(oshape[0], 1))
+            n, ms, f, by = agg.get("grouped16_img", (0, 0.0, 0.0, 0.0))
+            agg["grouped16_img"] = (n + 1, ms + e0.elapsed_time(e1), f + 2.0 * m_out * 9 * 16 * C, by + 4.0 * (rows_in + m_out) * C + 4.0 * 9 * 16 * C)
         return agg
 
 
@@ -443,12 +557,14 @@ def main():
     orig_conv_rows = ops.conv_rows
     orig_tail = ops.bottleneck_tail
     orig_chain = ops.bottleneck_chain
+    orig_grouped = ops.grouped16_conv3x3_images
     ev_steps = 0
     if rank == 0 and graphed is None and not os.environ.get("LDN_BENCH_NO_EVENTS"):
         ops.conv_image = timer.wrap(orig_conv_image)
         ops.conv_rows = timer.wrap_rows(orig_conv_rows)
         ops.bottleneck_tail = timer.wrap_tail(orig_tail)
         ops.bottleneck_chain = timer.wrap_chain(orig_chain)
+        ops.grouped16_conv3x3_images = timer.wrap_grouped_images(orig_grouped)
         ev_steps = max(2, min(args.steps, 10))
         try:
             t1 = time.perf_counter()
@@ -462,6 +578,7 @@ def main():
             ops.conv_rows = orig_conv_rows
             ops.bottleneck_tail = orig_tail
             ops.bottleneck_chain = orig_chain
+            ops.grouped16_conv3x3_images = orig_grouped
     if world > 1:
         torch.distributed.barrier()
 
@@ -490,7 +607,9 @@ def main():
     agg = timer.summary()
     if agg:
         # per-launch HBM traffic of the stage-3 instance of each kernel from the committed PMC passes (profiles/)
-        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if not os.path.exists(tj):
+            tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
         traffic = json.load(open(tj)) if (args.workload == "channel" and args.batch == 256 and os.path.exists(tj)) else {}
         mode = args.math
 
@@ -529,20 +648,40 @@ def main():
                     "algorithmic_tflops": tf, "executed_mfma_tflops": 3 * tf, "frac_of_bf16_mfma_peak_executed": 3 * tf / BF16_MFMA_PEAK_TFLOPS}
 
         def chain_roofline(n, ms, flops, nbytes):
-            # whole stage-3 run in one launch; with full fusion a block moves its input once and its output once (411 MB at bs256)
+            # whole stage-3 run in one launch; with full fusion a block moves its input once and its output once (411 MB at bs256).
+            # Two floors: HBM (algorithmic bytes at 8 TB/s) and the matrix pipe (3 bf16 MFMA products per algorithmic product at
+            # 2.5 PFLOP/s); `bound` names the LARGER one (the binding roof), `frac` is measured against it, both fractions are given.
             achieved = nbytes / (ms * 1e-3) / 1e9
             tf = flops / (ms * 1e-3) / 1e12
             nb = getattr(timer, "chain_blocks", 1)
+            hbm_floor_us = nbytes / n / (HBM_PEAK_GBS * 1e9) * 1e6
+            mfma_floor_us = 3.0 * flops / n / (BF16_MFMA_PEAK_TFLOPS * 1e12) * 1e6
+            mfma_binds = mfma_floor_us > hbm_floor_us
+            tr = traffic.get("chain_fused_bf16x3", {})
             return {"kernel": "k_chain (one launch = a run of stride-1 channel-mode bottlenecks: masker -> conv1 -> conv2 3x3 -> conv3 "
                               "+ residual per block, one workgroup per image, bf16x3)",
-                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic.get("chain_fused_bf16x3", {}).get("traffic_bytes_per_launch"),
-                    "traffic_scope": traffic.get("chain_fused_bf16x3", {}).get("scope"),
+                    "bound": "mfma" if mfma_binds else "hbm",
+                    "achieved": 3 * tf if mfma_binds else achieved, "peak": BF16_MFMA_PEAK_TFLOPS if mfma_binds else HBM_PEAK_GBS,
+                    "unit": "TFLOP/s" if mfma_binds else "GB/s",
+                    "frac": (3 * tf / BF16_MFMA_PEAK_TFLOPS) if mfma_binds else achieved / HBM_PEAK_GBS,
+                    "floors_us_per_launch": {"hbm": hbm_floor_us, "mfma_bf16x3_executed": mfma_floor_us},
+                    "frac_hbm": achieved / HBM_PEAK_GBS, "achieved_gbs_algorithmic": achieved,
+                    "frac_mfma_executed": 3 * tf / BF16_MFMA_PEAK_TFLOPS, "executed_mfma_tflops": 3 * tf, "algorithmic_tflops": tf,
+                    "traffic": tr.get("traffic_bytes_per_launch"), "traffic_scope": tr.get("scope"),
+                    "traffic_source": tr.get("source", "committed PMC pass (profiles/), NOT measured in this run"),
                     "launches": n, "avg_launch_us": 1e3 * ms / n, "blocks_per_launch": nb, "avg_us_per_block": 1e3 * ms / n / nb,
-                    "algorithmic_mbytes_per_launch": nbytes / n / 1e6, "algorithmic_mbytes_per_block": nbytes / n / nb / 1e6,
-                    "algorithmic_tflops": tf, "executed_mfma_tflops": 3 * tf, "frac_of_bf16_mfma_peak_executed": 3 * tf / BF16_MFMA_PEAK_TFLOPS}
+                    "algorithmic_mbytes_per_launch": nbytes / n / 1e6, "algorithmic_mbytes_per_block": nbytes / n / nb / 1e6}
 
-        pick = {"conv3_1x1": hbm_roofline, "tail_fused": tail_roofline, "chain_fused": chain_roofline}
+        def rows1_roofline(n, ms, flops, nbytes):
+            return two_floor("k_dense (shared-weight 1x1 over packed pixel rows: conv1 / conv3 / projection shortcuts / RegNet a, c / "
+                             "token-skip linears; bf16x3, averaged over all such launches of a step)", n, ms, flops, nbytes, 3.0 if mode != "fp32" else 16.0)
+
+        def grouped_roofline(n, ms, flops, nbytes):
+            return two_floor("k_grouped16_img (LAD-RegNet conv b: grouped 3x3, 16 channels per group, whole kept images staged in LDS, bf16x3)",
+                             n, ms, flops, nbytes, 3.0 * 10.0 / 9.0)   # five K steps of two taps for nine taps
+
+        pick = {"conv3_1x1": hbm_roofline, "tail_fused": tail_roofline, "chain_fused": chain_roofline, "rows_1x1": rows1_roofline,
+                "grouped16_img": grouped_roofline}
         objs = {k: pick.get(k, mfma_roofline)(*v) for k, v in agg.items()}
         if "rows_3x3" in objs:
             objs["rows_3x3"]["kernel"] = ("k_dense<.., T9> (3x3 conv over packed active rows through the neighbour table, shared weights, bf16x3)"
@@ -607,6 +746,26 @@ def main():
         ops.set_math_mode(args.math)
         out = step()   # leave the modules' last_*_mask in the headline mode for the same-mask parity leg below
         torch.cuda.synchronize()
+    if rank == 0 and world == 1 and not args.no_legs and not args.graph and (wl["p_channel"] is not None or wl["p_spatial"] is not None):
+        # the SAME kernels with every unit kept (maskers recalibrated to keep 1.0): what the dynamic masks buy on this implementation
+        try:
+            calibrate_maskers(model, x, 1.0 if wl["p_channel"] is not None else None, 1.0 if wl["p_spatial"] is not None else None)
+            for _ in range(2):
+                out1 = step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                out1 = step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 4
+            result["same_kernels_keep_1.0"] = {"value": args.batch / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt,
+                                               "mean_block_flops_ratio": round(out1[5].float().mean().item(), 4),
+                                               "realised_speedup_of_the_masks": 1e3 * dt / result["ms_per_step"]}
+        except Exception as e:   # informative only
+            result["same_kernels_keep_1.0"] = {"error": repr(e)[:200]}
+        model.load_state_dict({k: v.to(dev) for k, v in calibrated_sd.items()})
+        out = step()
+        torch.cuda.synchronize()
     if rank == 0 and world == 1:
         from oracle import torch_ref as TR
         if "arch" in wl:
@@ -646,6 +805,10 @@ def main():
                     result["masker_decision_audit"] = audit_masker_decisions(model, refg, x, ops, args.math)
                 except Exception as e:   # informative only
                     result["masker_decision_audit"] = {"error": repr(e)[:200]}
+                try:
+                    result["masker_decision_audit"]["free_running"] = free_running_decisions(model, refg, x, ops, args.math)
+                except Exception as e:   # informative only
+                    result["masker_decision_audit"]["free_running"] = {"error": repr(e)[:200]}
                 ref = ref.cpu()
             except Exception as e:  # the baseline is informative only
                 result["dense_emulation_gpu"] = {"error": repr(e)[:200]}
@@ -697,6 +860,9 @@ def main():
                 if "realised_speedup_fp32_mode" in result:   # the predictor models fp32 FMA lanes: the like-for-like comparison
                     result["realised_over_predicted"]["math_fp32"] = result["realised_speedup_fp32_mode"] / best
                 result["realised_over_predicted"]["predicted"] = best
+                k1 = result.get("same_kernels_keep_1.0", {})
+                if "realised_speedup_of_the_masks" in k1:   # static baseline = the same kernels with nothing skipped (not eager PyTorch)
+                    result["realised_over_predicted"]["vs_same_kernels_keep_1.0"] = k1["realised_speedup_of_the_masks"] / best
     if rank == 0 and args.workload == "channel":
         # the MI355X-native latency model of THIS implementation (laudnet_amd/predictor.py, calibrated on profiles/r02_density_sweep.jsonl):
         # predicted step time at the keep probability of this run, and its predicted speedup over the same kernels at density 1

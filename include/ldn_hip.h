@@ -148,6 +148,15 @@ int ldn_channel_masker(const float* x, int B, int HW, int C, const float* w1, co
                        int gap_splits, void* stream);
 size_t ldn_channel_masker_workspace_bytes(int B, int HW, int C);
 
+/* ---- a7/a8: the FLOPs bookkeeping of a whole forward in one launch (laud_resnet.py:112-147 per block -- sparse_flops, dense_flops,
+ * flops_perc -- and :321-356 for the static stem / pool / classifier terms).  For block j (n_blocks of them):
+ *   (s3, s2, s1, cs) = st_in[j][0..st_cols-1] if st_in != NULL (st_cols 3: cs = 1), else (1, 1, 1, 1);
+ *   cs = sum_b cnt[j][b] / denom[j] where denom[j] > 0   (channel-mode blocks: cnt = ch_cnt [n_blocks][B], denom = B * width);
+ *   sparse = t0 + t1 cs s1 + t2 cs^2 s2 + t3 cs s3 + t4 with terms[j] = (masker, conv1, conv2, conv3, downsample) FLOPs (fp64);
+ *   perc[j] = sparse / (t0 + .. + t4);  flops[0] = sum_j sparse + static_flops;  st_out[j] = (s3, s2, s1, cs). */
+int ldn_forward_stats(const int32_t* cnt, int B, const float* denom, const float* st_in, int st_cols, const double* terms,
+                      double static_flops, int n_blocks, float* st_out, float* perc, float* flops, void* stream);
+
 /* ---- a7 (channel mode): per-image channel-subset convolution --------------------------------
  * (laud_resnet.py:115-144 with apply_channel_mask, models/utils.py:18-25; also the plain dense
  * NHWC 1x1/3x3 conv when k_idx==n_idx==NULL, used for the downsample branch :138-141)

@@ -32,6 +32,7 @@ SIGNATURES = {
     "ldn_channel_masker_splits": ([_I], _I),
     "ldn_channel_masker": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P], _I),
     "ldn_channel_masker_workspace_bytes": ([_I, _I, _I], C.c_size_t),
+    "ldn_forward_stats": ([_P, _I, _P, _P, _I, _P, C.c_double, _I, _P, _P, _P, _P], _I),
     "ldn_conv_packed": ([_P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P,
                          _I, _P, _I, _P, _P, _I, _P, _I, _I, _P], _I),
     "ldn_grouped_conv3x3_rows": ([_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P], _I),

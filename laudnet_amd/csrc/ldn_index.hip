@@ -859,6 +859,62 @@ extern "C" int ldn_scatter_add_relu(const float* packed, int ld_packed, const in
     return LDN_OK;
 }
 
+namespace ldn {
+// FLOPs bookkeeping of a whole forward in ONE launch (laud_resnet.py:112-147 per block, :321-356 for the static parts): per block j
+//   sparse_j = t[j][0] + t[j][1] cs s1 + t[j][2] cs^2 s2 + t[j][3] cs s3 + t[j][4],   perc_j = sparse_j / sum_i t[j][i],
+//   flops = sum_j sparse_j + static          (fp64 inside, as laudnet_amd's flops_from_sparsities; summed in block order)
+// with (s3, s2, s1, cs) = st_in[j] where given, and cs = sum_b cnt[j][b] / denom[j] for channel-mode blocks (denom[j] > 0).
+__global__ __launch_bounds__(256) void k_forward_stats(const int32_t* cnt, int B, const float* denom, const float* st_in, int st_cols,
+                                                       const double* terms, double static_flops, int n, float* st_out, float* perc,
+                                                       float* flops) {
+    __shared__ double s_sparse[512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = wave; j < n; j += 4) {          // one wave per block
+        float s3 = 1.f, s2 = 1.f, s1 = 1.f, cs = 1.f;
+        if (st_in) {
+            s3 = st_in[j * st_cols]; s2 = st_in[j * st_cols + 1]; s1 = st_in[j * st_cols + 2];
+            if (st_cols > 3) cs = st_in[j * st_cols + 3];
+        }
+        if (cnt && denom && denom[j] > 0.f) {
+            long acc = 0;                        // integer sum: exact, order-free
+            for (int b = lane; b < B; b += 64) acc += cnt[(size_t)j * B + b];
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            cs = (float)acc / denom[j];          // = torch: cnt.sum().float() / denom  (sum exact in int64, one fp32 division)
+        }
+        if (lane == 0) {
+            const double* t = terms + (size_t)j * 5;
+            const double dcs = (double)cs;
+            double sp = t[0] + t[1] * dcs * (double)s1;
+            sp = sp + t[2] * (dcs * dcs) * (double)s2;
+            sp = sp + t[3] * dcs * (double)s3;
+            sp = sp + t[4];
+            const double tot = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
+            s_sparse[j] = sp;
+            perc[j] = (float)(sp / tot);
+            st_out[j * 4] = s3; st_out[j * 4 + 1] = s2; st_out[j * 4 + 2] = s1; st_out[j * 4 + 3] = cs;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double f = 0.0;
+        for (int j = 0; j < n; ++j) f += s_sparse[j];
+        flops[0] = (float)(f + static_flops);
+    }
+}
+}  // namespace ldn
+
+extern "C" int ldn_forward_stats(const int32_t* cnt, int B, const float* denom, const float* st_in, int st_cols, const double* terms,
+                                 double static_flops, int n_blocks, float* st_out, float* perc, float* flops, void* stream) {
+    LDN_REQUIRE(terms && st_out && perc && flops, "ldn_forward_stats: null pointer");
+    LDN_REQUIRE(n_blocks > 0 && n_blocks <= 512, "ldn_forward_stats: 1 .. 512 blocks (got %d)", n_blocks);
+    LDN_REQUIRE((cnt == nullptr) == (denom == nullptr) && (!cnt || B > 0), "ldn_forward_stats: cnt and denom go together");
+    LDN_REQUIRE(!st_in || st_cols == 3 || st_cols == 4, "ldn_forward_stats: st_in has 3 or 4 columns");
+    hipLaunchKernelGGL(ldn::k_forward_stats, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), cnt, B, denom, st_in, st_cols, terms,
+                       static_flops, n_blocks, st_out, perc, flops);
+    LDN_CHECK_LAUNCH("k_forward_stats");
+    return LDN_OK;
+}
+
 extern "C" int ldn_channel_masker_splits(int HW) {
     int s = HW / 256;
     if (s < 1) s = 1;

@@ -874,9 +874,8 @@ class ResNet(nn.Module):
         in_shape = tuple(x.shape)
         x = self._stem_forward(x)
         x, stats, sizes = self._run_blocks(x)
-        st = self._stack_stats(stats, x.device)                    # [n_blocks, 4] = s3, s2, s1, cs
+        st, perc, flops = self._forward_stats(stats, in_shape, x.device)   # st [n_blocks, 4] = s3, s2, s1, cs
         s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
-        perc, flops = self.flops_from_sparsities(in_shape, s3, s2, s1, cs)
 
         x = self.avgpool(x)
         x = torch.flatten(x, 1)
@@ -1092,6 +1091,35 @@ class ResNet(nn.Module):
                 self._stem = (w, (bn.bias - bn.running_mean * scale).contiguous())
             self._stem_key = key
         return self._stem
+
+    use_fused_stats = os.environ.get("LDN_FUSED_STATS", "1") != "0"   # the bookkeeping of a forward as one launch (ldn_forward_stats)
+
+    def _forward_stats(self, stats, in_shape, dev):
+        """Per-block stats -> (st [n_blocks, 4], flops_perc [n_blocks], flops).  All blocks channel mode (they hand over their per-image
+        channel counts) or all blocks spatial / layer (three sparsities each): ONE stack + ONE launch (ldn_forward_stats; eager PyTorch
+        spent ~28 tiny kernels = 0.13 ms of a 13 ms step here).  Mixed models take the tensor-op path below."""
+        chan = [isinstance(s_, tuple) for s_ in stats]
+        if self.use_fused_stats and dev.type == "cuda" and (all(chan) or not any(chan)):
+            key = (str(dev), tuple(in_shape[1:]))
+            if getattr(self, "_terms_key", None) != key:
+                terms, static = self.flops_table(in_shape)
+                self._terms_key = key
+                self._terms = torch.tensor(terms, dtype=torch.float64, device=dev)
+                self._static_flops = float(static)
+            if all(chan):
+                same = len({tuple(s_[0].shape) for s_ in stats}) == 1
+                if same:
+                    dkey = (str(dev), tuple(s_[1] for s_ in stats))
+                    if getattr(self, "_denoms_key", None) != dkey:
+                        self._denoms_key = dkey
+                        self._denoms = torch.tensor(dkey[1], dtype=torch.float32, device=dev)
+                    cnt = torch.stack([s_[0] for s_ in stats])
+                    return ops.forward_stats(self._terms, self._static_flops, cnt=cnt, denom=self._denoms)
+            elif all((not isinstance(s_, tuple)) and s_.numel() == stats[0].numel() for s_ in stats):
+                return ops.forward_stats(self._terms, self._static_flops, st_in=torch.stack(stats))
+        st = self._stack_stats(stats, dev)
+        perc, flops = self.flops_from_sparsities(in_shape, st[:, 0], st[:, 1], st[:, 2], st[:, 3])
+        return st, perc, flops
 
     def _stack_stats(self, stats, dev):
         """Per-block stats -> [n_blocks, 4].  Channel-mode blocks hand over (per-image channel counts, B * width):

@@ -175,6 +175,29 @@ def scatter_add_relu(packed, rows, identity2d, out2d=None, count=None, cap=None)
     return out2d
 
 
+def forward_stats(terms, static_flops, *, cnt=None, denom=None, st_in=None):
+    """The FLOPs bookkeeping of a forward in one launch (see ldn_forward_stats).  terms [n,5] float64 (device); cnt [n,B] int32 +
+    denom [n] float32 (channel-mode blocks: cs = cnt.sum() / denom where denom > 0) and / or st_in [n,3|4] float32.
+    Returns (st [n,4] = s3, s2, s1, cs; perc [n]; flops 0-dim)."""
+    L.require_device(terms, cnt, denom, st_in)
+    lib = L.load()
+    n = terms.shape[0]
+    dev = terms.device
+    if terms.dtype != torch.float64 or tuple(terms.shape) != (n, 5) or not terms.is_contiguous():
+        raise L.LdnError("forward_stats: terms must be a contiguous float64 [n, 5] tensor")
+    if cnt is not None and (tuple(cnt.shape[:1]) != (n,) or cnt.dim() != 2 or denom is None or tuple(denom.shape) != (n,)):
+        raise L.LdnError("forward_stats: cnt must be [n, B] with denom [n]")
+    if st_in is not None and (st_in.dim() != 2 or st_in.shape[0] != n or st_in.shape[1] not in (3, 4)):
+        raise L.LdnError("forward_stats: st_in must be [n, 3] or [n, 4]")
+    st = torch.empty(n, 4, device=dev, dtype=torch.float32)
+    perc = torch.empty(n, device=dev, dtype=torch.float32)
+    flops = torch.empty((), device=dev, dtype=torch.float32)
+    L.check(lib.ldn_forward_stats(L.ptr(_i32c(cnt, "cnt")), cnt.shape[1] if cnt is not None else 0, L.ptr(_f32c(denom, "denom")),
+                                  L.ptr(_f32c(st_in, "st_in")), st_in.shape[1] if st_in is not None else 0, L.ptr(terms),
+                                  float(static_flops), n, L.ptr(st), L.ptr(perc), L.ptr(flops), L.stream_ptr(terms)), "ldn_forward_stats")
+    return st, perc, flops
+
+
 # ---------------------------------------------------------------------------------------- a7 rows
 _SPLIT_CACHE = {}   # (data_ptr, _version, shape) of an fp32 weight -> its pre-split n-major copy (ldn_conv_rows_split)
 DENSE_TAPS = tuple(int(t) for t in os.environ.get("LDN_DENSE_TAPS", "1,9").split(","))   # tuning: "1,9" sends the packed-row 3x3 to k_dense too

@@ -128,7 +128,7 @@ def test_regnet_state_dict_surface_matches_reference():
 
 # ---- header <-> ctypes SIGNATURES <-> INTEGRATION.md stub, argument by argument ----------------------------------------------
 def _header_prototypes():
-    """name -> list of argument classes ('P' pointer, 'I' int, 'F' float, 'Z' size_t) parsed from include/ldn_hip.h."""
+    """name -> list of argument classes ('P' pointer, 'I' int, 'F' float, 'D' double, 'Z' size_t) parsed from include/ldn_hip.h."""
     text = open(os.path.join(ROOT, "include", "ldn_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
@@ -143,6 +143,8 @@ def _header_prototypes():
                     kinds.append("P")
                 elif re.match(r"(const )?float\b", a):
                     kinds.append("F")
+                elif re.match(r"(const )?double\b", a):
+                    kinds.append("D")
                 elif re.match(r"(const )?size_t\b", a):
                     kinds.append("Z")
                 elif re.match(r"(const )?(int|int32_t|unsigned)\b", a):
@@ -158,6 +160,8 @@ def _kind(ct):
         return "I"
     if ct is ctypes.c_float:
         return "F"
+    if ct is ctypes.c_double:
+        return "D"
     if ct is ctypes.c_size_t:
         return "Z"
     if ct is ctypes.c_void_p or ct is ctypes.c_char_p or (isinstance(ct, type) and issubclass(ct, ctypes._Pointer)):

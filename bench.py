@@ -459,6 +459,9 @@ def main():
                     "replay as the extra leg `hipgraph_replay`)")
     ap.add_argument("--keep", type=float, default=None, help="keep probability the maskers are calibrated to (default: the "
                     "workload's target-0.5 operating point: 0.62 for channel units, 0.5 for spatial / layer units)")
+    ap.add_argument("--target-flops", type=float, default=None, help="calibrate the keep probability by bisection until the module's mean "
+                    "FLOPs ratio reaches this value (default: 0.5 for --workload spatial, off otherwise: the other workloads' survey "
+                    "keep probabilities already realise 0.51-0.52)")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the MFMA convolutions (include/ldn_hip.h: ldn_set_math_mode); fp32 storage either way")
     args = ap.parse_args()
@@ -507,6 +510,22 @@ def main():
         wl = dict(wl, p_channel=args.keep if wl["p_channel"] is not None else None,
                   p_spatial=args.keep if wl["p_spatial"] is not None else None, name=wl["name"] + f" (keep {args.keep})")
     calibrate_maskers(model, x, wl["p_channel"], wl["p_spatial"])
+    keep_used = wl["p_channel"] if wl["p_channel"] is not None else wl["p_spatial"]
+    tf = args.target_flops if args.target_flops is not None else (0.5 if (args.workload == "spatial" and args.keep is None) else None)
+    if tf is not None:
+        # "target-0.5" means the module-reported mean FLOPs ratio (laud_resnet.py:146), not the keep probability: a kept patch drags the
+        # dilated conv1 region along (mask1), so keep 0.5 realises 0.59.  Bisect the keep probability the maskers are calibrated to.
+        lo, hi = 0.05, 1.0
+        for _ in range(12):
+            mid = 0.5 * (lo + hi)
+            calibrate_maskers(model, x, mid if wl["p_channel"] is not None else None, mid if wl["p_spatial"] is not None else None)
+            with torch.no_grad():
+                r = model(x, 1.0)[5].float().mean().item()
+            keep_used = mid
+            if abs(r - tf) < 0.002:
+                break
+            lo, hi = (mid, hi) if r < tf else (lo, mid)
+        wl = dict(wl, name=wl["name"] + f" (keep {keep_used:.3f} -> FLOPs ratio {r:.3f})")
     calibrated_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
     graphed = None
@@ -595,6 +614,7 @@ def main():
                    "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                    "parallelism": f"dp{world} (batch shards, all-gather logits + all-reduce stats over RCCL)",
                    "mean_block_flops_ratio": round(flops_perc, 4), "module_macs_per_image": flops_per_img,
+                   "keep_probability_calibrated_to": round(float(keep_used), 4),
                    "launch": "hipGraph replay" if args.graph else "eager",
                    "math_mode": args.math + (" (per-call argument of the C ABI; fp32 storage; the fp32-MFMA figure of the same "
                                              "workload is `fp32_mfma_mode`)" if args.math != "fp32" else ""),

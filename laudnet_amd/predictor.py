@@ -35,7 +35,9 @@ import os
 from dataclasses import dataclass, field
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CALIBRATION = os.path.join(ROOT, "profiles", "r02_predictor_calibration.json")
+CALIBRATION = os.path.join(ROOT, "profiles", "r03_predictor_calibration.json")
+if not os.path.exists(CALIBRATION):
+    CALIBRATION = os.path.join(ROOT, "profiles", "r02_predictor_calibration.json")
 
 
 @dataclass
@@ -71,6 +73,14 @@ class Calibration:
     co_resident_gain: float = 1.3     # throughput gain of two co-resident workgroups per CU (64-wide layers) over one
     launch_s: float = 6.0e-6          # launch gap between dependent kernels
     fixed_s: float = 0.0              # residual per forward (bookkeeping kernels, pooling, classifier)
+    # -- packed-row workloads (spatial / layer / LAD-RegNet layer skip; round 3)
+    rows_cu_eff: float = 0.55         # k_dense: fraction of a CU's bf16 MFMA peak inside the K loop of a 256-row tile (executed FLOPs)
+    narrow_alpha: float = 0.5         # ... x (tile columns / 256) ** narrow_alpha on narrower tiles (fewer MFMAs per staged activation row)
+    tile_fixed_s: float = 8.0e-6      # prologue + epilogue of a tile's workgroup (tables, first chunk's round trip, transposes and stores)
+    rows_hbm_eff: float = 0.5         # fraction of 8 TB/s the row kernels' gathers / scatters reach together
+    idx_s: float = 30e-6              # index-list build per spatial block (two launches over the mask), beyond its bytes
+    grouped_eff: float = 0.5          # k_grouped16_img: fraction of 8 TB/s on its rows in + rows out
+    rows_fixed_s: float = 0.3e-3      # per-forward residual of the packed-row workloads (stem aside)
     source: str = "defaults"
 
     @staticmethod
@@ -199,17 +209,54 @@ class Predictor:
         t_b = (in_bytes + out_bytes + 4.0 * k * n) / (self.hw.hbm_bytes_per_s * self.cal.hbm_eff)
         return max(t_m, t_b) + self.cal.launch_s
 
+    def strided_rows_per_workgroup(self, b: BlockShape) -> tuple:
+        """(output rows per workgroup, workgroups per image, input pixels staged per K slice) of the fused tail on a stride-2 block:
+        the halo'd input region (2 R + 1 input rows) must fit ONE LDS slice slot beside the three W2 slots (csrc/ldn_tail.hip)."""
+        ns = b.width // 32
+        r = max(1, min(b.h, 256 // b.w))
+
+        def fits(rr):
+            region = min(b.stride * (rr - 1) + 3, b.h_in) * b.w_in
+            slice_b = -(-((-(-region // 8) * 8 + 1) * 128) // 1024) * 1024
+            return 1280 + slice_b + 3 * 16 * ns * 256 <= self.hw.lds_bytes
+        while r > 1 and not fits(r):
+            r -= 1
+        mb = math.ceil(b.h / r)
+        r = math.ceil(b.h / mb)
+        return r, mb, min(b.stride * (r - 1) + 3, b.h_in) * b.w_in
+
     def first_block(self, b: BlockShape, batch: int, density: float) -> float:
-        """The stage's first block (projection shortcut, stride 2 from stage 2 on): gathered conv1 / conv2 / conv3 on the general
-        kernels (their K and N shrink with the density) + the dense projection."""
+        """The stage's first block (projection shortcut; stride 2 from stage 2 on) as executed since round 3: the dense projection
+        (k_dense), conv1 on per-image workgroups at the INPUT resolution (k_head), conv2 (stride 2) -> conv3 + residual on per-image
+        workgroups whose halo'd input region is four times their output block (k_tail<NS, 2>)."""
         G = b.width // b.gran
         kp = expected_padded_channels(G, b.gran, density)
         kp2 = expected_padded_sq(G, b.gran, density)
+        k64 = expected_padded_channels(G, b.gran, density, 64)
         px_in, px = b.h_in * b.w_in, b.h * b.w
-        t = self.dense_rows(batch * px_in, b.cin, kp, 4.0 * batch * px_in * b.cin, 4.0 * batch * px_in * kp)          # conv1
-        t += self.dense_rows(batch * px, 9.0 * kp2 / max(kp, 1.0), kp, 4.0 * batch * px_in * kp, 4.0 * batch * px * kp)   # conv2
-        t += self.dense_rows(batch * px, kp, b.cout, 4.0 * batch * px * (kp + b.cout), 4.0 * batch * px * b.cout)         # conv3 + residual
-        t += self.dense_rows(batch * px, b.cin, b.cout, 4.0 * batch * px * b.cin, 4.0 * batch * px * b.cout)             # projection
+        act_rate = self.hw.hbm_bytes_per_s * self.cal.act_hbm_eff / self.hw.cus
+        cu = self.hw.cu_mfma_peak * self.cal.cu_mfma_eff
+        t = self.dense_rows(batch * px, b.cin, b.cout, 4.0 * batch * px * b.cin, 4.0 * batch * px * b.cout)             # projection
+        # conv1: workgroups of <= 256 input pixels
+        mb1 = math.ceil(px_in / 256)
+        p1 = px_in / mb1
+        t_wg = self.cal.phase_cost_s + 6.0 * 32 * math.ceil(p1 / 32) * b.cin * kp / cu + 4.0 * p1 * (b.cin + kp) / act_rate + \
+            4.0 * k64 * b.cin / self.cal.cu_l2_bytes_per_s
+        gain = self.cal.co_resident_gain if b.width <= 64 else 1.0
+        t += math.ceil(batch * mb1 / self.hw.cus) * t_wg / gain + self.cal.launch_s
+        # conv2 + conv3
+        if b.stride == 1:
+            r, mb, halo = self.rows_per_workgroup(b)
+            region = r * b.w * halo
+        else:
+            r, mb, region = self.strided_rows_per_workgroup(b)
+        p2 = r * b.w
+        flops = 6.0 * 32 * math.ceil(p2 / 32) * (9.0 * kp2 + kp * b.cout)
+        act = 4.0 * (region * kp + 2.0 * p2 * b.cout)
+        wts = 4.0 * (9.0 * kp2 + kp * b.cout)
+        t_wg = 2 * self.cal.phase_cost_s + flops / cu + act / act_rate + wts / self.cal.cu_l2_bytes_per_s
+        g2 = self.cal.co_resident_gain if (b.width <= 64 and b.stride == 1) else 1.0
+        t += math.ceil(batch * mb / self.hw.cus) * t_wg / g2 + self.cal.launch_s
         return t
 
     def dense_block(self, b: BlockShape, batch: int) -> float:
@@ -262,6 +309,108 @@ class Predictor:
         dyn = self.predict_resnet(batch, layers, density, gran, input_hw)
         sta = self.predict_resnet(batch, layers, (1.0,) * 4, gran, input_hw)
         return {"static_ms": sta["ms"], "dynamic_ms": dyn["ms"], "speedup": sta["ms"] / dyn["ms"]}
+
+    # ================================================================================================ packed-row workloads (round 3)
+    # spatial / layer modes of LAUD-ResNet and LAD-RegNet layer skip run on shared-weight row kernels over packed pixel lists
+    # (k_dense: 256-row x NT-column tiles, one workgroup per CU; k_grouped16_img).  A launch is priced as
+    #     t = max(rounds x t_tile, bytes / (8 TB/s x rows_hbm_eff)) + launch,     rounds = ceil(tiles / 256 CUs),
+    #     t_tile = tile_fixed + executed FLOPs of a tile / (a CU's MFMA peak x rows_cu_eff x (NT / 256) ** narrow_alpha)
+    # The ROUNDS are what the measurements show first: the layer workload's stage-3 3x3 (two 128-column tiles per 256 rows) takes
+    # 160 us at keep 0.62 (244 workgroups: one round) and 261 us at keep 0.75 (294: two rounds), profiles/r03_density_sweep_layer.jsonl
+    # and the kernel stats behind it (gpurun_out/r3h) -- +63 % time for +21 % rows.
+    def tile_columns(self, n: int, m_cap: float, taps: int = 1) -> int:
+        """The library's choice of the tile width (csrc/ldn_dense.hip: ldn_conv_rows_split)."""
+        mt = math.ceil(m_cap / 256.0)
+        if taps == 9:
+            return 128 if (n % 128 == 0 or n > 64) else 64
+        if n % 256 == 0 and mt * (n // 256) >= 384:
+            return 256
+        if n % 128 == 0:
+            return 128
+        if n <= 64:
+            return 64
+        if n % 160 == 0 or (n % 32 != 0 and n > 128):
+            return 160
+        return 128
+
+    def _rows(self, rows: float, k: float, n: int, in_bytes: float, out_bytes: float, m_cap: float, taps: int = 1) -> float:
+        if rows <= 0:
+            return self.cal.launch_s
+        nt = self.tile_columns(n, m_cap, taps)
+        tiles = math.ceil(rows / 256.0) * math.ceil(n / nt)
+        rounds = math.ceil(tiles / self.hw.cus)
+        eff = self.cal.rows_cu_eff * min(1.0, nt / 256.0) ** self.cal.narrow_alpha
+        t_tile = self.cal.tile_fixed_s + 6.0 * 256 * taps * k * nt / (self.hw.cu_mfma_peak * eff)
+        t_b = (in_bytes + out_bytes + 4.0 * taps * k * n) / (self.hw.hbm_bytes_per_s * self.cal.rows_hbm_eff)
+        return max(rounds * t_tile, t_b) + self.cal.launch_s
+
+    def spatial_block(self, b: BlockShape, batch: int, s3: float, s1: float, layer_mode: bool = False, prev_s3: float = 1.0) -> dict:
+        """One spatial- or layer-mode bottleneck: masker, index lists, conv1 on the dilated list (N1 rows), 3x3 on the output list
+        (N3 rows, nine gathered h1 rows each), conv3 + residual scatter; first blocks add the dense projection.
+        s3 / s1 = kept fraction of output / conv1 positions (the module's own sparsity outputs)."""
+        px_in, px = b.h_in * b.w_in, b.h * b.w
+        n1, n3 = s1 * batch * px_in, s3 * batch * px
+        cap1, cap3 = batch * px_in, batch * px
+        t = {}
+        # masker: one pass over x (layer mode: only the images the previous block updated are re-read, the rest are carried)
+        frac = prev_s3 if (layer_mode and not b.downsample and b.stride == 1) else 1.0
+        t["masker"] = 4.0 * frac * batch * px_in * b.cin / (self.hw.hbm_bytes_per_s * self.cal.hbm_eff) + 2 * self.cal.launch_s
+        t["index"] = (self.cal.launch_s if layer_mode else self.cal.idx_s + 2 * self.cal.launch_s) + 4.0 * 11 * n3 / (self.hw.hbm_bytes_per_s * self.cal.hbm_eff)
+        t["conv1"] = self._rows(n1, b.cin, b.width, 4.0 * n1 * b.cin, 4.0 * n1 * b.width, cap1)
+        t["conv2"] = self._rows(n3, b.width, b.width, 4.0 * n1 * b.width, 4.0 * n3 * b.width, cap3, taps=9)
+        t["conv3"] = self._rows(n3, b.width, b.cout, 4.0 * n3 * (b.width + b.cout), 4.0 * n3 * b.cout, cap3)
+        if b.downsample:
+            t["projection"] = self._rows(batch * px, b.cin, b.cout, 4.0 * batch * px * b.cin, 4.0 * batch * px * b.cout, cap3)
+        t["s"] = sum(t.values())
+        return t
+
+    def predict_rows_resnet(self, batch: int, s3, s1, layers=(3, 4, 23, 3), input_hw=(224, 224), layer_mode: bool = False) -> dict:
+        """Spatial- / layer-mode LAUD-ResNet forward from the per-block densities (lists over the blocks in execution order, as the
+        module returns them / bench.py logs them under `block_densities`)."""
+        blocks = resnet_blocks(layers, input_hw)
+        total = self.stem(batch, input_hw) + self.cal.rows_fixed_s
+        rows = [("stem", total)]
+        prev = 1.0
+        for i, (s, b) in enumerate(blocks):
+            r = self.spatial_block(b, batch, s3[i], s1[i], layer_mode, prev)
+            rows.append((f"layer{s + 1}.{i}", r["s"]))
+            total += r["s"]
+            prev = s3[i]
+        return {"s": total, "ms": 1e3 * total, "rows": rows}
+
+    def predict_regnet_layerskip(self, batch: int, keep, widths=(64, 144, 320, 784), depths=(1, 3, 8, 2), stem_width=32, input_hw=(224, 224),
+                                 group_width=16) -> dict:
+        """LAD-RegNet-Y layer skip (BASELINE config 4): per block a (1x1) on the kept images' rows, b (grouped 3x3, HBM-bound),
+        SE (three small launches over the kept rows), c (1x1) + residual; every stage's first block has stride 2 and a dense projection.
+        keep = per-block kept fraction of images (list) or one number."""
+        n_blocks = sum(depths)
+        keep = list(keep) if hasattr(keep, "__len__") else [float(keep)] * n_blocks
+        h, w = input_hw[0] // 2, input_hw[1] // 2
+        px_stem = batch * h * w
+        total = max(6.0 * px_stem * 48 * stem_width / (self.hw.mfma_peak * 0.1),
+                    4.0 * batch * (3 * input_hw[0] * input_hw[1] + stem_width * h * w) / (self.hw.hbm_bytes_per_s * self.cal.hbm_eff)) + self.cal.launch_s
+        total += self.cal.rows_fixed_s
+        rows = [("stem", total)]
+        cin, i = stem_width, 0
+        for s, (wd, d) in enumerate(zip(widths, depths)):
+            for j in range(d):
+                stride = 2 if j == 0 else 1
+                ho, wo = h // stride, w // stride
+                p = keep[i]
+                n1, n3 = p * batch * h * w, p * batch * ho * wo
+                mem = self.hw.hbm_bytes_per_s * self.cal.rows_hbm_eff
+                t = 4.0 * batch * h * w * cin / (self.hw.hbm_bytes_per_s * self.cal.hbm_eff) * (1.0 if j == 0 else keep[i - 1]) + 3 * self.cal.launch_s   # masker + index
+                t += self._rows(n1, cin, wd, 4.0 * n1 * cin, 4.0 * n1 * wd, batch * h * w)                              # a
+                t += 4.0 * (n1 + n3) * wd / (self.hw.hbm_bytes_per_s * self.cal.grouped_eff) + self.cal.launch_s       # b
+                t += 2.0 * 4.0 * n3 * wd / mem + 3 * self.cal.launch_s                                                 # SE: pool pass + scale pass
+                t += self._rows(n3, wd, wd, 4.0 * n3 * 2.0 * wd, 4.0 * n3 * wd, batch * ho * wo)                       # c + residual
+                if j == 0:
+                    t += self._rows(batch * ho * wo, cin, wd, 4.0 * batch * ho * wo * cin, 4.0 * batch * ho * wo * wd, batch * ho * wo)   # projection
+                rows.append((f"block{s + 1}-{j}", t))
+                total += t
+                cin, h, w = wd, ho, wo
+                i += 1
+        return {"s": total, "ms": 1e3 * total, "rows": rows}
 
     def best_channel_granularity(self, stage_shape: BlockShape, batch: int, density: float, candidates=(2, 4, 8, 16, 32)) -> dict:
         """Latency of a fused block per channel granularity at equal density: coarser groups waste less MFMA tile padding

@@ -227,9 +227,9 @@ class ResBottleneckBlock(_PrepCache):
         f = self.f
         if f.dyn_mode == "channel":
             return self._run_channel(x, inplace)
-        if f.masker_spatial.mask_channel_group != 1:
-            raise LdnError("HIP path: LAD-RegNet spatial masks with spatial_mask_channel_group > 1 are not built")
-        if f.dyn_mode == "both" or f.mask_size != 1:
+        if f.dyn_mode == "both" or f.mask_size != 1 or f.masker_spatial.mask_channel_group != 1:
+            # (several mask groups: every group of output channels has its own mask -- also with one patch per image, where a
+            # dropped image may keep the other half of its channels -- so a / b / SE run densely and c is scattered per group)
             return self._run_spatial_general(x, inplace, defer_stats)
         p = f.prepared(x.device)
         B, Cin, Hi, Wi = x.shape
@@ -292,9 +292,21 @@ class ResBottleneckBlock(_PrepCache):
             patch = f.forced_spatial_mask.to(device=dev, dtype=torch.float32).contiguous()
         else:
             patch = f.masker_spatial.decide(x)
-        ix = ops.mask_to_index(patch[:, 0].contiguous(), Ho, Wo, s)          # mask3 list (conv c) and the three sparsities
-        x2d = xn.reshape(B * Hi * Wi, Cin)
+        G = f.masker_spatial.mask_channel_group
         cout = p["wc"].shape[0]
+        # spatial_mask_channel_group > 1 (laud_regnet.py:145-147,172-177,198 with models/utils.py:27-33,74-89): group g of the OUTPUT
+        # channels of conv c has its own pixel mask; ExpandMask ORs the groups, so the sparsities the reference reports for conv b / a
+        # are those of the UNION of the group masks, the one of conv c is the mean over all group masks.
+        union = patch[:, 0] if G == 1 else patch.amax(dim=1)
+        ix = ops.mask_to_index(union.contiguous(), Ho, Wo, s)                # union list and the three sparsities
+        if G == 1:
+            groups = [(ix, slice(0, cout))]
+        else:
+            if cout % (4 * G) != 0:
+                raise LdnError("HIP path: spatial_mask_channel_group must divide the output channels into multiples of 4")
+            groups = [(ops.mask_to_index(patch[:, g].contiguous(), Ho, Wo, s), slice(g * (cout // G), (g + 1) * (cout // G))) for g in range(G)]
+            ix.stats = torch.cat((patch.mean().reshape(1), ix.stats[1:]))
+        x2d = xn.reshape(B * Hi * Wi, Cin)
         if both:
             if w_b % 8 != 0:
                 raise LdnError("HIP path: LAD-RegNet 'both' mode needs a bottleneck width that is a multiple of 8")
@@ -317,21 +329,26 @@ class ResBottleneckBlock(_PrepCache):
         if self.proj is not None:
             wp, sp, tp = self._proj(dev)
             out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
-            ops.conv_rows(x2d, wp, sp, tp, out2d, a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, s, dev), taps=1, m_cap=ix.cap3, relu=2,
-                          relu_if_neg=ix.pos3)
+            ds_rows = self._ds_rows(B, Hi, Wi, Ho, Wo, s, dev)
+            for ig, cs_ in groups:   # ReLU directly where the (pixel, group) is inactive: no branch output is added there
+                ops.conv_rows(x2d, wp[cs_], sp[cs_], tp[cs_], out2d[:, cs_], a_rows=ds_rows, taps=1, m_cap=ix.cap3, relu=2,
+                              relu_if_neg=ig.pos3)
             resid = out2d
         elif inplace:
             resid = out2d = x2d
         else:
             resid, out2d = x2d, torch.relu(x2d)
-        if both:   # c: gathered input channels (per image) x packed active pixels
-            ops.conv_packed(h_b2d, p["wc_k"], p["sc"], p["tc"], out2d, B=B, row_prefix=ix.pre3, m_cap=Ho * Wo, a_map=ix.idx3, taps=1,
-                            out_map=ix.idx3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual2d=resid)
+        if both:   # c: gathered input channels (per image) x packed active pixels (per output-channel group)
+            for g, (ig, cs_) in enumerate(groups):
+                wck = p["wc_k"] if G == 1 else p.setdefault(f"wc_k_grp{g}of{G}", p["wc_k"][:, :, cs_].contiguous())
+                ops.conv_packed(h_b2d, wck, p["sc"][cs_], p["tc"][cs_], out2d[:, cs_], B=B, row_prefix=ig.pre3, m_cap=Ho * Wo, a_map=ig.idx3,
+                                taps=1, out_map=ig.idx3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual2d=resid[:, cs_])
             f.last_channel_mask = cmask
             cs = cmask.mean().reshape(1)
         else:
-            ops.conv_rows(h_b2d, p["wc"], p["sc"], p["tc"], out2d, a_rows=ix.idx3, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
-                          out_rows=ix.idx3, residual2d=resid)
+            for ig, cs_ in groups:
+                ops.conv_rows(h_b2d, p["wc"][cs_], p["sc"][cs_], p["tc"][cs_], out2d[:, cs_], a_rows=ig.idx3, taps=1, m_count=ig.cnt[0:1],
+                              m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs_])
             cs = None if defer_stats else torch.ones(1, device=dev)
         f.last_spatial_mask = patch
         return ops.from_nhwc(out2d.view(B, Ho, Wo, cout)), (ix.stats if cs is None else torch.cat((ix.stats, cs)))

@@ -334,3 +334,32 @@ def test_layer_carry_is_bit_identical():
         assert torch.equal(outs[0][0], outs[1][0])
     finally:
         ops.set_math_mode("fp32")
+
+
+# ------------------------------------------------------------------ LAD-RegNet with two spatial mask groups per block
+REGNET_X = load_golden("regnet_extra.pt")
+
+
+@pytest.mark.parametrize("name", sorted(REGNET_X["cases"]))
+def test_regnet_two_spatial_mask_groups(math_mode, name):
+    """spatial_mask_channel_group = 2 (laud_regnet.py:145-147,172-177,198): conv c and the projection's ReLU follow a pixel mask per
+    half of the output channels; patch masks, one mask per image (layer skip with two groups) and `both` mode, against the
+    fixtures the reference generated with the same injected masks (make_regnet_groups_golden.py), and with its own maskers."""
+    from fill import seeded_bernoulli
+    fx = REGNET_X["cases"][name]
+    model, x = _hip_regnet(fx)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got[1:6], fx["masker_run"][1:6], atol=1e-6, what=name + " stats (same decisions)")
+    assert_tuple_close(got[:1], fx["masker_run"][:1], atol=logit_atol(math_mode, fx["masker_run"]), rtol=LOGIT_RTOL[math_mode], what=name + " logits")
+    for i, blk in enumerate(model.blocks()):
+        ms = blk.f.masker_spatial
+        blk.f.forced_spatial_mask = seeded_bernoulli((fx["batch"], ms.mask_channel_group, ms.mask_size, ms.mask_size), 0.5, fx["mask_seed"] + 2 * i)
+        if blk.f.masker_channel is not None:
+            blk.f.forced_channel_mask = seeded_bernoulli((fx["batch"], blk.f.masker_channel.channel_dyn_group), 0.62, fx["mask_seed"] + 2 * i + 1).to(DEV)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got[:1], fx["injected_run"][:1], atol=logit_atol(math_mode, fx["injected_run"]), rtol=LOGIT_RTOL[math_mode], what=name + " injected logits")
+    assert_tuple_close(got[1:6], fx["injected_run"][1:6], atol=1e-6, what=name + " injected stats")
+    assert_tuple_close(got[6:], fx["injected_run"][6:], atol=0.0, rtol=1e-5, what=name + " injected flops")
+

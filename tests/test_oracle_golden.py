@@ -214,3 +214,26 @@ def test_regnet_injected_run(name):
     with torch.no_grad():
         got = model(x, 1.0)
     assert_tuple_close(got, fx["injected_run"], atol=2e-5, rtol=1e-5, what=name)
+
+
+# ---- LAD-RegNet with two spatial mask groups per block (reference-generated regnet_extra.pt, make_regnet_groups_golden.py)
+REGNET_X = load_golden("regnet_extra.pt")
+
+
+@pytest.mark.parametrize("name", sorted(REGNET_X["cases"]))
+def test_regnet_two_mask_groups(name):
+    fx = REGNET_X["cases"][name]
+    assert fx["kw"]["spatial_mask_channel_group"] == [2, 2, 2, 2]
+    model, x = _build_regnet(fx)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got, fx["masker_run"], atol=2e-5, rtol=1e-5, what=name + " masker run")
+    blocks = [(n, b.f) for n, b in model.blocks()]
+    masks = injected_masks_for(blocks, fx["batch"], fx["mask_seed"])
+    for bname, f in blocks:
+        f.forced_spatial_mask = masks[bname].get("spatial")
+        f.forced_channel_mask = masks[bname].get("channel")
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got, fx["injected_run"], atol=2e-5, rtol=1e-5, what=name + " injected run")
+

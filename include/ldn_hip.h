@@ -124,7 +124,9 @@ int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int taps, cons
  * taps == 9: a_rows is the [rows][9] neighbour table of ldn_mask_to_index.  shift_classes 16 + pix_map + geometry: the
  * border-class shift table of the channel algebra, as in ldn_conv_packed.  Two optional epilogue terms of the dense
  * execution of channel mode: post_sub [cout] is subtracted after the ReLU, chan_mask [B][cout] {0,1} multiplies
- * row r by the mask of image floor(dst(r) / rows_per_image) (apply_channel_mask, models/utils.py:18-25, fused). */
+ * row r by the mask of image floor(dst(r) / rows_per_image) (apply_channel_mask, models/utils.py:18-25, fused).
+ * relu == 3 (this entry point only): exact GELU 0.5 v (1 + erf(v / sqrt 2)) instead of the ReLU -- the fc1 -> GELU of a
+ * token-skipping transformer block (DyNetSimulator/adavit/simulate_adavit.py:136-150) without a pass over the hidden rows. */
 int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                         const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
                         const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr, float* out,

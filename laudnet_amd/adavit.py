@@ -5,7 +5,7 @@ The reference ships no model for this configuration, only the latency model of i
 MLP / residual updates on the selected tokens only.  This module executes that operator list on PACKED token lists with the
 kernels of libldn_hip.so: the keep mask becomes a row list (ldn_mask_to_index on a [B, L, 1] mask), the linears are the packed-row
 1x1 kernel (k_dense: gather rows in, scatter-add rows out, fused bias + residual), the attention is ldn_packed_mha (one workgroup
-per image and head over the image's kept tokens).  LayerNorm and GELU are library element-wise ops.  Parity is UNPINNED (there is
+per image and head over the image's kept tokens).  The GELU is an epilogue of fc1 (relu mode 3 of ldn_conv_rows_split); LayerNorm is a library op.  Parity is UNPINNED (there is
 nothing in the reference to pin it to): tests compare against oracle/adavit_ref.py, a dense masked restatement of the same operator
 list.  Inference only; no CPU fallback."""
 from __future__ import annotations
@@ -60,8 +60,7 @@ class TokenSkipBlock(nn.Module):
         ops.conv_rows(att, wp, None, bp, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d)
         xn = F.layer_norm(x2d, (self.dim,), self.norm2.weight, self.norm2.bias, self.norm2.eps)
         hid = torch.empty(rows, w1.shape[0], device=x2d.device, dtype=torch.float32)
-        ops.conv_rows(xn, w1, None, b1, hid, a_rows=tok_rows, taps=1, m_count=count, m_cap=rows, relu=0)
-        hid = F.gelu(hid)
+        ops.conv_rows(xn, w1, None, b1, hid, a_rows=tok_rows, taps=1, m_count=count, m_cap=rows, relu=3)   # fc1 + bias + GELU in the epilogue
         ops.conv_rows(hid, w2, None, b2, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d)
         return x2d
 

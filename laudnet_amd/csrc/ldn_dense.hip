@@ -325,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     int orw[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) orw[it] = s_orow[wave * 32 + trw + 8 * it];
+    const bool gelu = p.relu == 3;
     auto load_res = [&](int j, f32x4 (&res)[4], f32x4& sc, f32x4& sh, f32x4& ps) {
         const int cb = n0 + 32 * j + tc * 4;
         const bool cok = FULL || cb < p.cout;                    // (a ragged last subtile: columns beyond cout are neither read nor stored)
@@ -370,6 +371,10 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
             if (orw[it] & D_ROW_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+            }
+            if (gelu) {   // exact (erf) GELU of the token-skip MLP: the hidden activations never make a second trip through HBM
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = 0.5f * x[e] * (1.f + erff(x[e] * 0.70710678118654752f));
             }
             x = (x - ps) * cm[it];
             if (orw[it] >= 0 && cok)
@@ -430,7 +435,7 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
     LDN_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 4 == 0, "ldn_conv_rows_split: cin must be a multiple of 8 and cout of 4 (got %d, %d)", cin, cout);
     LDN_REQUIRE(lda % 4 == 0 && lda >= cin && ldo % 4 == 0 && ldo >= cout && (!residual || (ldr % 4 == 0 && ldr >= cout)),
                 "ldn_conv_rows_split: strides must be multiples of 4 and cover the row");
-    LDN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || relu_if_neg), "ldn_conv_rows_split: bad relu mode");
+    LDN_REQUIRE(relu >= 0 && relu <= 3 && (relu != 2 || relu_if_neg), "ldn_conv_rows_split: bad relu mode (0 none, 1 ReLU, 2 ReLU on the rows with relu_if_neg < 0, 3 GELU)");
     LDN_REQUIRE((uintptr_t)a % 16 == 0 && (uintptr_t)w_split % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 &&
                 (uintptr_t)shift % 16 == 0 && (uintptr_t)scale % 16 == 0, "ldn_conv_rows_split: pointers must be 16-byte aligned");
     LDN_REQUIRE(taps == 1 || (taps == 9 && a_rows), "ldn_conv_rows_split: taps must be 1, or 9 with a neighbour table");

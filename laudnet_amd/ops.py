@@ -242,8 +242,8 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
     dense_ok = (USE_DENSE_KERNEL and mode == "bf16x3" and taps in DENSE_TAPS and cin % DENSE_K_MULT == 0 and cout % DENSE_N_MULT == 0
                 and a2d.stride(0) >= cin)
     classes = 1 if shift.dim() == 1 else shift.shape[0]
-    if (post_sub is not None or chan_mask is not None or classes != 1) and not dense_ok:
-        raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table need the bf16x3 path (cin, cout multiples of 32)")
+    if (post_sub is not None or chan_mask is not None or classes != 1 or relu == 3) and not dense_ok:
+        raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table / the GELU epilogue need the bf16x3 path (cin, cout multiples of 32)")
     if dense_ok:
         hi, wi, ho, wo, stride = geom if geom is not None else (0, 0, 0, 0, 1)
         L.check(lib.ldn_conv_rows_split(L.ptr(_f32rows(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")), taps,

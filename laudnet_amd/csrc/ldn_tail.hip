@@ -88,6 +88,49 @@ __device__ __forceinline__ void split2(float v, __bf16& hi, __bf16& lo) {
 constexpr int T_KIDX_BYTES = 1280;        // int[W + 32] channel list (W <= 256)
 constexpr int T_W2_SLOTS = 3;
 
+// The MFMA section of one conv2 chunk (tap TR_'s h1 rows of slice slot HS_ x the staged W2 tile WS_): B fragment = h1 row of the tap
+// (per-lane LDS address), A = staged W2 rows; per n-subtile two K16 steps, the weight fragment of the second requested before the
+// MFMAs of the first (the schedule is pinned: left alone, hipcc hoists every fragment read of the chunk and spills).
+#define LDN_TAIL_CHUNK_MFMA(WS_, HS_, TR_) {                                                                  \
+            const unsigned char* ws = (WS_); \
+            const unsigned rbase = (unsigned)(TR_) * 128u, rx = ((unsigned)(TR_) >> 1) & 7u; \
+            bf16x8 bh[2], bl[2]; \
+    _Pragma("unroll") \
+            for (int half = 0; half < 2; ++half) { \
+                const unsigned sl = 2u * (2u * half + h); \
+                bh[half] = *reinterpret_cast<const bf16x8*>((HS_) + rbase + ((sl ^ rx) << 4)); \
+                bl[half] = *reinterpret_cast<const bf16x8*>((HS_) + rbase + (((sl + 1) ^ rx) << 4)); \
+            } \
+    _Pragma("unroll") \
+            for (int j = 0; j < NS; ++j) { \
+                if (j < nsub) { \
+                    u32x2 e0[4], e1[4]; \
+    _Pragma("unroll") \
+                    for (int q = 0; q < 4; ++q) e0[q] = *reinterpret_cast<const u32x2*>(ws + a_lane + q * W2_ROW + j * 256); \
+    _Pragma("unroll") \
+                    for (int q = 0; q < 4; ++q) e1[q] = *reinterpret_cast<const u32x2*>(ws + a_lane + (8 + q) * W2_ROW + j * 256); \
+                    { \
+                        const u32x4 ahu = {e0[0][0], e0[1][0], e0[2][0], e0[3][0]}; \
+                        const u32x4 alu = {e0[0][1], e0[1][1], e0[2][1], e0[3][1]}; \
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu); \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[j], 0, 0, 0); \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[j], 0, 0, 0); \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[j], 0, 0, 0); \
+                    } \
+                    { \
+                        const u32x4 ahu = {e1[0][0], e1[1][0], e1[2][0], e1[3][0]}; \
+                        const u32x4 alu = {e1[0][1], e1[1][1], e1[2][1], e1[3][1]}; \
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu); \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[j], 0, 0, 0); \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[j], 0, 0, 0); \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[j], 0, 0, 0); \
+                    } \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); \
+                } \
+            } \
+}
+
 // NS = W / 32 (maximum n-subtiles / K slices of an image): 2, 4 or 8;  ST = stride of the 3x3 (1 or 2: the first block of a stage,
 // laud_resnet.py:123 with stride 2 -- the block's halo'd input region then holds 2 R + 1 input rows for R output rows)
 template <int NS, int ST = 1>
@@ -96,7 +139,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     // NS == 2 (stage 1: 14 short blocks per image, all of them bound by the CU's memory pipe in their conv3 phase and idle on it in
     // their conv2 phase): ONE h1 slice slot and 128 registers, so that TWO workgroups fit a CU and overlap each other's phases.
     // ST == 2: the input region is four times the output block, one slice slot is all that fits.
-    constexpr int SLICE_BUFS = (NS == 2 || ST == 2) ? 1 : 2;
+    // ST == 2: the input region is four times the output block -- it is staged one PARITY PLANE at a time (the taps of a stride-2 3x3
+    // read one plane each: (even | odd input rows) x (even | odd input columns)), two plane slots.
+    constexpr int SLICE_BUFS = ST == 2 ? 2 : (NS == 2 ? 1 : 2);
     constexpr int W2_ROW = NS * 256;                  // bytes of one k-pair row of the staged W2 tile: W entries of 8 B
     constexpr int W2_SLOT = 16 * W2_ROW;              // 16 k-pairs = one K slice of 32
     constexpr int CW = NS == 8 ? 32 : 64;             // output channels per conv3 chunk
@@ -124,9 +169,24 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     const int rows = min(p.rows_per_blk, p.Ho - y0);
     const int npix = rows * p.Wo;                              // <= 256
     const int yin0 = max(ST * y0 - 1, 0), yin1 = min(ST * (y0 + rows - 1) + 1, p.Hi - 1);
-    const int NR = (yin1 - yin0 + 1) * p.Wi;                   // input pixels resident per slice
+    const int NR = (yin1 - yin0 + 1) * p.Wi;                   // input pixels resident per slice (stride 1)
     const int NRp = round_up(NR, 8);
-    const int ZR = NRp;                                        // index of the all-zero row of each slice slot
+    const int ZR = ST == 2 ? p.slice_bytes / 128 - 1 : NRp;    // index of the all-zero row of each slice slot (never touched by the DMA)
+    // stride 2: the four parity planes g = 2 (input row odd) + (input column odd) of the block's input region, in PLANE coordinates
+    // (input pixel (iy, ix) = plane pixel (iy >> 1, ix >> 1)); rows / columns that exist in the map and are read by some tap
+    int plo[4] = {0, 0, 0, 0}, pw[4] = {1, 1, 1, 1}, pn[4] = {0, 0, 0, 0}, clo[4] = {0, 0, 0, 0};
+    if constexpr (ST == 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int py = g >> 1, px = g & 1;
+            const int rlo = py ? max(y0 - 1, 0) : y0;
+            const int rhi = min(y0 + rows - 1, (p.Hi - 1 - py) >> 1);           // 2 pr + py <= Hi - 1
+            const int chi = min(p.Wo - 1, (p.Wi - 1 - px) >> 1);
+            plo[g] = rlo; clo[g] = 0;
+            pw[g] = max(chi + 1, 1);
+            pn[g] = (rhi >= rlo && chi >= 0 && p.Hi - 1 - py >= 0 && p.Wi - 1 - px >= 0) ? (rhi - rlo + 1) * (chi + 1) : 0;
+        }
+    }
     const long in_row0 = (long)b * p.Hi * p.Wi + (long)yin0 * p.Wi;     // first input pixel (flat) of the region
     const long out_row0 = (long)b * p.Ho * p.Wo + (long)y0 * p.Wo;      // first output pixel (flat) of the block
 
@@ -154,7 +214,12 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     for (int t = 0; t < 9; ++t) {
         const int iy = ST * oy + t / 3 - 1, ix = ST * ox + t % 3 - 1;
         const bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-        trow[t] = ok ? (iy - yin0) * p.Wi + ix : ZR;
+        if constexpr (ST == 2) {
+            const int g = (iy & 1) * 2 + (ix & 1);
+            trow[t] = ok ? ((iy >> 1) - plo[g]) * pw[g] + ((ix >> 1) - clo[g]) : ZR;   // row of the tap's plane slot
+        } else {
+            trow[t] = ok ? (iy - yin0) * p.Wi + ix : ZR;
+        }
     }
     // border class of the pixel for the shift table of the channel algebra: (top | bottom << 1) * 4 + (left | right << 1)
     // = which tap rows / columns fall outside the INPUT map
@@ -183,8 +248,17 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
         const int ch = 2 * v < Kb ? s_kidx[2 * v] : -1;
         npo[e] = ch >= 0 ? (long)(ch >> 1) * 16 : -1;
     }
-    auto dma_w2 = [&](int c) {
-        const int s = c / 9, t = c - 9 * s;
+    // stride 2: piece q (8 plane pixels) of parity plane g of K slice `slice` into plane slot `buf`
+    auto dma_plane = [&](int slice, int g, int buf, int q) {
+        const int r = q * 8 + (lane >> 3);
+        const int lslot = (lane & 7) ^ ((r >> 1) & 7);
+        const int pr = r / pw[g], pc = r - pr * pw[g];
+        const long pix = (long)b * p.Hi * p.Wi + (long)(2 * (plo[g] + pr) + (g >> 1)) * p.Wi + 2 * (clo[g] + pc) + (g & 1);
+        const unsigned char* src = r < pn[g] ? p.h1 + pix * p.h1_row_bytes + slice * 128 + lslot * 16
+                                             : reinterpret_cast<const unsigned char*>(g_tail_zero);
+        dma16(src, lds_h1 + buf * p.slice_bytes + q * 1024);
+    };
+    auto dma_w2x = [&](int c, int s, int t) {       // chunk c (W2 slot c % 3) = tap t of K slice s
         const unsigned slot = lds_w2 + (c % T_W2_SLOTS) * W2_SLOT;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -208,6 +282,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
             }
         }
     };
+    auto dma_w2 = [&](int c) { dma_w2x(c, c / 9, c % 9); };   // stride 1: taps in order
     auto wait_chunk = [&]() {   // everything but this wave's last n_w2 DMA instructions (= the W2 pieces of the NEXT chunk) has landed
         if (n_w2 == 1) wait_vm<1>();
         else if (n_w2 == 2) wait_vm<2>();
@@ -224,13 +299,57 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     const int nchunks = nsub * 9;
     const int nq = NRp / 8;                                     // DMA pieces per h1 slice (<= 72)
     const bool active = wave * 32 < npix;                       // waves beyond the block's pixels only stage and synchronise
+    // fragment addressing
+    const unsigned a_lane = (unsigned)(4 * h * W2_ROW + l31 * 8);          // A (weights): k-pair rows 4h .. 4h+3 of a K16 step
+    if constexpr (ST == 2) {
+        // ---- stride 2: per K slice the nine taps are walked PLANE BY PLANE -- (odd row, odd column): taps 0 2 6 8; (even, odd): 3 5;
+        // (odd, even): 1 7; (even, even): 4 -- so that only one parity plane of the slice (a quarter of the input region) is in LDS
+        // at a time: plane u + 1 is fetched into the other slot, spread over the chunks of plane u.  The sum over the taps of an
+        // output is the same set of products in a different order of the K axis (fp32 accumulation: results differ from the
+        // tap-ordered stride-1 form in the last bits only, like any change of the K order).
+        constexpr int ORD[4] = {3, 1, 2, 0};                    // plane g of position o in the walk
+        constexpr int NTP[4] = {4, 2, 2, 1};                    // taps per position
+        constexpr int TAPS[4][4] = {{0, 2, 6, 8}, {3, 5, 3, 3}, {1, 7, 1, 1}, {4, 4, 4, 4}};
+        auto tap_of = [&](int c) {                              // chunk c -> tap (c % 9 walks 0 2 6 8 | 3 5 | 1 7 | 4)
+            constexpr int SEQ[9] = {0, 2, 6, 8, 3, 5, 1, 7, 4};
+            return SEQ[c % 9];
+        };
+        if (nchunks > 0) {
+            for (int q = wave; q < (pn[3] + 7) / 8; q += 8) dma_plane(0, 3, 0, q);   // plane (slice 0, odd / odd) -> slot 0
+            dma_w2x(0, 0, tap_of(0));
+            dma_w2x(1, 0, tap_of(1));
+        }
+        TT(tr1)
+        int c = 0;
+        for (int s = 0; s < nsub; ++s) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int u = 4 * s + o;                        // plane counter: slot u & 1
+                const unsigned char* hs = s_h1 + (u & 1) * p.slice_bytes;
+                const int gn = ORD[(o + 1) & 3], sn = o == 3 ? s + 1 : s;      // the plane after this one
+                const int npn = sn < nsub ? (pn[gn] + 7) / 8 : 0;              // its DMA pieces
+#pragma unroll
+                for (int i = 0; i < NTP[o]; ++i) {
+                    TT(ta)
+                    wait_chunk();
+                    lds_barrier();     // chunk c and this plane are in LDS for every wave; every wave has left chunk c - 1 (and plane u - 1)
+                    TT(tb)
+                    TT_ADD(w2wait, ta, tb)
+                    // issue: this chunk's share of the next plane first, then the W2 tile of chunk c + 2 (the counted wait relies on the order)
+                    for (int q = i * 8 + wave; q < npn; q += 8 * NTP[o]) dma_plane(sn, gn, (u + 1) & 1, q);
+                    if (c + 2 < nchunks) dma_w2x(c + 2, (c + 2) / 9, tap_of(c + 2));
+                    else { for (int e = 0; e < n_w2; ++e) dma16(g_tail_zero, lds_w2 + ((c + 2) % T_W2_SLOTS) * W2_SLOT + (2 * wave) * W2_ROW); }
+                    if (active) LDN_TAIL_CHUNK_MFMA(s_w2 + (c % T_W2_SLOTS) * W2_SLOT, hs, trow[TAPS[o][i]])
+                    ++c;
+                }
+            }
+        }
+    } else {
     if (nchunks > 0) {
         for (int q = wave; q < nq; q += 8) dma_h1(0, q);        // slice 0
         dma_w2(0);
         dma_w2(1);                                              // nchunks >= 9
     }
-    // fragment addressing
-    const unsigned a_lane = (unsigned)(4 * h * W2_ROW + l31 * 8);          // A (weights): k-pair rows 4h .. 4h+3 of a K16 step
     TT(tr1)
     for (int s = 0; s < nsub; ++s) {
         const unsigned char* hs = s_h1 + (s % SLICE_BUFS) * p.slice_bytes;
@@ -261,51 +380,13 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
 #if LDN_TAIL_PRIO == 1
             __builtin_amdgcn_s_setprio(1);
 #endif
-            // compute chunk c: tap t of K slice s.  B fragment = h1 row of the tap (per-lane LDS address), A = staged W2 rows.
-            const unsigned char* ws = s_w2 + (t % T_W2_SLOTS) * W2_SLOT;
-            const unsigned rbase = (unsigned)trow[t] * 128u, rx = ((unsigned)trow[t] >> 1) & 7u;
-            bf16x8 bh[2], bl[2];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const unsigned sl = 2u * (2u * half + h);       // logical 16-byte slot of this lane's octet (hi); lo = sl + 1
-                bh[half] = *reinterpret_cast<const bf16x8*>(hs + rbase + ((sl ^ rx) << 4));
-                bl[half] = *reinterpret_cast<const bf16x8*>(hs + rbase + (((sl + 1) ^ rx) << 4));
-            }
-            // per n-subtile: two K16 steps; the weight fragment of the second is requested before the MFMAs of the first
-            // (the schedule is pinned: left alone, hipcc hoists every fragment read of the chunk and spills)
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                if (j < nsub) {
-                    u32x2 e0[4], e1[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) e0[q] = *reinterpret_cast<const u32x2*>(ws + a_lane + q * W2_ROW + j * 256);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) e1[q] = *reinterpret_cast<const u32x2*>(ws + a_lane + (8 + q) * W2_ROW + j * 256);
-                    {
-                        const u32x4 ahu = {e0[0][0], e0[1][0], e0[2][0], e0[3][0]};
-                        const u32x4 alu = {e0[0][1], e0[1][1], e0[2][1], e0[3][1]};
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[j], 0, 0, 0);
-                    }
-                    {
-                        const u32x4 ahu = {e1[0][0], e1[1][0], e1[2][0], e1[3][0]};
-                        const u32x4 alu = {e1[0][1], e1[1][1], e1[2][1], e1[3][1]};
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[j], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                }
-            }
+            LDN_TAIL_CHUNK_MFMA(s_w2 + (t % T_W2_SLOTS) * W2_SLOT, hs, trow[t])
 #if LDN_TAIL_PRIO == 1
             __builtin_amdgcn_s_setprio(0);
 #endif
         }
     }
+    }   // ST == 1
     wait_vm<0>();
     lds_barrier();         // every wave is out of the conv2 loop: the slice / W2 regions are free
     TT(tr2)
@@ -501,14 +582,18 @@ __global__ __launch_bounds__(512, ((NS == 2 && ST == 1) ? 4 : 2)) void k_tail(co
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_tail)
 
-// input pixels resident per slice for a block of R output rows (stride st, pad 1)
-static int tail_region_pixels(int R, int Hi, int Wi, int st) { return min(st * (R - 1) + 3, Hi) * Wi; }
+// pixels resident per slice slot for a block of R output rows: stride 1 -- the halo'd input region (R + 2 rows); stride 2 -- the
+// largest PARITY PLANE of the region ((R + 1) plane rows x Wo plane columns: the taps read one plane each)
+static int tail_region_pixels(int R, int Hi, int Wi, int st) {
+    if (st == 2) return min(R + 1, (Hi + 1) / 2) * ((Wi - 1) / 2 + 1);
+    return min(R + 2, Hi) * Wi;
+}
 
 // bytes of LDS of the conv2 phase for blocks of R output rows (NS = width / 32)
 static size_t tail_lds2(int R, int Hi, int Wi, int NS, int st) {
     const int nr = tail_region_pixels(R, Hi, Wi, st);
     const size_t slice = (size_t)round_up((round_up(nr, 8) + 1) * 128, 1024);
-    return (size_t)T_KIDX_BYTES + ((NS == 2 || st == 2) ? 1 : 2) * slice + (size_t)T_W2_SLOTS * 16 * NS * 256;
+    return (size_t)T_KIDX_BYTES + (st == 2 ? 2 : (NS == 2 ? 1 : 2)) * slice + (size_t)T_W2_SLOTS * 16 * NS * 256;
 }
 
 // output rows per workgroup: as many as 256 pixels, the 160 KiB of LDS and the 72-piece slice pipeline allow; 0 = the map does not fit
@@ -517,7 +602,7 @@ static int tail_rows_per_block(int Hi, int Wi, int NS, int st, int* mblocks) {
     int R = 256 / Wo;
     if (R < 1) return 0;
     if (R > Ho) R = Ho;
-    // (the single-slot forms fetch a slice with every wave at once: no 72-piece limit of the spread-out prefetch)
+    // (stride 1, two slots: a slice is prefetched one piece per wave and tap = at most 72 pieces; the other forms have no such limit)
     auto fits = [&](int r) {
         return tail_lds2(r, Hi, Wi, NS, st) <= 160 * 1024 && (st == 2 || NS == 2 || round_up(tail_region_pixels(r, Hi, Wi, st), 8) / 8 <= 72);
     };

@@ -211,14 +211,15 @@ class Predictor:
 
     def strided_rows_per_workgroup(self, b: BlockShape) -> tuple:
         """(output rows per workgroup, workgroups per image, input pixels staged per K slice) of the fused tail on a stride-2 block:
-        the halo'd input region (2 R + 1 input rows) must fit ONE LDS slice slot beside the three W2 slots (csrc/ldn_tail.hip)."""
+        the region is staged one parity plane at a time -- the largest plane ((R + 1) x Wo plane pixels) must fit each of the TWO LDS
+        slice slots beside the three W2 slots (csrc/ldn_tail.hip: tail_rows_per_block)."""
         ns = b.width // 32
         r = max(1, min(b.h, 256 // b.w))
 
         def fits(rr):
-            region = min(b.stride * (rr - 1) + 3, b.h_in) * b.w_in
-            slice_b = -(-((-(-region // 8) * 8 + 1) * 128) // 1024) * 1024
-            return 1280 + slice_b + 3 * 16 * ns * 256 <= self.hw.lds_bytes
+            plane = min(rr + 1, (b.h_in + 1) // 2) * b.w
+            slice_b = -(-((-(-plane // 8) * 8 + 1) * 128) // 1024) * 1024
+            return 1280 + 2 * slice_b + 3 * 16 * ns * 256 <= self.hw.lds_bytes
         while r > 1 and not fits(r):
             r -= 1
         mb = math.ceil(b.h / r)

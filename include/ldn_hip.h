@@ -126,12 +126,19 @@ int ldn_conv_rows(const float* a, int lda, const int32_t* a_rows, int taps, cons
  * execution of channel mode: post_sub [cout] is subtracted after the ReLU, chan_mask [B][cout] {0,1} multiplies
  * row r by the mask of image floor(dst(r) / rows_per_image) (apply_channel_mask, models/utils.py:18-25, fused).
  * relu == 3 (this entry point only): exact GELU 0.5 v (1 + erf(v / sqrt 2)) instead of the ReLU -- the fc1 -> GELU of a
- * token-skipping transformer block (DyNetSimulator/adavit/simulate_adavit.py:136-150) without a pass over the hidden rows. */
+ * token-skipping transformer block (DyNetSimulator/adavit/simulate_adavit.py:136-150) without a pass over the hidden rows.
+ * ln_stats / ln_c1 (optional, taps == 1): the LayerNorm in front of a token-skip linear (simulate_adavit.py:90-93,136-140) as an
+ * epilogue term -- LN(x) . w + b = rstd (x . w' - mean c1) + (w . beta + b) with w' = gamma * w (what w_split then holds),
+ * c1[n] = sum_k w'[n][k] (ln_c1 [cout]), {mean, rstd} of every SOURCE row in ln_stats [rows of a][2] (ldn_row_stats), and the
+ * constant in `shift`: the normalised rows never exist in memory. */
 int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                         const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
                         const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr, float* out,
                         int ldo, const float* post_sub, const float* chan_mask, int rows_per_image, int shift_classes,
-                        const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride, void* stream);
+                        const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride, const float* ln_stats,
+                        const float* ln_c1, void* stream);
+/* stats[r] = {mean, 1 / sqrt(biased variance + eps)} of row r of x [rows][ld >= C] (nn.LayerNorm's statistics), C % 4 == 0, C <= 1024 */
+int ldn_row_stats(const float* x, int ld, int rows, int C, float eps, float* stats, void* stream);
 
 /* ---- a2: Masker_channel_MLP.forward, eval branch (models/utils.py:113-131) + index build ----
  * x [B,HW,C] NHWC -> global average pool -> Linear(C,hidden)+ReLU+Linear(hidden,2G) (hidden>0)

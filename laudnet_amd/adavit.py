@@ -5,14 +5,13 @@ The reference ships no model for this configuration, only the latency model of i
 MLP / residual updates on the selected tokens only.  This module executes that operator list on PACKED token lists with the
 kernels of libldn_hip.so: the keep mask becomes a row list (ldn_mask_to_index on a [B, L, 1] mask), the linears are the packed-row
 1x1 kernel (k_dense: gather rows in, scatter-add rows out, fused bias + residual), the attention is ldn_packed_mha (one workgroup
-per image and head over the image's kept tokens).  The GELU is an epilogue of fc1 (relu mode 3 of ldn_conv_rows_split); LayerNorm is a library op.  Parity is UNPINNED (there is
+per image and head over the image's kept tokens).  LayerNorm and GELU are epilogue terms of the linears (ldn_row_stats + the ln_* / relu-mode-3 arguments of ldn_conv_rows_split).  Parity is UNPINNED (there is
 nothing in the reference to pin it to): tests compare against oracle/adavit_ref.py, a dense masked restatement of the same operator
 list.  Inference only; no CPU fallback."""
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from ._lib import LdnError
@@ -38,11 +37,23 @@ class TokenSkipBlock(nn.Module):
         self._w = None
 
     def _weights(self, dev):
+        """Linear weights as k_dense wants them ([out, 1, in] fp32).  The two LayerNorms are folded into the linears that follow them
+        (ldn_conv_rows_split: LN(x) . w + b = rstd (x . (gamma * w) - mean c1) + (w . beta + b)): qkv and fc1 carry gamma-scaled
+        weights, c1 = their row sums and the constant as bias; only the rows' {mean, rstd} are computed per call (ldn_row_stats)."""
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._w is None or self._w[0] != key:
-            f = lambda lin: (lin.weight.detach().float().reshape(lin.out_features, 1, lin.in_features).contiguous().to(dev),
-                             lin.bias.detach().float().contiguous().to(dev))
-            self._w = (key, f(self.qkv), f(self.proj), f(self.fc1), f(self.fc2))
+            with torch.no_grad():
+                def plain(lin):
+                    return (lin.weight.detach().float().reshape(lin.out_features, 1, lin.in_features).contiguous().to(dev),
+                            lin.bias.detach().float().contiguous().to(dev))
+
+                def after_ln(lin, ln):
+                    w = lin.weight.detach().double()
+                    g, be = ln.weight.detach().double(), ln.bias.detach().double()
+                    wg = w * g.view(1, -1)
+                    return (wg.float().reshape(lin.out_features, 1, lin.in_features).contiguous().to(dev),
+                            (w @ be + lin.bias.detach().double()).float().contiguous().to(dev), wg.sum(dim=1).float().contiguous().to(dev))
+                self._w = (key, after_ln(self.qkv, self.norm1), plain(self.proj), after_ln(self.fc1, self.norm2), plain(self.fc2))
         return self._w[1:]
 
     def run_packed(self, x2d, tok_rows, prefix, count, B, max_tokens):
@@ -51,16 +62,16 @@ class TokenSkipBlock(nn.Module):
             raise LdnError("laudnet_amd implements the eval-mode (inference) hot path only")
         if ops.get_math_mode() != "bf16x3":
             raise LdnError("TokenSkipBlock runs in the bf16x3 arithmetic mode (ops.set_math_mode('bf16x3'))")
-        (wq, bq), (wp, bp), (w1, b1), (w2, b2) = self._weights(x2d.device)
+        (wq, bq, cq), (wp, bp), (w1, b1, c1), (w2, b2) = self._weights(x2d.device)
         rows = x2d.shape[0]
-        xn = F.layer_norm(x2d, (self.dim,), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        st = ops.row_stats(x2d, self.norm1.eps)                                                 # {mean, rstd} of every token (norm1)
         qkv = torch.empty(rows, 3 * self.dim, device=x2d.device, dtype=torch.float32)
-        ops.conv_rows(xn, wq, None, bq, qkv, taps=1, m_cap=rows, relu=0)                       # q / k / v for every token
+        ops.conv_rows(x2d, wq, None, bq, qkv, taps=1, m_cap=rows, relu=0, ln_stats=st, ln_c1=cq)    # norm1 + q / k / v for every token
         att = ops.packed_mha(qkv, tok_rows, prefix, B, self.heads, max_tokens)                  # [capacity, dim], packed
         ops.conv_rows(att, wp, None, bp, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d)
-        xn = F.layer_norm(x2d, (self.dim,), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        st = ops.row_stats(x2d, self.norm2.eps)                                                 # norm2 (after the attention update)
         hid = torch.empty(rows, w1.shape[0], device=x2d.device, dtype=torch.float32)
-        ops.conv_rows(xn, w1, None, b1, hid, a_rows=tok_rows, taps=1, m_count=count, m_cap=rows, relu=3)   # fc1 + bias + GELU in the epilogue
+        ops.conv_rows(x2d, w1, None, b1, hid, a_rows=tok_rows, taps=1, m_count=count, m_cap=rows, relu=3, ln_stats=st, ln_c1=c1)   # norm2 + fc1 + GELU
         ops.conv_rows(hid, w2, None, b2, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d)
         return x2d
 

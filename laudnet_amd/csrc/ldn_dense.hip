@@ -29,6 +29,8 @@ struct DenseArgs {
     const float* post_sub;                            // optional [cout]: subtracted after the ReLU (channel algebra)
     const float* chmask; int rows_per_img;            // optional [B][cout] {0,1}: out *= chmask[dst / rows_per_img][n] (dense channel exec)
     int mtn, ntn;                                     // M tiles (of 256 rows), N tiles (of NT columns)
+    const float* ln_stats; const float* ln_c1;        // optional LayerNorm of the A rows as an epilogue term: [rows_a][2] = {mean, rstd} of
+                                                      // every SOURCE row, and c1[n] = sum_k w[n][k] (w carries the LayerNorm weight)
 };
 
 __device__ __attribute__((aligned(16))) float g_dense_zero[4] = {0.f, 0.f, 0.f, 0.f};
@@ -345,6 +347,17 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         load_res(j, res, sc, sh, ps);
         f32x4 cm[4];
         const bool cok = FULL || n0 + 32 * j + tc * 4 < p.cout;
+        // LayerNorm of the activation rows, applied AFTER the GEMM: LN(x) . w = rstd (x . w' - mean sum_k w'[k]) + const, w' = gamma * w
+        float2 lst[4];
+        f32x4 lc1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.ln_stats) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int ar = s_arow[wave * 32 + trw + 8 * it];
+                lst[it] = ar >= 0 ? *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)ar) : float2{0.f, 1.f};
+            }
+            if (cok) lc1 = *reinterpret_cast<const f32x4*>(p.ln_c1 + n0 + 32 * j + tc * 4);
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const float* src = (p.chmask && orw[it] >= 0 && cok) ? p.chmask + (size_t)((orw[it] & (D_ROW_RELU - 1)) / p.rows_per_img) * p.cout + n0 + 32 * j + tc * 4
@@ -367,6 +380,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
             const int row = trw + 8 * it;
             f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
             const f32x4 shr = (T9 && p.shift_classes > 1 && cok) ? *reinterpret_cast<const f32x4*>(p.shift + s_cls[wave * 32 + row] + n0 + 32 * j + tc * 4) : sh;
+            if (p.ln_stats) x = (x - lc1 * lst[it].x) * lst[it].y;
             x = x * sc + shr + res[it];
             if (orw[it] & D_ROW_RELU) {
 #pragma unroll
@@ -391,6 +405,38 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         r[0] = a_wait; r[1] = a_bar; r[2] = a_issue; r[3] = a_prep; r[4] = a_mfma; r[5] = d_loop - d_start; r[6] = dend - d_loop; r[7] = nchunks;
     }
 #endif
+}
+
+// LayerNorm statistics of the rows of a [rows, C] matrix: stats[r] = {mean, 1 / sqrt(var + eps)} (biased variance, as nn.LayerNorm),
+// one wave per row, the row held in registers (two passes over registers, one over memory).
+__global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, int ld, int rows, int C, float eps, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * ld;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < C ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * (size_t)r) = float2{mean, rsqrtf(q / (float)C + eps)};
 }
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_dense)
@@ -430,8 +476,10 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
                                    const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
                                    float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
                                    int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
-                                   void* stream) {
+                                   const float* ln_stats, const float* ln_c1, void* stream) {
     LDN_REQUIRE(a && w_split && shift && out, "ldn_conv_rows_split: null pointer");
+    LDN_REQUIRE((ln_stats == nullptr) == (ln_c1 == nullptr) && (!ln_stats || taps == 1), "ldn_conv_rows_split: ln_stats and ln_c1 go together (1x1 only)");
+    LDN_REQUIRE((uintptr_t)ln_stats % 8 == 0 && (uintptr_t)ln_c1 % 16 == 0, "ldn_conv_rows_split: ln_stats / ln_c1 must be 8 / 16-byte aligned");
     LDN_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 4 == 0, "ldn_conv_rows_split: cin must be a multiple of 8 and cout of 4 (got %d, %d)", cin, cout);
     LDN_REQUIRE(lda % 4 == 0 && lda >= cin && ldo % 4 == 0 && ldo >= cout && (!residual || (ldr % 4 == 0 && ldr >= cout)),
                 "ldn_conv_rows_split: strides must be multiples of 4 and cover the row");
@@ -446,7 +494,7 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
     if (m_cap <= 0) return LDN_OK;
     DenseArgs d{a, lda, a_rows, m_count, m_cap, static_cast<const unsigned char*>(w_split), cin, cout, scale, shift, relu,
                 relu_if_neg, out_rows, residual, ldr, out, ldo, taps, shift_classes, pix_map, Hi, Wi, Ho > 0 ? Ho : 1, Wo > 0 ? Wo : 1,
-                stride, post_sub, chan_mask, rows_per_image > 0 ? rows_per_image : 1, 0, 0};
+                stride, post_sub, chan_mask, rows_per_image > 0 ? rows_per_image : 1, 0, 0, ln_stats, ln_c1};
     hipStream_t st = static_cast<hipStream_t>(stream);
     // columns per workgroup: as wide as the layer allows (fewer passes over the activation rows) while the grid still fills the chip
     const int mt = ceil_div(m_cap, D_ROWS);
@@ -460,4 +508,14 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
     if (use5 && (cout % 160 == 0 || (cout % 32 != 0 && cout > 128))) return launch_dense<5, false>(d, st);
     if (cout % 32 != 0 && cout > 128 && cout <= 256) return launch_dense<8, false>(d, st);   // a ragged layer in ONE column tile (144, 168, 216 ...)
     return launch_dense<4, false>(d, st);
+}
+
+extern "C" int ldn_row_stats(const float* x, int ld, int rows, int C, float eps, float* stats, void* stream) {
+    LDN_REQUIRE(x && stats, "ldn_row_stats: null pointer");
+    LDN_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 1024 && ld >= C && ld % 4 == 0, "ldn_row_stats: C must be a multiple of 4, at most 1024 (got %d), ld >= C", C);
+    LDN_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)stats % 8 == 0, "ldn_row_stats: pointers must be 16 / 8-byte aligned");
+    if (rows == 0) return LDN_OK;
+    hipLaunchKernelGGL(ldn::k_row_stats, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, rows, C, eps, stats);
+    LDN_CHECK_LAUNCH("k_row_stats");
+    return LDN_OK;
 }

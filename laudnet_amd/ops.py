@@ -221,9 +221,18 @@ def split_rows_weight(w):
     return hit[0]
 
 
+def row_stats(x2d, eps=1e-5):
+    """LayerNorm statistics of the rows of x2d [rows, C]: [rows, 2] = {mean, 1 / sqrt(biased var + eps)} (see ldn_row_stats)."""
+    L.require_device(x2d)
+    st = torch.empty(x2d.shape[0], 2, device=x2d.device, dtype=torch.float32)
+    L.check(L.load().ldn_row_stats(L.ptr(_f32rows(x2d, "x")), x2d.stride(0), x2d.shape[0], x2d.shape[1], float(eps), L.ptr(st),
+                                   L.stream_ptr(x2d)), "ldn_row_stats")
+    return st
+
+
 def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None, m_cap=None, relu=1,
               relu_if_neg=None, out_rows=None, residual2d=None, math=None, post_sub=None, chan_mask=None, rows_per_image=0,
-              pix_map=None, geom=None):
+              pix_map=None, geom=None, ln_stats=None, ln_c1=None):
     """Packed-row convolution (see ldn_conv_rows).  a2d [rows,lda>=cin]; w [cout,taps,cin]; out2d [rows,ldo].
     In bf16x3 mode the 1x1 form runs on k_dense (ldn_conv_rows_split) with a cached pre-split copy of the weights;
     post_sub / chan_mask (dense execution of channel mode) exist on that kernel only."""
@@ -242,8 +251,8 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
     dense_ok = (USE_DENSE_KERNEL and mode == "bf16x3" and taps in DENSE_TAPS and cin % DENSE_K_MULT == 0 and cout % DENSE_N_MULT == 0
                 and a2d.stride(0) >= cin)
     classes = 1 if shift.dim() == 1 else shift.shape[0]
-    if (post_sub is not None or chan_mask is not None or classes != 1 or relu == 3) and not dense_ok:
-        raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table / the GELU epilogue need the bf16x3 path (cin, cout multiples of 32)")
+    if (post_sub is not None or chan_mask is not None or classes != 1 or relu == 3 or ln_stats is not None) and not dense_ok:
+        raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table / the GELU and LayerNorm epilogues need the bf16x3 path (cin, cout multiples of 32)")
     if dense_ok:
         hi, wi, ho, wo, stride = geom if geom is not None else (0, 0, 0, 0, 1)
         L.check(lib.ldn_conv_rows_split(L.ptr(_f32rows(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")), taps,
@@ -253,7 +262,8 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
                                         L.ptr(_f32rows(residual2d, "residual")), residual2d.stride(0) if residual2d is not None else 0,
                                         L.ptr(_f32rows(out2d, "out")), out2d.stride(0), L.ptr(_f32c(post_sub, "post_sub")),
                                         L.ptr(_f32c(chan_mask, "chan_mask")), rows_per_image, classes, L.ptr(_i32c(pix_map, "pix_map")),
-                                        hi, wi, ho, wo, stride, L.stream_ptr(out2d)), "ldn_conv_rows_split")
+                                        hi, wi, ho, wo, stride, L.ptr(_f32c(ln_stats, "ln_stats")), L.ptr(_f32c(ln_c1, "ln_c1")),
+                                        L.stream_ptr(out2d)), "ldn_conv_rows_split")
         return out2d
     L.check(lib.ldn_conv_rows(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")), taps,
                               L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(_f32c(w, "w")), cin, cout,

@@ -91,3 +91,36 @@ def test_token_skip_trunk_deit_s_shape():
     finally:
         ops.set_math_mode("fp32")
     assert (got - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("rows,cin,cout,gather", [(2000, 384, 1152, False), (1500, 384, 1536, True), (300, 64, 128, True)])
+def test_layernorm_and_gelu_as_epilogue_terms(rows, cin, cout, gather):
+    """LN(x) . w + b with the LayerNorm applied AFTER the GEMM (ldn_row_stats + ln_stats / ln_c1 of ldn_conv_rows_split), and the exact
+    GELU of relu mode 3, against torch's layer_norm -> linear -> gelu in fp64; rows with a large mean (cancellation in the folded
+    form) included."""
+    import torch.nn.functional as F
+    from laudnet_amd import ops, load_library
+    load_library()
+    ops.set_math_mode("bf16x3")
+    try:
+        x = seeded_randn((rows, cin), 11)
+        x[: rows // 4] += 3.0                                     # mean / std = 3: the folded form subtracts mean * c1 after the GEMM
+        g, be = seeded_randn((cin,), 12) * 0.2 + 1.0, seeded_randn((cin,), 13) * 0.1
+        w = seeded_randn((cout, cin), 14) * (1.0 / cin) ** 0.5
+        b = seeded_randn((cout,), 15) * 0.1
+        st = ops.row_stats(x.to(DEV), 1e-5)
+        xd = x.double()
+        mean, var = xd.mean(1), xd.var(1, unbiased=False)
+        assert torch.allclose(st[:, 0].cpu().double(), mean, atol=1e-5) and torch.allclose(st[:, 1].cpu().double(), (var + 1e-5).rsqrt(), rtol=1e-5)
+        wg = (w.double() * g.double().view(1, -1))
+        src = torch.randperm(rows, generator=torch.Generator().manual_seed(3))[: rows // 2].to(torch.int32) if gather else None
+        n = rows // 2 if gather else rows
+        out = torch.zeros(n, cout, device=DEV)
+        ops.conv_rows(x.to(DEV), wg.float().reshape(cout, 1, cin).contiguous().to(DEV), None, (w.double() @ be.double() + b.double()).float().to(DEV),
+                      out, a_rows=None if src is None else src.to(DEV), taps=1, m_cap=n, relu=3, ln_stats=st, ln_c1=wg.sum(1).float().to(DEV))
+        xs = xd if src is None else xd[src.long()]
+        want = F.gelu(F.linear(F.layer_norm(xs, (cin,), g.double(), be.double(), 1e-5), w.double(), b.double()))
+        err = (out.cpu().double() - want).abs().max().item()
+        assert err < 2e-4, err
+    finally:
+        ops.set_math_mode(None)

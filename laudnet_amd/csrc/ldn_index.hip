@@ -864,12 +864,12 @@ namespace ldn {
 //   sparse_j = t[j][0] + t[j][1] cs s1 + t[j][2] cs^2 s2 + t[j][3] cs s3 + t[j][4],   perc_j = sparse_j / sum_i t[j][i],
 //   flops = sum_j sparse_j + static          (fp64 inside, as laudnet_amd's flops_from_sparsities; summed in block order)
 // with (s3, s2, s1, cs) = st_in[j] where given, and cs = sum_b cnt[j][b] / denom[j] for channel-mode blocks (denom[j] > 0).
-__global__ __launch_bounds__(256) void k_forward_stats(const int32_t* cnt, int B, const float* denom, const float* st_in, int st_cols,
+__global__ __launch_bounds__(1024) void k_forward_stats(const int32_t* cnt, int B, const float* denom, const float* st_in, int st_cols,
                                                        const double* terms, double static_flops, int n, float* st_out, float* perc,
                                                        float* flops) {
     __shared__ double s_sparse[512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int j = wave; j < n; j += 4) {          // one wave per block
+    for (int j = wave; j < n; j += 16) {         // one wave per block (sixteen waves: the per-block chains of dependent loads overlap)
         float s3 = 1.f, s2 = 1.f, s1 = 1.f, cs = 1.f;
         if (st_in) {
             s3 = st_in[j * st_cols]; s2 = st_in[j * st_cols + 1]; s1 = st_in[j * st_cols + 2];
@@ -909,7 +909,7 @@ extern "C" int ldn_forward_stats(const int32_t* cnt, int B, const float* denom, 
     LDN_REQUIRE(n_blocks > 0 && n_blocks <= 512, "ldn_forward_stats: 1 .. 512 blocks (got %d)", n_blocks);
     LDN_REQUIRE((cnt == nullptr) == (denom == nullptr) && (!cnt || B > 0), "ldn_forward_stats: cnt and denom go together");
     LDN_REQUIRE(!st_in || st_cols == 3 || st_cols == 4, "ldn_forward_stats: st_in has 3 or 4 columns");
-    hipLaunchKernelGGL(ldn::k_forward_stats, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), cnt, B, denom, st_in, st_cols, terms,
+    hipLaunchKernelGGL(ldn::k_forward_stats, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), cnt, B, denom, st_in, st_cols, terms,
                        static_flops, n_blocks, st_out, perc, flops);
     LDN_CHECK_LAUNCH("k_forward_stats");
     return LDN_OK;

@@ -460,8 +460,9 @@ def main():
     ap.add_argument("--keep", type=float, default=None, help="keep probability the maskers are calibrated to (default: the "
                     "workload's target-0.5 operating point: 0.62 for channel units, 0.5 for spatial / layer units)")
     ap.add_argument("--target-flops", type=float, default=None, help="calibrate the keep probability by bisection until the module's mean "
-                    "FLOPs ratio reaches this value (default: 0.5 for --workload spatial, off otherwise: the other workloads' survey "
-                    "keep probabilities already realise 0.51-0.52)")
+                    "FLOPs ratio (laud_resnet.py:146) reaches this value; default 0.5 = the 'target-0.5' of the workloads (the reference "
+                    "trains towards that FLOPs ratio: utils/sparsity_loss_unify.py); --keep P fixes the keep probability instead "
+                    "(SURVEY 8d's p = 0.62 / 0.5 realise 0.513 / 0.59)")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the MFMA convolutions (include/ldn_hip.h: ldn_set_math_mode); fp32 storage either way")
     args = ap.parse_args()
@@ -511,10 +512,11 @@ def main():
                   p_spatial=args.keep if wl["p_spatial"] is not None else None, name=wl["name"] + f" (keep {args.keep})")
     calibrate_maskers(model, x, wl["p_channel"], wl["p_spatial"])
     keep_used = wl["p_channel"] if wl["p_channel"] is not None else wl["p_spatial"]
-    tf = args.target_flops if args.target_flops is not None else (0.5 if (args.workload == "spatial" and args.keep is None) else None)
+    tf = args.target_flops if args.target_flops is not None else (0.5 if args.keep is None else None)
     if tf is not None:
         # "target-0.5" means the module-reported mean FLOPs ratio (laud_resnet.py:146), not the keep probability: a kept patch drags the
-        # dilated conv1 region along (mask1), so keep 0.5 realises 0.59.  Bisect the keep probability the maskers are calibrated to.
+        # dilated conv1 region along (mask1), so keep 0.5 realises 0.59 in spatial mode; channel keep 0.62 realises 0.513.  Bisect the
+        # keep probability the maskers are calibrated to until the ratio is 0.500 +- 0.002.
         lo, hi = 0.05, 1.0
         for _ in range(12):
             mid = 0.5 * (lo + hi)
@@ -898,8 +900,7 @@ def main():
             P = Predictor()
             bd = block_densities
             if args.workload == "channel":
-                keep = args.keep if args.keep is not None else wl["p_channel"]
-                dyn = P.predict_resnet(args.batch, density=(keep,) * 4)["ms"]
+                dyn = P.predict_resnet(args.batch, density=(float(keep_used),) * 4)["ms"]
                 sta = P.predict_resnet(args.batch, density=(1.0,) * 4)["ms"]
             elif args.workload == "regnet":
                 dyn = P.predict_regnet_layerskip(args.batch, bd["s3"])["ms"]

@@ -64,10 +64,13 @@ int ldn_default_math_mode(void);
  * B * ldn_channel_masker_splits(Hi*Wi) * C entries, only needed for S == 1 (layer skip: whole-image window); after the call it
  * holds the images' partial channel sums.  carry_prefix (optional, S == 1 only) [B+1]: the kept-row prefix (img_prefix3 of
  * ldn_mask_to_index) of the PREVIOUS layer-skip block on the same residual stream, with `work` the buffer that block's call
- * filled: an image that block skipped (empty range) is unchanged, so its sums are reused instead of re-read. */
+ * filled: an image that block skipped (empty range) is unchanged, so its sums are reused instead of re-read.
+ * Patch masks (1 < S < Hi): `work` (optional, B*S*S*C floats) receives every patch's pooled channel means; carry_mask (optional)
+ * [B][S][S] {0,1} = the patch mask the PREVIOUS block on the same residual stream executed (the union of its mask groups), with
+ * `work` the buffer the previous call filled: a patch that block did not touch keeps its means, its window is not re-read. */
 int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w /*[2g,C]*/,
                        const float* bias /*[2g]*/, int g, int S, float* mask, float* logits, float* work,
-                       const int32_t* carry_prefix, void* stream);
+                       const int32_t* carry_prefix, const float* carry_mask, void* stream);
 /* bytes of `work` the call above needs for this shape (0 = none); every *_workspace_bytes twin below follows the same rule */
 size_t ldn_spatial_masker_workspace_bytes(int B, int Hi, int Wi, int C, int S);
 

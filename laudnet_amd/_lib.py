@@ -20,7 +20,7 @@ SIGNATURES = {
     "ldn_debug_violations": ([C.POINTER(_I), C.POINTER(_I), _I], _I),
     "ldn_device_cus": ([C.POINTER(_I)], _I),
     "ldn_default_math_mode": ([], _I),
-    "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P], _I),
+    "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "ldn_spatial_masker_workspace_bytes": ([_I, _I, _I, _I, _I], C.c_size_t),
     "ldn_mask_to_index": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "ldn_mask_to_index_workspace_bytes": ([_I, _I, _I, _I], C.c_size_t),

@@ -47,7 +47,8 @@ __device__ __forceinline__ int block_rank(bool flag, int* s_w, int& chunk_total)
 __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict__ x, int B, int Hi, int Wi, int C,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          int g, int S, float* __restrict__ mask,
-                                                         float* __restrict__ logits) {
+                                                         float* __restrict__ logits, float* __restrict__ pool_work,
+                                                         const float* __restrict__ carry_mask) {
     const int lane = threadIdx.x & 63;
     const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool pooled = S < Hi;  // models/utils.py:48
@@ -65,11 +66,19 @@ __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict_
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = 0.f;
     const int G2 = 2 * g;
+    // Patch carry: pool_work [B][Sy][Sx][C] keeps every patch's pooled channel means.  A patch the PREVIOUS block of the same
+    // residual stream left untouched (carry_mask[b][patch] == 0: its conv3 wrote no pixel of it) has the means that block's masker
+    // stored -- they are reused instead of re-reading the window (the same floats: bit-identical decisions).
+    float* const pw_row = pool_work ? pool_work + ((size_t)b * Sy * Sx + pp) * C : nullptr;
+    const bool reuse = pw_row && carry_mask && carry_mask[(size_t)b * Sy * Sx + pp] < 0.5f;
     if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
         // 16 bytes per lane: one wave instruction covers 256 channels of a pixel; the pixel loop is unrolled so that several
         // KiB per wave are in flight (this kernel is one HBM pass over x)
         for (int c = lane * 4; c < C; c += 256) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (reuse) {
+                s = *reinterpret_cast<const f32x4*>(pw_row + c);
+            } else {
             // the window's pixels in row-major order, eight loads in flight per lane, added in that order (same sums as the plain loop)
             const int pw = x1 - x0, np = (y1 - y0) * pw;
             const float* base = x + ((size_t)(b * Hi + y0) * Wi + x0) * C + c;
@@ -89,6 +98,8 @@ __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict_
                 s += *reinterpret_cast<const f32x4*>(base + ((size_t)py * Wi + px) * C);
             }
             s *= inv;
+            if (pw_row) *reinterpret_cast<f32x4*>(pw_row + c) = s;
+            }
 #pragma unroll
             for (int o = 0; o < 8; ++o)
                 if (o < G2) {
@@ -99,9 +110,14 @@ __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict_
     } else {
         for (int c = lane; c < C; c += 64) {
             float s = 0.f;
-            for (int y = y0; y < y1; ++y)
-                for (int xx = x0; xx < x1; ++xx) s += x[((size_t)(b * Hi + y) * Wi + xx) * C + c];
-            s *= inv;
+            if (reuse) {
+                s = pw_row[c];
+            } else {
+                for (int y = y0; y < y1; ++y)
+                    for (int xx = x0; xx < x1; ++xx) s += x[((size_t)(b * Hi + y) * Wi + xx) * C + c];
+                s *= inv;
+                if (pw_row) pw_row[c] = s;
+            }
 #pragma unroll
             for (int o = 0; o < 8; ++o)
                 if (o < G2) acc[o] += w[o * C + c] * s;
@@ -723,8 +739,9 @@ extern "C" int ldn_device_cus(int* cus) {
 }
 
 extern "C" size_t ldn_spatial_masker_workspace_bytes(int B, int Hi, int Wi, int C, int S) {
-    if (!(S < Hi && S == 1)) return 0;   // only the whole-image window (layer skip) is reduced in two stages
-    return (size_t)B * ldn_channel_masker_splits(Hi * Wi) * C * sizeof(float);
+    if (!(S < Hi)) return 0;             // one logit per pixel: nothing pooled, nothing to keep
+    if (S > 1) return (size_t)B * S * S * C * sizeof(float);     // the patches' pooled channel means (optional: patch carry)
+    return (size_t)B * ldn_channel_masker_splits(Hi * Wi) * C * sizeof(float);   // whole-image window (layer skip): two-stage reduction
 }
 constexpr size_t kWholeImageLds = 150 * 1024;   // per-image tables up to this size are built by one workgroup per image
 constexpr size_t kBandLds = 64 * 1024;          // LDS budget of a band (several workgroups per CU)
@@ -758,7 +775,7 @@ extern "C" size_t ldn_channel_masker_workspace_bytes(int B, int HW, int C) {
 
 extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, const float* w, const float* bias,
                                   int g, int S, float* mask, float* logits, float* work, const int32_t* carry_prefix,
-                                  void* stream) {
+                                  const float* carry_mask, void* stream) {
     LDN_REQUIRE(x && w && bias && mask, "ldn_spatial_masker: null pointer");
     LDN_REQUIRE(g >= 1 && g <= 4, "ldn_spatial_masker: mask groups must be 1..4 (got %d)", g);
     LDN_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C > 0 && S > 0, "ldn_spatial_masker: bad shape");
@@ -778,8 +795,11 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
         return LDN_OK;
     }
     const long jobs = (long)B * (pooled ? S * S : Hi * Wi);
+    LDN_REQUIRE(!carry_mask || work, "ldn_spatial_masker: carry_mask needs the work buffer of the previous call");
+    LDN_REQUIRE((uintptr_t)work % 16 == 0, "ldn_spatial_masker: work must be 16-byte aligned");
     hipLaunchKernelGGL(k_spatial_masker, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, B, Hi, Wi, C, w, bias, g, S, mask, logits);
+                       static_cast<hipStream_t>(stream), x, B, Hi, Wi, C, w, bias, g, S, mask, logits, pooled && S > 1 ? work : nullptr,
+                       pooled && S > 1 ? carry_mask : nullptr);
     LDN_CHECK_LAUNCH("k_spatial_masker");
     return LDN_OK;
 }

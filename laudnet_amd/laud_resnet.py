@@ -603,8 +603,12 @@ class Bottleneck(_PrepCache):
         # reference reports for them -- live on the UNION of the groups; only conv3's scatter is per group.
         union = patch[:, 0] if G == 1 else patch.amax(dim=1)
         ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride)
-        if ms.mask_size == 1 and G == 1 and self.forced_spatial_mask is None and getattr(ms, "last_work", None) is not None:
-            self.last_carry = (ms.last_work, ix.pre3, getattr(ms.last_work, "ldn_shape_key", None))      # layer skip: which images this block leaves unchanged, and their channel sums
+        if self.forced_spatial_mask is None and getattr(ms, "last_work", None) is not None:
+            key = getattr(ms.last_work, "ldn_shape_key", None)
+            if ms.mask_size == 1 and G == 1:
+                self.last_carry = (ms.last_work, ix.pre3, key)      # layer skip: which images this block leaves unchanged, and their channel sums
+            elif ms.mask_size > 1:
+                self.last_carry = (ms.last_work, None, key, union.contiguous())   # patch masks: the patches this block touches, and every patch's pooled means
         x2d = xn.reshape(B * Hi * Wi, Cin)
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
         ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
@@ -936,7 +940,7 @@ class ResNet(nn.Module):
             # layer skip: the images the previous block skipped reach this block unchanged -> their channel sums (the masker's global
             # average pool) are carried over instead of re-read (one full read of x per block otherwise)
             prev = blocks[j - 1] if j > 0 else None
-            blk._carry_in = (prev.last_carry if (self.use_layer_carry and prev is not None and blk.dyn_mode == "layer" and prev.dyn_mode == "layer"
+            blk._carry_in = (prev.last_carry if (self.use_layer_carry and prev is not None and blk.dyn_mode in ("layer", "spatial") and prev.dyn_mode == blk.dyn_mode
                                                  and blk.stride == 1 and blk.downsample is None and blk.forced_spatial_mask is None
                                                  # the producer must leave the images it skips UNCHANGED: a block with a projection
                                                  # shortcut / stride 2 turns them into relu(downsample(x))

@@ -85,8 +85,9 @@ def from_nhwc(y):
 # ---------------------------------------------------------------------------------------- a1
 def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False, carry=None, return_work=False):
     """Masker_spatial eval forward (models/utils.py:47-65).  x_nhwc [B,H,W,C]; weight [2g,C]; bias [2g].
-    Returns (mask [B,g,Sy,Sx] float {0,1}, logits [B,2g,Sy,Sx] or None[, work]).  carry = (work, prefix, shape_key) of the previous
-    layer-skip block on the same residual stream (see ldn_spatial_masker): images that block skipped are not re-read."""
+    Returns (mask [B,g,Sy,Sx] float {0,1}, logits [B,2g,Sy,Sx] or None[, work]).  carry = (work, prefix, shape_key[, patch_mask]) of the
+    previous block on the same residual stream (see ldn_spatial_masker): images (layer skip) / patches (patch masks) that block left
+    untouched are not re-read."""
     L.require_device(x_nhwc, weight, bias)
     lib = L.load()
     B, H, W, C = x_nhwc.shape
@@ -95,18 +96,24 @@ def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False, c
     mask = torch.empty(B, groups, sy, sx, device=x_nhwc.device, dtype=torch.float32)
     logits = torch.empty(B, 2 * groups, sy, sx, device=x_nhwc.device, dtype=torch.float32) if want_logits else None
     nbytes = lib.ldn_spatial_masker_workspace_bytes(B, H, W, C, mask_size)
-    prefix = None
+    prefix = cmask = None
     # a carry is only taken from a masker call on a tensor of the SAME shape (the partial sums are [B][splits][C] of that shape: a
     # byte count alone can coincide between a stride-2 block's input and the next block's input)
     shape_key = (B, H, W, C, mask_size)
     if (carry is not None and nbytes and carry[0] is not None and len(carry) > 2 and tuple(carry[2]) == shape_key
             and carry[0].numel() * 4 == nbytes and carry[0].device == x_nhwc.device):
-        work, prefix = carry[0], _i32c(carry[1], "carry_prefix")
+        work = carry[0]
+        if mask_size == 1:
+            prefix = _i32c(carry[1], "carry_prefix")
+        else:   # patch masks: carry[3] = the [B, S, S] patch mask the previous block executed
+            cmask = _f32c(carry[3], "carry_mask") if len(carry) > 3 and carry[3] is not None else None
+            if cmask is None or tuple(cmask.shape) != (B, sy, sx):
+                work, cmask = _work(nbytes, x_nhwc.device), None
     else:
-        work = _work(nbytes, x_nhwc.device)
+        work = _work(nbytes, x_nhwc.device) if (mask_size == 1 or return_work) else None
     L.check(lib.ldn_spatial_masker(L.ptr(_f32c(x_nhwc, "x")), B, H, W, C, L.ptr(_f32c(weight, "w")),
                                    L.ptr(_f32c(bias, "bias")), groups, mask_size, L.ptr(mask), L.ptr(logits), L.ptr(work),
-                                   L.ptr(prefix), L.stream_ptr()), "ldn_spatial_masker")
+                                   L.ptr(prefix), L.ptr(cmask), L.stream_ptr()), "ldn_spatial_masker")
     if return_work and work is not None:
         work.ldn_shape_key = shape_key          # what a later call must match to reuse these sums (carry[2])
     return (mask, logits, work) if return_work else (mask, logits)
@@ -217,7 +224,8 @@ def split_rows_weight(w):
             hit = _SPLIT_CACHE[key] = (pack_w1_split(w2),)
         # the entry lives exactly as long as its source tensor (a module's folded weight dropped by invalidate() / a new checkpoint
         # takes its split copy with it; a later tensor that reuses the address starts from an empty slot)
-        weakref.finalize(w, _SPLIT_CACHE.pop, key, None)
+        # (tied to the tensor that OWNS the storage: callers pass throw-away views such as w3[channel_slice])
+        weakref.finalize(w._base if w._base is not None else w, _SPLIT_CACHE.pop, key, None)
     return hit[0]
 
 

@@ -74,7 +74,8 @@ def test_workspace_twins_without_gpu():
     lib = _lib.load()
     splits = lib.ldn_channel_masker_splits(3136)
     assert lib.ldn_channel_masker_workspace_bytes(256, 3136, 256) == 256 * splits * 256 * 4
-    assert lib.ldn_spatial_masker_workspace_bytes(4, 56, 56, 64, 14) == 0          # pooled to 14x14: no scratch
+    assert lib.ldn_spatial_masker_workspace_bytes(4, 56, 56, 64, 14) == 4 * 14 * 14 * 64 * 4    # pooled to 14x14: the patches' pooled means (patch carry)
+    assert lib.ldn_spatial_masker_workspace_bytes(4, 56, 56, 64, 56) == 0          # one logit per pixel: no scratch
     assert lib.ldn_spatial_masker_workspace_bytes(4, 56, 56, 64, 1) == 4 * splits * 64 * 4
     assert lib.ldn_mask_to_index_workspace_bytes(256, 14, 14, 1) == 3 * 256 * 4
     assert lib.ldn_mask_to_index_workspace_bytes(2, 200, 304, 1) > 3 * 2 * 4          # banded build: one entry per (image, band)

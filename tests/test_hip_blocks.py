@@ -336,6 +336,40 @@ def test_layer_carry_is_bit_identical():
         ops.set_math_mode("fp32")
 
 
+@pytest.mark.parametrize("gran,groups", [([4, 4, 2, 1], 1), ([4, 4, 4, 4], 1), ([2, 2, 2, 1], 2)])
+def test_patch_carry_is_bit_identical(gran, groups):
+    """Spatial mode with patch masks: the pooled channel means of the patches a block did not touch are carried to the next block's
+    masker (ldn_spatial_masker: work + carry_mask) instead of re-reading their windows -- the same floats, so logits, masks and outputs
+    are bit-identical to the execution without the carry; even (4-4-2-1), uneven (14 // 4: patches of 5, 5, 4 pixels) patch grids and
+    two mask groups (the carry follows the UNION of the groups)."""
+    import laudnet_amd
+    from laudnet_amd import ops
+    ops.set_math_mode("bf16x3")
+    try:
+        m = laudnet_amd.uni_resnet50(dyn_mode=["spatial"] * 4, mask_spatial_granularity=gran, spatial_mask_channel_group=[groups] * 4,
+                                     width_mult=0.5, input_size=224, num_classes=10).eval()
+        sd = fill_state_dict(m.state_dict(), 3)
+        for k in sd:       # zero the keep bias: fresh maskers keep everything (bias 5.0), the carry would never be exercised
+            if k.endswith("masker_spatial.conv.bias"):
+                sd[k] = torch.zeros_like(sd[k])
+        m.load_state_dict(sd)
+        m = m.to(DEV)
+        x = seeded_randn((6, 3, 224, 224), 5).to(DEV)
+        outs = []
+        for carry in (True, False):
+            m.use_layer_carry = carry
+            with torch.no_grad():
+                outs.append(m(x, 1.0))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert torch.equal(a, b)
+        assert 0.05 < float(torch.cat(outs[0][1]).mean()) < 0.95      # some patches dropped, some kept: the carry was exercised
+        blk = m.layer3[2]
+        assert blk.last_carry is not None and len(blk.last_carry) == 4 and blk.last_carry[3].shape[0] == 6
+    finally:
+        ops.set_math_mode("fp32")
+
+
 # ------------------------------------------------------------------ LAD-RegNet with two spatial mask groups per block
 REGNET_X = load_golden("regnet_extra.pt")
 

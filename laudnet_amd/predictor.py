@@ -345,7 +345,7 @@ class Predictor:
         t_b = (in_bytes + out_bytes + 4.0 * taps * k * n) / (self.hw.hbm_bytes_per_s * self.cal.rows_hbm_eff)
         return max(rounds * t_tile, t_b) + self.cal.launch_s
 
-    def spatial_block(self, b: BlockShape, batch: int, s3: float, s1: float, layer_mode: bool = False, prev_s3: float = 1.0) -> dict:
+    def spatial_block(self, b: BlockShape, batch: int, s3: float, s1: float, layer_mode: bool = False, prev_s3: float = -1.0) -> dict:
         """One spatial- or layer-mode bottleneck: masker, index lists, conv1 on the dilated list (N1 rows), 3x3 on the output list
         (N3 rows, nine gathered h1 rows each), conv3 + residual scatter; first blocks add the dense projection.
         s3 / s1 = kept fraction of output / conv1 positions (the module's own sparsity outputs)."""
@@ -353,8 +353,9 @@ class Predictor:
         n1, n3 = s1 * batch * px_in, s3 * batch * px
         cap1, cap3 = batch * px_in, batch * px
         t = {}
-        # masker: one pass over x (layer mode: only the images the previous block updated are re-read, the rest are carried)
-        frac = prev_s3 if (layer_mode and not b.downsample and b.stride == 1) else 1.0
+        # masker: one pass over x -- of which only the images (layer mode) / patches (spatial mode) the previous block touched are
+        # re-read when that block left the rest unchanged (stride 1, no projection: prev_s3 < 0 says it did not), the rest is carried
+        frac = prev_s3 if (prev_s3 >= 0.0 and not b.downsample and b.stride == 1) else 1.0
         t["masker"] = 4.0 * frac * batch * px_in * b.cin / (self.hw.hbm_bytes_per_s * self.cal.hbm_eff) + 2 * self.cal.launch_s
         t["index"] = (self.cal.launch_s if layer_mode else self.cal.idx_s + 2 * self.cal.launch_s) + 4.0 * 11 * n3 / (self.hw.hbm_bytes_per_s * self.cal.hbm_eff)
         t["conv1"] = self._rows(n1, b.cin, b.width, 4.0 * n1 * b.cin, 4.0 * n1 * b.width, cap1)
@@ -371,12 +372,12 @@ class Predictor:
         blocks = resnet_blocks(layers, input_hw)
         total = self.stem(batch, input_hw) + self.cal.rows_fixed_s
         rows = [("stem", total)]
-        prev = 1.0
+        prev = -1.0
         for i, (s, b) in enumerate(blocks):
             r = self.spatial_block(b, batch, s3[i], s1[i], layer_mode, prev)
             rows.append((f"layer{s + 1}.{i}", r["s"]))
             total += r["s"]
-            prev = s3[i]
+            prev = s3[i] if (not b.downsample and b.stride == 1) else -1.0      # a carry only from a block that leaves untouched units unchanged
         return {"s": total, "ms": 1e3 * total, "rows": rows}
 
     def predict_regnet_layerskip(self, batch: int, keep, widths=(64, 144, 320, 784), depths=(1, 3, 8, 2), stem_width=32, input_hw=(224, 224),

@@ -226,6 +226,21 @@ int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int
                         const float* shift2_tab, const float* post_sub2, const float* shift3, const float* residual,
                         int ldr, float* out, int ldo, float* colsum, void* stream);
 
+/* ---- a7 (channel mode, bf16x3): a WHOLE stride-1 identity-shortcut bottleneck on a SMALL map (H * Wd <= 64 pixels: the 7x7 maps of
+ * stage 4, laud_resnet.py:115-144 on the image's active channels) as ONE launch, one workgroup per image: conv1 -> bn1 + ReLU ->
+ * conv2 3x3 -> bn2 + ReLU -> conv3 -> bn3 + residual + ReLU.  h1 and h2 stay in the workgroup's LDS; the eight waves tile the image as
+ * 2 pixel tiles x 4 channel quarters, so widths up to 512 fit the accumulator registers (csrc/ldn_small.hip).  Operands, weight
+ * layouts and formulas are those of ldn_bottleneck_head + ldn_bottleneck_tail (stride 1); width % 64 == 0 and <= 512, cin % 32 == 0,
+ * cout % 128 == 0; x / residual / out [B*H*Wd][ldx / ldr / ldo] fp32, out may alias residual and x (in-place residual stream).
+ *   colsum (optional) [B][2][cout]: partial sums of out over the two pixel tiles (the next block's channel masker: gap_partial, 2 splits).
+ * ldn_bottleneck_smallmap_fits: 1 when this map / these widths fit the 160 KiB of LDS for EVERY channel count (0: use the other paths). */
+int ldn_bottleneck_smallmap_fits(int H, int Wd, int cin, int width, int cout);
+int ldn_bottleneck_smallmap(const float* x, int ldx, int B, int H, int Wd, int cin, int width, const void* w1_split,
+                            const void* w2_pairs, const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
+                            const float* scale1, const float* shift1, const float* post_sub1, const float* scale2,
+                            const float* shift2_tab, const float* post_sub2, const float* shift3, const float* residual, int ldr,
+                            float* out, int ldo, float* colsum, void* stream);
+
 /* ---- a2 + a7 (channel mode, bf16x3): a RUN of consecutive stride-1 channel-mode bottlenecks on maps of at most 256 pixels
  * (stage 3 of the ResNets: 14x14) as ONE launch -- per block: ldn_channel_masker on the GAP of the block's input, then
  * ldn_bottleneck_head, then ldn_bottleneck_tail (laud_resnet.py:104-147, block after block; models/utils.py:92-131).

@@ -55,6 +55,8 @@ SIGNATURES = {
     "ldn_stem3_conv": ([_P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P], _I),
     "ldn_packed_mha": ([_P, _I, _P, _P, _I, _I, _I, _I, C.c_float, _P, _I, _P], _I),
     "ldn_bottleneck_chain_fits": ([_I, _I, _I, _I, _I, _I], _I),
+    "ldn_bottleneck_smallmap_fits": ([_I, _I, _I, _I, _I], _I),
+    "ldn_bottleneck_smallmap": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
     "ldn_bottleneck_chain": ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P], _I),
 }
 

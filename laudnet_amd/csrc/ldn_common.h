@@ -60,6 +60,7 @@ int tu_violations_index(unsigned* count, unsigned* code, int reset);
 int tu_violations_regnet(unsigned* count, unsigned* code, int reset);
 int tu_violations_tail(unsigned* count, unsigned* code, int reset);
 int tu_violations_dense(unsigned* count, unsigned* code, int reset);
+int tu_violations_small(unsigned* count, unsigned* code, int reset);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

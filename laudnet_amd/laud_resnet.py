@@ -490,6 +490,35 @@ class Bottleneck(_PrepCache):
                 and self.width in (64, 128, 256) and Wo <= 256 and cout % 64 == 0
                 and ops.bottleneck_tail_splits(Hi, Wi, self.width, st) > 0)    # LDS / slice-pipeline limits, decided by the library
 
+    use_smallmap = os.environ.get("LDN_SMALLMAP", "1") != "0"   # the one-launch bottleneck on maps of at most 64 pixels (A/B switch)
+
+    def _smallmap_eligible(self, Cin, Hi, Wi):
+        """The whole block as ONE launch, one workgroup per image (ldn_bottleneck_smallmap): bf16x3 arithmetic, stride 1, identity
+        shortcut, an even channel granularity, a map of at most 64 pixels whose activations fit the workgroup's LDS at this width
+        (stage 4 of the ResNets: 7x7 x 512)."""
+        cout = self.conv3.out_channels
+        return (self.use_smallmap and self.channel_exec in ("auto", "smallmap") and ops.get_math_mode() == "bf16x3"
+                and self.stride == 1 and self.downsample is None and Cin == cout and self.channel_dyn_granularity % 2 == 0
+                and Hi * Wi <= 64 and ops.bottleneck_smallmap_fits(Hi, Wi, Cin, self.width, cout))
+
+    def _run_channel_smallmap(self, x, p, gap_in=None, want_gap=False):
+        B, Cin, Hi, Wi = x.shape
+        gran = self.channel_dyn_granularity
+        xn = ops.as_nhwc(x)
+        if gap_in is not None and getattr(self.masker_channel, "accepts_fused_gap", False):
+            mask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask, gap=gap_in)
+        else:
+            mask, idx, cnt, _ = self.masker_channel.lists(x, gran, mask_in=self.forced_channel_mask)
+        w2p, w3p = self.tail_weights(p)
+        out = xn if self._inplace else torch.empty_like(xn)
+        gap_out = torch.empty(B, 2, Cin, device=x.device, dtype=torch.float32) if want_gap else None
+        ops.bottleneck_smallmap(xn, p["w1s"], w2p, w3p, idx, cnt, p["s1"], p["t1"], p["c1"], p["s2"], p["t2_tab"], p["c2"], p["t3c"], out,
+                                residual=xn, colsum=gap_out)
+        self.last_channel_mask = mask
+        self.last_gap = gap_out
+        self.last_channel_cnt = cnt
+        return ops.from_nhwc(out), mask
+
     def tail_weights(self, p):
         """conv2 / conv3 weights in the pre-split pair-interleaved layouts of ldn_bottleneck_tail (built once, cached with the
         other folded parameters)."""
@@ -522,6 +551,8 @@ class Bottleneck(_PrepCache):
         # front of a stride-2 block (208 / 240 px inputs: 13x13, 15x15) and non-square maps stay on the gather path, which
         # takes the geometry explicitly
         dense_ok = Hi == Ho * self.stride and Wi == Wo * self.stride
+        if self._smallmap_eligible(Cin, Hi, Wi):
+            return self._run_channel_smallmap(x, p, gap_in, want_gap)
         if self.channel_exec == "dense" and not dense_ok:
             raise LdnError(f"Bottleneck: channel_exec='dense' needs Hi == Ho*stride (got {Hi}x{Wi} -> {Ho}x{Wo})")
         if dense_ok and (self.channel_exec == "dense" or (self.channel_exec == "auto" and Ho * Wo <= 64)):

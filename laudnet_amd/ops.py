@@ -597,6 +597,37 @@ def bottleneck_tail(h1_split, w2_pairs, w3_pairs, ch_idx, ch_cnt, scale2, shift2
     return out_nhwc
 
 
+def bottleneck_smallmap_fits(H, W, cin, width, cout):
+    """Does a whole bottleneck on an H x W map fit one workgroup (ldn_bottleneck_smallmap_fits)?"""
+    return bool(L.load().ldn_bottleneck_smallmap_fits(H, W, cin, width, cout))
+
+
+def bottleneck_smallmap(x_nhwc, w1_split, w2_pairs, w3_pairs, ch_idx, ch_cnt, scale1, shift1, post_sub1, scale2, shift2_tab, post_sub2,
+                        shift3, out_nhwc, *, residual=None, colsum=None):
+    """A whole stride-1 channel-mode bottleneck on a small map as one launch (see ldn_bottleneck_smallmap).  x_nhwc [B,H,Wd,cin],
+    out_nhwc / residual [B,H,Wd,cout] (may be the same tensor as x_nhwc); colsum [B,2,cout]."""
+    L.require_device(x_nhwc, w1_split, w2_pairs, w3_pairs, out_nhwc)
+    lib = L.load()
+    B, H, Wd, cin = x_nhwc.shape
+    width = ch_idx.shape[1]
+    cout = out_nhwc.shape[-1]
+    if tuple(out_nhwc.shape) != (B, H, Wd, cout) or (residual is not None and tuple(residual.shape) != (B, H, Wd, cout)):
+        raise L.LdnError(f"bottleneck_smallmap: out / residual must be [B={B}, {H}, {Wd}, cout]")
+    if colsum is not None and (tuple(colsum.shape) != (B, 2, cout) or not colsum.is_contiguous()):
+        raise L.LdnError("bottleneck_smallmap: colsum must be a contiguous [B, 2, cout] tensor")
+    for w in (w1_split, w2_pairs, w3_pairs):
+        if w.dtype != torch.bfloat16 or not w.is_contiguous():
+            raise L.LdnError("bottleneck_smallmap: weights must be the contiguous bf16 tensors of pack_w1_split / pack_w2_pairs / pack_w3_pairs")
+    L.check(lib.ldn_bottleneck_smallmap(L.ptr(_f32c(x_nhwc, "x")), cin, B, H, Wd, cin, width, L.ptr(w1_split), L.ptr(w2_pairs),
+                                        L.ptr(w3_pairs), cout, L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")),
+                                        L.ptr(_f32c(scale1, "scale1")), L.ptr(_f32c(shift1, "shift1")), L.ptr(_f32c(post_sub1, "post_sub1")),
+                                        L.ptr(_f32c(scale2, "scale2")), L.ptr(_f32c(shift2_tab, "shift2_tab")),
+                                        L.ptr(_f32c(post_sub2, "post_sub2")), L.ptr(_f32c(shift3, "shift3")), L.ptr(residual),
+                                        cout if residual is not None else 0, L.ptr(_f32c(out_nhwc, "out")), cout, L.ptr(colsum),
+                                        L.stream_ptr(out_nhwc)), "ldn_bottleneck_smallmap")
+    return out_nhwc
+
+
 # ---------------------------------------------------------------------------------------- a8: the static stem
 def pack_stem_weights(w_scaled):
     """bn1-scaled conv1.weight [cout,3,7,7] fp32 -> MFMA fragment order [cout/32][11][64][hi 8 | lo 8] bf16 (ldn_stem_conv_pool):

@@ -287,56 +287,69 @@ __global__ __launch_bounds__(512, 2) void k_smallmap(const SmallArgs p) {
             // weight fragment row of this lane for subtile j = q + 4 i: list row n = 32 j + l31 = piece n / 64 of wave (n % 64) / 8
             const unsigned w_rd = (unsigned)((64 + ((4 * (q & 1) + (l31 >> 3)) * nw + (q >> 1)) * 8 + (l31 & 7)) * 128);   // + i * 2048
             unsigned coff = 0;
-            struct Frag { f32x4 x0, x1; bf16x8 ah[4], al[4]; };
-            auto load_frag = [&](Frag& f, int kk) {
-                if (!active) return;
-                const unsigned char* xs = smem + S_ACT_OFF + coff;
-                const unsigned sl = 4u * kk + 2u * h;                   // x: fp32 k .. k+3 | k+4 .. k+7 of this lane's half of the K16 step
-                f.x0 = *reinterpret_cast<const f32x4*>(xs + pm * 128 + ((sl ^ xsw) << 4));
-                f.x1 = *reinterpret_cast<const f32x4*>(xs + pm * 128 + (((sl + 1) ^ xsw) << 4));
-                const unsigned slw = 4u * kk + 2u * h;                  // weights: octet 2 kk + h = slots (hi, lo)
-                const unsigned char* wr = xs + w_rd;
+            // the loop is instantiated per subtile count of the wave (0: a wave without pixels or channels only stages and synchronises):
+            // predicated fragment reads cost copies of the whole register set at every branch join
+            auto run = [&](auto NVc) {
+                constexpr int NV = decltype(NVc)::value;
+                struct Frag { f32x4 x0, x1; bf16x8 ah[NV > 0 ? NV : 1], al[NV > 0 ? NV : 1]; };
+                auto load_frag = [&](Frag& f, int kk) {
+                    if constexpr (NV > 0) {
+                        const unsigned char* xs = smem + S_ACT_OFF + coff;
+                        const unsigned sl = 4u * kk + 2u * h;           // x: fp32 k .. k+3 | k+4 .. k+7 of this lane's half of the K16 step
+                        f.x0 = *reinterpret_cast<const f32x4*>(xs + pm * 128 + ((sl ^ xsw) << 4));
+                        f.x1 = *reinterpret_cast<const f32x4*>(xs + pm * 128 + (((sl + 1) ^ xsw) << 4));
+                        const unsigned char* wh = xs + w_rd + ((sl ^ wsw) << 4);          // weights: octet 2 kk + h = slots (hi, lo)
+                        const unsigned char* wl = xs + w_rd + (((sl + 1) ^ wsw) << 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < nv) {
-                        f.ah[i] = *reinterpret_cast<const bf16x8*>(wr + i * 2048 + ((slw ^ wsw) << 4));
-                        f.al[i] = *reinterpret_cast<const bf16x8*>(wr + i * 2048 + (((slw + 1) ^ wsw) << 4));
+                        for (int i = 0; i < NV; ++i) {
+                            f.ah[i] = *reinterpret_cast<const bf16x8*>(wh + i * 2048);
+                            f.al[i] = *reinterpret_cast<const bf16x8*>(wl + i * 2048);
+                        }
                     }
-            };
-            auto mfma_frag = [&](const Frag& f) {
-                if (!active) return;
-                bf16x8 bh, bl;
+                };
+                auto mfma_frag = [&](const Frag& f) {
+                    if constexpr (NV > 0) {
+                        bf16x8 bh, bl;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = pvalid ? (e < 4 ? f.x0[e] : f.x1[e - 4]) : 0.f;
-                    const __bf16 hb = (__bf16)v;
-                    bh[e] = hb;
-                    bl[e] = (__bf16)(v - (float)hb);
-                }
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = pvalid ? (e < 4 ? f.x0[e] : f.x1[e - 4]) : 0.f;
+                            const __bf16 hb = (__bf16)v;
+                            bh[e] = hb;
+                            bl[e] = (__bf16)(v - (float)hb);
+                        }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (i < nv) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], bh, acc[i], 0, 0, 0);
+                        for (int i = 0; i < NV; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], bh, acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (i < nv) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], bl, acc[i], 0, 0, 0);
+                        for (int i = 0; i < NV; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], bl, acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (i < nv) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], bh, acc[i], 0, 0, 0);
-            };
-            Frag f0, f1;
-            wait_vm_rt(ipc * (D - 1));                           // chunk 0
-            lds_barrier();
-            load_frag(f0, 0);
-#pragma unroll 1
-            for (int c = 0; c < nchunks; ++c) {
-                load_frag(f1, 1);
-                mfma_frag(f0);
-                ST(ta)
-                wait_vm_rt(ipc * (D - 2));                       // chunk c + 1 has landed ...
-                lds_barrier();                                   // ... for every wave; every wave has read chunk c
-                ST(tb)
-                ST_ADD(wt[0], ta, tb)
-                issue();
-                coff += slot1; if (coff == ring_bytes) coff = 0;
+                        for (int i = 0; i < NV; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], bh, acc[i], 0, 0, 0);
+                    }
+                };
+                Frag f0, f1;
+                wait_vm_rt(ipc * (D - 1));                       // chunk 0
+                lds_barrier();
                 load_frag(f0, 0);
-                mfma_frag(f1);
+#pragma unroll 1
+                for (int c = 0; c < nchunks; ++c) {
+                    load_frag(f1, 1);
+                    mfma_frag(f0);
+                    ST(ta)
+                    wait_vm_rt(ipc * (D - 2));                   // chunk c + 1 has landed ...
+                    lds_barrier();                               // ... for every wave; every wave has read chunk c
+                    ST(tb)
+                    ST_ADD(wt[0], ta, tb)
+                    issue();
+                    coff += slot1; if (coff == ring_bytes) coff = 0;
+                    load_frag(f0, 0);
+                    mfma_frag(f1);
+                }
+            };
+            switch (active ? nv : 0) {
+                case 0: run(std::integral_constant<int, 0>{}); break;
+                case 1: run(std::integral_constant<int, 1>{}); break;
+                case 2: run(std::integral_constant<int, 2>{}); break;
+                case 3: run(std::integral_constant<int, 3>{}); break;
+                default: run(std::integral_constant<int, 4>{}); break;
             }
             wait_vm_n<0>();
             lds_barrier();                                     // the ring is dead: its place is h1's
@@ -446,68 +459,84 @@ __global__ __launch_bounds__(512, 2) void k_smallmap(const SmallArgs p) {
                 const int nv = nsub > q ? (nsub - q + 3) / 4 : 0;             // this wave's n-subtiles: q, q + 4, ...
                 const unsigned a_rd = (unsigned)(4 * h * W2ROW + l31 * 8 + q * 256);
                 unsigned coff = 0;                               // slot offset of the chunk the next fragments are read from
-                struct Frag { bf16x8 bh, bl; u32x2 e[4][4]; };
-                // fragments of step (slice s, tap tp, K16 step kk); `rows` = byte offset of the step's 8 rows within the chunk's slot
-                auto load_frag = [&](Frag& f, int s, int tp, int kk, unsigned rows) {
-                    if (!active) return;
-                    const int ty = (tp * 11) >> 5;                                   // tp / 3 for tp < 9
-                    const int r = ((tmask >> tp) & 1u) ? pm + (ty - 1) * p.Wd + (tp - 3 * ty - 1) : -1;
-                    const unsigned char* hrow = r >= 0 ? s_act + (size_t)s * HW * 128 + r * 128 : smem + S_ZERO_OFF;
-                    const unsigned rx = r >= 0 ? ((unsigned)r >> 1) & 7u : 0u;
-                    const unsigned sl = 2u * (2u * kk + h);
-                    f.bh = *reinterpret_cast<const bf16x8*>(hrow + ((sl ^ rx) << 4));
-                    f.bl = *reinterpret_cast<const bf16x8*>(hrow + (((sl + 1) ^ rx) << 4));
-                    const unsigned char* wa = smem + G.ring_off + coff + rows + a_rd;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i < nv) {
-#pragma unroll
-                            for (int qq = 0; qq < 4; ++qq) f.e[i][qq] = *reinterpret_cast<const u32x2*>(wa + qq * W2ROW + i * 1024);
-                        }
-                };
-                auto mfma_frag = [&](const Frag& f) {
-                    if (!active) return;
-                    bf16x8 ah[4], al[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const u32x4 ahu = {f.e[i][0][0], f.e[i][1][0], f.e[i][2][0], f.e[i][3][0]};
-                        const u32x4 alu = {f.e[i][0][1], f.e[i][1][1], f.e[i][2][1], f.e[i][3][1]};
-                        ah[i] = __builtin_bit_cast(bf16x8, ahu); al[i] = __builtin_bit_cast(bf16x8, alu);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (i < nv) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], f.bh, acc[i], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (i < nv) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], f.bl, acc[i], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (i < nv) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], f.bh, acc[i], 0, 0, 0);
-                };
-                auto sync_issue = [&]() {          // the next chunk has landed for every wave; every wave has read the current one
-                    ST(ta)
-                    wait_vm_rt(ipc * (D - 2));
-                    lds_barrier();
-                    ST(tb)
-                    ST_ADD(wt[1], ta, tb)
-                    issue();
-                    coff += slotB; if (coff == ring_bytes) coff = 0;
-                };
-                Frag f0, f1;
-                wait_vm_rt(ipc * (D - 1));                       // chunk 0
-                lds_barrier();
-                load_frag(f0, 0, 0, 0, 0);
                 const unsigned half_rows = (unsigned)(8 * W2ROW);
-                ST(ta)
+                auto run = [&](auto NVc) {
+                    constexpr int NV = decltype(NVc)::value;    // the wave's subtile count as a constant (see conv1)
+                    struct Frag { bf16x8 bh, bl; u32x2 e[NV > 0 ? NV : 1][4]; };
+                    // fragments of step (slice s, tap tp, K16 step kk); `rows` = byte offset of the step's 8 rows within the chunk's slot
+                    auto load_frag = [&](Frag& f, int s, int tp, int kk, unsigned rows) {
+                        if constexpr (NV > 0) {
+                            const int ty = (tp * 11) >> 5;                                   // tp / 3 for tp < 9
+                            const int r = ((tmask >> tp) & 1u) ? pm + (ty - 1) * p.Wd + (tp - 3 * ty - 1) : -1;
+                            const unsigned char* hrow = r >= 0 ? s_act + (size_t)s * HW * 128 + r * 128 : smem + S_ZERO_OFF;
+                            const unsigned rx = r >= 0 ? ((unsigned)r >> 1) & 7u : 0u;
+                            const unsigned sl = 2u * (2u * kk + h);
+                            f.bh = *reinterpret_cast<const bf16x8*>(hrow + ((sl ^ rx) << 4));
+                            f.bl = *reinterpret_cast<const bf16x8*>(hrow + (((sl + 1) ^ rx) << 4));
+                            const unsigned char* w0 = smem + G.ring_off + coff + rows + a_rd;      // the four k-pair rows of this lane's half
+                            const unsigned char* w1 = w0 + W2ROW;
+                            const unsigned char* w2 = w1 + W2ROW;
+                            const unsigned char* w3 = w2 + W2ROW;
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) {
+                                f.e[i][0] = *reinterpret_cast<const u32x2*>(w0 + i * 1024);
+                                f.e[i][1] = *reinterpret_cast<const u32x2*>(w1 + i * 1024);
+                                f.e[i][2] = *reinterpret_cast<const u32x2*>(w2 + i * 1024);
+                                f.e[i][3] = *reinterpret_cast<const u32x2*>(w3 + i * 1024);
+                            }
+                        }
+                    };
+                    auto mfma_frag = [&](const Frag& f) {
+                        if constexpr (NV > 0) {
+                            bf16x8 ah[NV], al[NV];
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) {
+                                const u32x4 ahu = {f.e[i][0][0], f.e[i][1][0], f.e[i][2][0], f.e[i][3][0]};
+                                const u32x4 alu = {f.e[i][0][1], f.e[i][1][1], f.e[i][2][1], f.e[i][3][1]};
+                                ah[i] = __builtin_bit_cast(bf16x8, ahu); al[i] = __builtin_bit_cast(bf16x8, alu);
+                            }
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], f.bh, acc[i], 0, 0, 0);
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], f.bl, acc[i], 0, 0, 0);
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], f.bh, acc[i], 0, 0, 0);
+                        }
+                    };
+                    auto sync_issue = [&]() {          // the next chunk has landed for every wave; every wave has read the current one
+                        ST(ta)
+                        wait_vm_rt(ipc * (D - 2));
+                        lds_barrier();
+                        ST(tb)
+                        ST_ADD(wt[1], ta, tb)
+                        issue();
+                        coff += slotB; if (coff == ring_bytes) coff = 0;
+                    };
+                    Frag f0, f1;
+                    wait_vm_rt(ipc * (D - 1));                   // chunk 0
+                    lds_barrier();
+                    load_frag(f0, 0, 0, 0, 0);
 #pragma unroll 1
-                for (int s = 0; s < nsub; ++s) {
+                    for (int s = 0; s < nsub; ++s) {
 #pragma unroll 1
-                    for (int tp = 0; tp < 9; ++tp) {
-                        const int tn = tp == 8 ? 0 : tp + 1, sn = tp == 8 ? (s + 1 < nsub ? s + 1 : s) : s;   // the (slice, tap) after this one
-                        if (nks == 1) sync_issue();
-                        load_frag(f1, s, tp, 1, nks == 2 ? half_rows : 0u);
-                        mfma_frag(f0);
-                        sync_issue();
-                        load_frag(f0, sn, tn, 0, 0u);
-                        mfma_frag(f1);
+                        for (int tp = 0; tp < 9; ++tp) {
+                            const int tn = tp == 8 ? 0 : tp + 1, sn = tp == 8 ? (s + 1 < nsub ? s + 1 : s) : s;   // the (slice, tap) after this one
+                            if (nks == 1) sync_issue();
+                            load_frag(f1, s, tp, 1, nks == 2 ? half_rows : 0u);
+                            mfma_frag(f0);
+                            sync_issue();
+                            load_frag(f0, sn, tn, 0, 0u);
+                            mfma_frag(f1);
+                        }
                     }
+                };
+                ST(ta)
+                switch (active ? nv : 0) {
+                    case 0: run(std::integral_constant<int, 0>{}); break;
+                    case 1: run(std::integral_constant<int, 1>{}); break;
+                    case 2: run(std::integral_constant<int, 2>{}); break;
+                    case 3: run(std::integral_constant<int, 3>{}); break;
+                    default: run(std::integral_constant<int, 4>{}); break;
                 }
                 ST(tb)
                 ST_ADD(ct[1], ta, tb)

@@ -56,6 +56,9 @@ __device__ unsigned long long* g_small_trace = nullptr;
 
 namespace {
 
+#ifndef SM_FORCE_K16
+#define SM_FORCE_K16 0
+#endif
 constexpr int S_LDS = 160 * 1024;
 constexpr int S_KIDX_BYTES = 2304;                    // int[W + 32], W <= 512
 constexpr int S_ZERO_OFF = S_KIDX_BYTES;              // one all-zero row of 128 B (out-of-image taps)
@@ -146,7 +149,8 @@ __host__ __device__ inline SmallGeom small_geom(int HW, int nsub) {
     g.space = S_LDS - g.ring_off;
     g.w2row = (nsub > 0 ? (nsub + 3) / 4 : 1) * 1024;                // bytes of one staged k-pair row of W2: nsub * 32 entries of 8 B, whole DMA instructions
     const int slot32 = 16 * g.w2row;
-    if (2 * slot32 <= g.space) { g.nks2 = 2; g.slot2 = slot32; g.d2 = g.space / slot32 < 3 ? g.space / slot32 : 3; }
+    // K32 chunks when three of them fit, else K16 chunks in a deeper ring (measured: two K32 slots are behind four K16 slots)
+    if (SM_FORCE_K16 == 0 && 3 * slot32 <= g.space) { g.nks2 = 2; g.slot2 = slot32; g.d2 = g.space / slot32 < 3 ? g.space / slot32 : 3; }
     else { g.nks2 = 1; g.slot2 = 8 * g.w2row; g.d2 = g.space / g.slot2 < 4 ? g.space / g.slot2 : 4; }
     g.d3 = g.space / 32768 < 3 ? g.space / 32768 : 3;
     return g;

@@ -81,6 +81,9 @@ class Calibration:
     idx_s: float = 30e-6              # index-list build per spatial block (two launches over the mask), beyond its bytes
     grouped_eff: float = 0.5          # k_grouped16_img: fraction of 8 TB/s on its rows in + rows out
     rows_fixed_s: float = 0.3e-3      # per-forward residual of the packed-row workloads (stem aside)
+    # -- the one-launch small-map bottleneck (k_smallmap, stage 4; measured on the kernel alone: tools/bench_small.py at keep 0.5 / 0.62 / 0.75)
+    small_step_s: float = 0.93e-6     # one K16 step of a workgroup (barrier + DMA burst + fragment reads; its 7-12 MFMAs hide under it)
+    small_single_slot: float = 1.55   # ... x this when the image's channel list leaves a single ring slot (more than 480 of 512 channels kept)
     source: str = "defaults"
 
     @staticmethod
@@ -270,6 +273,22 @@ class Predictor:
             t += self.dense_rows(batch * px, b.cin, b.cout, 4.0 * batch * px * b.cin, 4.0 * batch * px * b.cout)
         return t + 2 * self.cal.launch_s                          # GAP + masker MLP launches
 
+    def smallmap_block(self, b: BlockShape, batch: int, density: float) -> float:
+        """A stride-1 identity block on a map of <= 64 pixels as ONE launch, one workgroup per image (ldn_bottleneck_smallmap): the
+        workgroup walks cin / 16 K16 steps of conv1, 9 Kp / 16 of the 3x3 and (cout / 512) Kp / 16 of conv3 (Kp = the image's list padded
+        to 32); a step costs the same whatever its MFMA count at these sizes (instruction issue and the per-step barrier bound it)."""
+        G = b.width // b.gran
+        kp = expected_padded_channels(G, b.gran, density)
+        steps = b.cin / 16.0 + (9.0 + math.ceil(b.cout / 512.0)) * kp / 16.0
+        t_wg = steps * self.cal.small_step_s * (self.cal.small_single_slot if kp > 480 else 1.0) + 2 * self.cal.phase_cost_s
+        return math.ceil(batch / self.hw.cus) * t_wg + 2 * self.cal.launch_s        # + the masker's MLP launch
+
+    @staticmethod
+    def smallmap_fits(b: BlockShape) -> bool:
+        """laud_resnet.Bottleneck._smallmap_eligible / ldn_bottleneck_smallmap_fits for the ResNet shapes."""
+        return (b.stride == 1 and not b.downsample and b.cin == b.cout and b.h * b.w <= 64 and b.width <= 512 and b.width % 64 == 0
+                and 2432 + (b.width // 32) * b.h * b.w * 128 + 32768 <= 160 * 1024 and b.gran % 2 == 0)
+
     def stem(self, batch: int, input_hw=(224, 224)) -> float:
         """k_stem: conv 7x7 (K padded to 176) on 17x15-pixel tiles recomputed 1.14x + pooled output."""
         px = batch * (input_hw[0] // 2) * (input_hw[1] // 2)
@@ -288,7 +307,10 @@ class Predictor:
         while i < len(blocks):
             s, b = blocks[i]
             d = density[s]
-            if b.h * b.w <= 64:                                                  # dense execution (stage 4 at 224)
+            if b.h * b.w <= 64 and self.smallmap_fits(b):                        # one launch per block (stage 4, blocks 2 and 3)
+                t = self.smallmap_block(b, batch, d)
+                kind = "smallmap"
+            elif b.h * b.w <= 64:                                                # dense execution (stage 4's first block at 224)
                 t = self.dense_block(b, batch)
                 kind = "dense"
             elif b.downsample or b.stride != 1:

@@ -56,10 +56,11 @@ def main():
     chain_res(f1.x)
 
     # ---- channel workload, stage 2: dense-kernel efficiency and the per-forward residual on the step time
+    # (+ the per-step cost of the one-launch stage-4 blocks and the penalty of their single-slot rings, keep 1.0)
     def step_res(v):
-        cal.dense_mfma_eff, cal.fixed_s = v[0], v[1] * 1e-3
+        cal.dense_mfma_eff, cal.fixed_s, cal.small_step_s, cal.small_single_slot = v[0], v[1] * 1e-3, v[2] * 1e-6, v[3]
         return [(predict(P, "channel", p) - p["ms"]) / p["ms"] for p in data["channel"] if is_fit(p)]
-    f2 = least_squares(step_res, [0.28, 0.2], bounds=([0.15, 0.0], [0.5, 2.0]))
+    f2 = least_squares(step_res, [0.28, 0.2, 0.93, 1.55], bounds=([0.15, 0.0, 0.6, 1.0], [0.5, 2.0, 1.3, 2.5]))
     step_res(f2.x)
 
     # ---- packed-row workloads: one set of row-kernel constants for spatial + layer (+ RegNet with its grouped-conv efficiency)
@@ -89,12 +90,12 @@ def main():
                           max_abs_rel_err_out_of_sample=max(abs(r["rel_err"]) for r in rows if not r["used_for_fit"]))
     consts = {k: getattr(cal, k) for k in ("cu_mfma_eff", "act_hbm_eff", "cu_l2_bytes_per_s", "phase_cost_s", "dense_mfma_eff", "hbm_eff", "co_resident_gain",
                                             "launch_s", "fixed_s", "rows_cu_eff", "narrow_alpha", "tile_fixed_s", "rows_hbm_eff", "idx_s",
-                                            "grouped_eff", "rows_fixed_s")}
+                                            "grouped_eff", "rows_fixed_s", "small_step_s", "small_single_slot")}
     out = dict(constants=consts,
                fitted=["cu_mfma_eff", "act_hbm_eff", "cu_l2_bytes_per_s", "dense_mfma_eff", "fixed_s", "rows_cu_eff", "narrow_alpha", "tile_fixed_s", "rows_hbm_eff",
-                       "grouped_eff", "rows_fixed_s"],
+                       "grouped_eff", "rows_fixed_s", "small_step_s", "small_single_slot"],
                fit_keeps=list(FIT), held_out_keeps=[0.4, 0.62, 0.9],
-               source="profiles/r03_density_sweep_{channel,spatial,layer,regnet}.jsonl (tools/density_sweep.sh, one MI355X, one gpurun call)",
+               source="profiles/r03_density_sweep_{channel,spatial,layer,regnet}.jsonl (tools/density_sweep.sh on one MI355X; the channel sweep redone after the one-launch stage-4 blocks)",
                summary=summary, tables=tables)
     json.dump(out, open(OUT, "w"), indent=1)
     print(json.dumps(dict(constants=consts, summary=summary), indent=1))

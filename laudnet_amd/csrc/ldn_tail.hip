@@ -731,6 +731,32 @@ __device__ __forceinline__ void wait_vm_rt(int n) {   // counted wait with a run
     }
 }
 
+// NF consecutive 1 KB pieces of a ring slot with ONE address set-up: piece f = sbase (wave-uniform) + vo[f] (per-lane byte offset, biased by
+// the caller with (3 - f) * 1024 against sbase - 3072) -> LDS lds_base + f * 1024 + lane * 16.  The instruction offset of
+// global_load_lds_dwordx4 moves the LDS destination as well as the global source (tools/experiments/dma_offset.hip).
+template <int NF> __device__ __forceinline__ void dma16_pieces(const unsigned (&vo)[4], const void* sbase, unsigned lds_base) {
+    unsigned keep;
+    if constexpr (NF == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vo[0]), "s"(sbase), "s"(lds_base) : "memory");
+    else if constexpr (NF == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vo[0]), "v"(vo[1]), "s"(sbase), "s"(lds_base) : "memory");
+    else if constexpr (NF == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %3, %4 offset:2048\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "s"(sbase), "s"(lds_base) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(sbase), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ const void* uniform_cptr(const void* v) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+}
+
 constexpr int H_XROWS = 256;                          // rows of the x tile of a ring slot (pixels of the block, padded)
 
 template <int NS>
@@ -769,32 +795,40 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
     const bool active = wave * 32 < npix;
     const int per_chunk = (active ? 4 : 0) + nw;                         // this wave's DMA instructions per chunk (4 = its 32 x rows)
 
-    // DMA of chunk c into slot c % D.  Wave w moves x rows [32 w, 32 w + 32) and weight rows {64 i + 8 w .. + 7}.
-    // one instruction = 8 rows x 128 B: lane = (row r0 + (lane >> 3), physical slot lane & 7); XOR swizzle on the SOURCE address
+    // DMA of chunk c into slot c % D.  Wave w moves x rows [32 w, 32 w + 32) and weight rows {64 i + 8 w .. + 7} (i < nw).
+    // one instruction = 8 rows x 128 B: lane = (row r0 + (lane >> 3), physical slot lane & 7); XOR swizzle on the SOURCE address.
+    // Round 3: a wave's pieces are CONSECUTIVE kilobytes of the slot (the weight rows are staged wave-major: piece i of wave w is the 1 KB
+    // block w * nw + i) and take one address set-up per group (dma16_pieces): the per-lane source offsets are fixed for the whole K loop,
+    // the chunk only moves the scalar base.  Rows beyond the block's pixels / the image's list fetch existing rows instead of a zero line:
+    // those pixels are never stored, and the accumulator columns beyond the list meet zero epilogue tables.
+    unsigned xo[4], wo[4];
+    {
+        const int r8 = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wave * 32 + i * 8 + r8;
+            const int ls = (lane & 7) ^ ((r >> 1) & 7);
+            xo[i] = (unsigned)((min(r, npix - 1) * p.ldx + ls * 4) * 4 + (3 - i) * 1024);
+            const int rw = i * 64 + wave * 8 + r8;
+            const int lw = (lane & 7) ^ (r8 >> 1);
+            const int ch = s_nidx[min(rw, max(Nb, 1) - 1)];
+            wo[i] = (unsigned)(max(ch, 0) * p.cin * 4 + lw * 16 + (3 - i) * 1024);
+        }
+    }
+    const unsigned char* const xbase = reinterpret_cast<const unsigned char*>(p.x + row0 * p.ldx) - 3072;
+    const unsigned char* const wbase = p.w1s - 3072;
     auto dma_chunk = [&](int c) {
         const unsigned slot = lds_ring + (c % D) * slot_bytes;
-        if (active) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = wave * 32 + i * 8 + (lane >> 3);
-                const int ls = (lane & 7) ^ ((r >> 1) & 7);
-                const float* src = r < npix ? p.x + (row0 + r) * p.ldx + c * 32 + ls * 4 : g_tail_zero;
-                dma16(src, slot + (wave * 32 + i * 8) * 128);
-            }
-        }
-        for (int i = 0; i < nw; ++i) {
-            const int r = i * 64 + wave * 8 + (lane >> 3);
-            const int ls = (lane & 7) ^ ((r >> 1) & 7);
-            const int ch = s_nidx[min(r, W + 31)];
-            const unsigned char* src = ch >= 0 ? p.w1s + ((long)ch * (p.cin / 8) + c * 4) * 32 + ls * 16
-                                               : reinterpret_cast<const unsigned char*>(g_tail_zero);
-            dma16(src, slot + (xrows + i * 64 + wave * 8) * 128);
-        }
+        const int cc = min(c, nchunks - 1);              // chunks beyond the K loop: the last one again (keeps the per-iteration DMA count constant)
+        if (active) dma16_pieces<4>(xo, uniform_cptr(xbase + (long)cc * 128), __builtin_amdgcn_readfirstlane(slot + wave * 32 * 128));
+        const void* wb = uniform_cptr(wbase + (long)cc * 128);
+        const unsigned wl = __builtin_amdgcn_readfirstlane(slot + (xrows + wave * nw * 8) * 128);
+        if (nw == 1) dma16_pieces<1>(wo, wb, wl);
+        else if (nw == 2) dma16_pieces<2>(wo, wb, wl);
+        else if (nw == 3) dma16_pieces<3>(wo, wb, wl);
+        else dma16_pieces<4>(wo, wb, wl);
     };
-    auto dma_dummy = [&](int c) {   // keeps the per-iteration DMA count constant at the end of the K loop
-        const unsigned slot = lds_ring + (c % D) * slot_bytes;
-        for (int i = 0; i < per_chunk; ++i) dma16(g_tail_zero, slot + (xrows + (i % nw) * 64 + wave * 8) * 128);
-    };
+    auto dma_dummy = [&](int c) { dma_chunk(c); };
 
     f32x16 acc[NS];
 #pragma unroll
@@ -804,7 +838,10 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
 
     for (int c = 0; c < D - 1; ++c) { if (c < nchunks) dma_chunk(c); else dma_dummy(c); }
     const unsigned xrow = (unsigned)(wave * 32 + l31), xsw = (xrow >> 1) & 7u;
-    const unsigned wsw = ((unsigned)l31 >> 1) & 7u;      // weight row 32 j + l31: (row >> 1) & 7 == (l31 >> 1) & 7
+    const unsigned wsw = ((unsigned)l31 >> 1) & 3u;      // weight rows are swizzled by their row WITHIN the 8-row piece
+    // list row n = 32 j + l31 is row n % 8 of piece n / 64 of wave (n % 64) / 8: LDS row ((4 (j & 1) + (l31 >> 3)) * nw + (j >> 1)) * 8 + (l31 & 7)
+    const unsigned wrow_e = (unsigned)((((l31 >> 3)) * nw * 8 + (l31 & 7)) * 128);            // even j
+    const unsigned wrow_o = (unsigned)((((4 + (l31 >> 3))) * nw * 8 + (l31 & 7)) * 128);      // odd j
     for (int c = 0; c < nchunks; ++c) {
         wait_vm_rt(per_chunk * (D - 2));     // chunk c has landed; the D - 2 chunks issued after it may still fly
         lds_barrier();                       // ... for every wave; every wave has left chunk c - 1
@@ -836,12 +873,14 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
         bf16x8 a0h, a0l, a1h, a1l;
         const unsigned sl0 = 2u * h, sl1 = 4u + 2u * h;
         auto frag0 = [&](int j) {
-            a0h = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl0 ^ wsw) << 4));
-            a0l = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl0 + 1) ^ wsw) << 4));
+            const unsigned char* wr = ws + ((j & 1) ? wrow_o : wrow_e) + (j >> 1) * 1024;
+            a0h = *reinterpret_cast<const bf16x8*>(wr + ((sl0 ^ wsw) << 4));
+            a0l = *reinterpret_cast<const bf16x8*>(wr + (((sl0 + 1) ^ wsw) << 4));
         };
         auto frag1 = [&](int j) {
-            a1h = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + ((sl1 ^ wsw) << 4));
-            a1l = *reinterpret_cast<const bf16x8*>(ws + (32 * j + l31) * 128 + (((sl1 + 1) ^ wsw) << 4));
+            const unsigned char* wr = ws + ((j & 1) ? wrow_o : wrow_e) + (j >> 1) * 1024;
+            a1h = *reinterpret_cast<const bf16x8*>(wr + ((sl1 ^ wsw) << 4));
+            a1l = *reinterpret_cast<const bf16x8*>(wr + (((sl1 + 1) ^ wsw) << 4));
         };
 #define LDN_HEAD_STEP(J)                                                                                  \
         frag1(J);                                                                                         \

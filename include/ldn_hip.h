@@ -140,7 +140,7 @@ int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps
                         int ldo, const float* post_sub, const float* chan_mask, int rows_per_image, int shift_classes,
                         const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride, const float* ln_stats,
                         const float* ln_c1, void* stream);
-/* stats[r] = {mean, 1 / sqrt(biased variance + eps)} of row r of x [rows][ld >= C] (nn.LayerNorm's statistics), C % 4 == 0, C <= 1024 */
+/* stats[r] = {mean, 1 / sqrt(biased variance + eps)} of row r of x [rows][ld >= C] (nn.LayerNorm's statistics), C % 4 == 0, C <= 2048 */
 int ldn_row_stats(const float* x, int ld, int rows, int C, float eps, float* stats, void* stream);
 
 /* ---- a2: Masker_channel_MLP.forward, eval branch (models/utils.py:113-131) + index build ----

@@ -50,9 +50,14 @@ class TokenSkipBlock(nn.Module):
                 def after_ln(lin, ln):
                     w = lin.weight.detach().double()
                     g, be = ln.weight.detach().double(), ln.bias.detach().double()
-                    wg = w * g.view(1, -1)
-                    return (wg.float().reshape(lin.out_features, 1, lin.in_features).contiguous().to(dev),
-                            (w @ be + lin.bias.detach().double()).float().contiguous().to(dev), wg.sum(dim=1).float().contiguous().to(dev))
+                    wg = (w * g.view(1, -1)).float()
+                    # c1 multiplies the row MEAN and cancels against the GEMM's large term when |mean| >> std: it must be the row sum
+                    # of the weights the kernel actually multiplies with (the bf16 hi + lo split of wg, ~16 mantissa bits), not of
+                    # the exact products -- the mismatch would be amplified by rstd
+                    hi, lo = ops._hi_lo(wg)
+                    c1 = (hi.double() + lo.double()).sum(dim=1)
+                    return (wg.reshape(lin.out_features, 1, lin.in_features).contiguous().to(dev),
+                            (w @ be + lin.bias.detach().double()).float().contiguous().to(dev), c1.float().contiguous().to(dev))
                 self._w = (key, after_ln(self.qkv, self.norm1), plain(self.proj), after_ln(self.fc1, self.norm2), plain(self.fc2))
         return self._w[1:]
 

@@ -414,10 +414,10 @@ __global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, 
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const float* xr = x + (size_t)r * ld;
-    f32x4 v[4];
+    f32x4 v[8];     // C <= 2048 (ViT-H: 1280)
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         const int c = (i * 64 + lane) * 4;
         v[i] = c < C ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, 
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < C) {
 #pragma unroll
@@ -512,7 +512,7 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
 
 extern "C" int ldn_row_stats(const float* x, int ld, int rows, int C, float eps, float* stats, void* stream) {
     LDN_REQUIRE(x && stats, "ldn_row_stats: null pointer");
-    LDN_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 1024 && ld >= C && ld % 4 == 0, "ldn_row_stats: C must be a multiple of 4, at most 1024 (got %d), ld >= C", C);
+    LDN_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 2048 && ld >= C && ld % 4 == 0, "ldn_row_stats: C must be a multiple of 4, at most 2048 (got %d), ld >= C", C);
     LDN_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)stats % 8 == 0, "ldn_row_stats: pointers must be 16 / 8-byte aligned");
     if (rows == 0) return LDN_OK;
     hipLaunchKernelGGL(ldn::k_row_stats, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, rows, C, eps, stats);

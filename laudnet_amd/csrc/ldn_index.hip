@@ -797,6 +797,11 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
     }
     const long jobs = (long)B * (pooled ? S * S : Hi * Wi);
     LDN_REQUIRE(!carry_mask || work, "ldn_spatial_masker: carry_mask needs the work buffer of the previous call");
+    // The pooling bins floor(i*H/S) .. ceil((i+1)*H/S) overlap when H % S != 0 while the previous block's conv3 writes pixels by the
+    // nearest mapping floor(y*S/H): a bin can then hold pixels of a NEIGHBOURING patch that block did rewrite, so an untouched patch's
+    // stored means are stale.  The carry is only exact on even grids.
+    LDN_REQUIRE(!carry_mask || !pooled || (Hi % S == 0 && Wi % S == 0),
+                "ldn_spatial_masker: the patch carry needs H %% S == 0 and W %% S == 0 (got %dx%d, S=%d)", Hi, Wi, S);
     LDN_REQUIRE((uintptr_t)work % 16 == 0, "ldn_spatial_masker: work must be 16-byte aligned");
     hipLaunchKernelGGL(k_spatial_masker, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, B, Hi, Wi, C, w, bias, g, S, mask, logits, pooled && S > 1 ? work : nullptr,

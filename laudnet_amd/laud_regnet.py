@@ -340,7 +340,13 @@ class ResBottleneckBlock(_PrepCache):
             resid, out2d = x2d, torch.relu(x2d)
         if both:   # c: gathered input channels (per image) x packed active pixels (per output-channel group)
             for g, (ig, cs_) in enumerate(groups):
-                wck = p["wc_k"] if G == 1 else p.setdefault(f"wc_k_grp{g}of{G}", p["wc_k"][:, :, cs_].contiguous())
+                if G == 1:
+                    wck = p["wc_k"]
+                else:   # sliced once per module (setdefault would evaluate the slice + copy on every forward)
+                    gk = f"wc_k_grp{g}of{G}"
+                    if gk not in p:
+                        p[gk] = p["wc_k"][:, :, cs_].contiguous()
+                    wck = p[gk]
                 ops.conv_packed(h_b2d, wck, p["sc"][cs_], p["tc"][cs_], out2d[:, cs_], B=B, row_prefix=ig.pre3, m_cap=Ho * Wo, a_map=ig.idx3,
                                 taps=1, out_map=ig.idx3, k_idx=idx, k_cnt=cnt, kgran=gran, relu=1, residual2d=resid[:, cs_])
             f.last_channel_mask = cmask

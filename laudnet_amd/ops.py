@@ -100,14 +100,16 @@ def spatial_masker(x_nhwc, weight, bias, groups, mask_size, want_logits=False, c
     # a carry is only taken from a masker call on a tensor of the SAME shape (the partial sums are [B][splits][C] of that shape: a
     # byte count alone can coincide between a stride-2 block's input and the next block's input)
     shape_key = (B, H, W, C, mask_size)
-    if (carry is not None and nbytes and carry[0] is not None and len(carry) > 2 and tuple(carry[2]) == shape_key
-            and carry[0].numel() * 4 == nbytes and carry[0].device == x_nhwc.device):
+    if (carry is not None and nbytes and carry[0] is not None and len(carry) > 2 and carry[2] is not None
+            and tuple(carry[2]) == shape_key and carry[0].numel() * 4 == nbytes and carry[0].device == x_nhwc.device):
         work = carry[0]
         if mask_size == 1:
             prefix = _i32c(carry[1], "carry_prefix")
         else:   # patch masks: carry[3] = the [B, S, S] patch mask the previous block executed
             cmask = _f32c(carry[3], "carry_mask") if len(carry) > 3 and carry[3] is not None else None
-            if cmask is None or tuple(cmask.shape) != (B, sy, sx):
+            # uneven grids (H % S != 0): adaptive-pool bins overlap the nearest-mapped regions of neighbouring patches, so an
+            # untouched patch's stored means can be stale -- no carry there (the library refuses it too)
+            if cmask is None or tuple(cmask.shape) != (B, sy, sx) or H % mask_size or W % mask_size:
                 work, cmask = _work(nbytes, x_nhwc.device), None
     else:
         work = _work(nbytes, x_nhwc.device) if (mask_size == 1 or return_work) else None
@@ -216,9 +218,14 @@ USE_DENSE_KERNEL = os.environ.get("LDN_DENSE_KERNEL", "1") != "0"   # tuning swi
 
 def split_rows_weight(w):
     """[cout, 1, cin] (or [cout, cin]) fp32 -> [cout][cin/8][8 hi | 8 lo] bf16, cached until the tensor changes."""
-    key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device))
+    ident = (w.data_ptr(), tuple(w.shape), str(w.device))
+    key = ident + (w._version,)
     hit = _SPLIT_CACHE.get(key)
     if hit is None:
+        # a long-lived weight edited in place (BN re-estimation, fine-tuning loops that call the eval path) bumps _version at every
+        # edit: drop the copies of its older versions, or the cache grows by one entry per edit until the tensor dies
+        for stale in [k for k in _SPLIT_CACHE if k[:3] == ident]:
+            _SPLIT_CACHE.pop(stale, None)
         with torch.no_grad():
             w2 = w.detach().float().reshape(w.shape[0], -1)
             hit = _SPLIT_CACHE[key] = (pack_w1_split(w2),)

@@ -65,3 +65,9 @@ def seeded_randn(shape, seed: int) -> torch.Tensor:
 def seeded_bernoulli(shape, p: float, seed: int) -> torch.Tensor:
     u = torch.rand(tuple(shape), generator=torch.Generator().manual_seed(seed))
     return (u < p).to(torch.float32)
+
+
+def damp_residual_branches(sd: dict, factor: float = 0.3) -> dict:
+    """Scale the last BN of every residual branch (ResNet bn3 / LAD-RegNet conv c's BN) so that tens of seeded-random blocks keep
+    O(1) activations and logits (what zero_init_residual is for); the recipe of bench.py and tests/test_hip_fullsize.py."""
+    return {k: (v * factor if k.endswith("bn3.weight") or k.endswith(".f.c.1.weight") else v) for k, v in sd.items()}

@@ -68,6 +68,37 @@ def test_token_skip_block_vs_oracle(B, L, dim, heads):
     assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
 
 
+def test_token_skip_block_large_token_mean_and_wide_dim():
+    """the LayerNorm fold rstd (x . w' - mean c1) cancels two large terms when |mean| >> std -- c1 is the row sum of
+    the SPLIT weights the kernel multiplies with, so tokens with mean / std = 30 stay within 1e-3; dim 1280 (ViT-H: ldn_row_stats
+    beyond 1024 columns) runs instead of raising."""
+    from laudnet_amd import ops
+    from laudnet_amd.adavit import TokenSkipBlock
+    for dim, heads, off in ((384, 6, 30.0), (1280, 20, 3.0)):
+        B, L = 2, 48
+        ref = AR.TokenSkipBlockRef(dim, heads).eval()
+        torch.manual_seed(9)
+        for p_ in ref.parameters():
+            if p_.dim() > 1:
+                torch.nn.init.normal_(p_, std=0.05)
+        hip = TokenSkipBlock(dim, heads).eval()
+        hip.load_state_dict(ref.state_dict())
+        hip = hip.to(DEV)
+        x = seeded_randn((B, L, dim), 23)
+        x[:, ::2] += off
+        keep = _keep(B, L, 0.6, 24)
+        with torch.no_grad():
+            want = ref.double()(x.double(), keep.double()).float()
+        ops.set_math_mode("bf16x3")
+        try:
+            with torch.no_grad():
+                got = hip(x.to(DEV), keep.to(DEV)).cpu()
+        finally:
+            ops.set_math_mode("fp32")
+        err = (got - want).abs().max().item()
+        assert err < 1e-3 * max(1.0, want.abs().max().item()), (dim, err)
+
+
 def test_token_skip_trunk_deit_s_shape():
     from laudnet_amd import ops
     from laudnet_amd.adavit import TokenSkipViT

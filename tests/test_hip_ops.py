@@ -157,6 +157,37 @@ def test_spatial_masker(ops, cin, g, S, hin):
     assert not bool((differs & (margin > 1e-4)).any()), "mask decisions may differ only at near-ties"
 
 
+@pytest.mark.parametrize("hin,S", [(14, 3), (52, 7), (14, 7), (28, 7)])
+def test_spatial_masker_patch_carry_uneven_grid(ops, hin, S):
+    """on an uneven grid (H % S != 0) the adaptive-pool bin of a patch overlaps pixels the nearest mapping gives to a
+    NEIGHBOURING patch.  A previous block that rewrote only the neighbour leaves the patch's own carry flag at 0 although its bin changed:
+    the carry must not be taken there (ops gates it, the library refuses it); on even grids it stays bit-identical to a fresh pass."""
+    import laudnet_amd._lib as L
+    cin, B = 16, 3
+    w = seeded_randn((2, cin), 3).to(DEV)
+    b = torch.zeros(2, device=DEV)
+    x0 = F.relu(seeded_randn((B, hin, hin, cin), 11)).to(DEV).contiguous()
+    _, lg0, work = ops.spatial_masker(x0, w, b, 1, S, want_logits=True, return_work=True)
+    # the "previous block" executed a checkerboard patch mask: rewrite exactly the pixels its conv3 would (nearest mapping)
+    pm = ((torch.arange(S)[:, None] + torch.arange(S)[None, :]) % 2).float().expand(B, S, S).contiguous()
+    iy = (torch.arange(hin) * S) // hin
+    pix = pm[:, iy][:, :, iy].to(DEV)                              # [B, H, W] nearest up-sampling (laud_resnet.py:106)
+    x1 = (x0 + 3.0 * pix[..., None]).contiguous()
+    _, want = ops.spatial_masker(x1, w, b, 1, S, want_logits=True)
+    _, got = ops.spatial_masker(x1, w, b, 1, S, want_logits=True, carry=(work, None, work.ldn_shape_key, pm.to(DEV)))
+    assert torch.equal(got, want), (hin, S)
+    assert not torch.equal(want, lg0)
+    if hin % S:
+        lib = L.load()
+        mask = torch.empty(B, 1, S, S, device=DEV)
+        rc = lib.ldn_spatial_masker(L.ptr(x1), B, hin, hin, cin, L.ptr(w), L.ptr(b), 1, S, L.ptr(mask), None, L.ptr(work), None,
+                                    L.ptr(pm.to(DEV)), L.stream_ptr())
+        assert rc != 0 and b"patch carry" in lib.ldn_last_error()
+    # a carry whose shape key was lost (work tensor re-created by .to() / .view) is dropped, not a TypeError
+    _, got2 = ops.spatial_masker(x1, w, b, 1, S, want_logits=True, carry=(work, None, None, pm.to(DEV)))
+    assert torch.equal(got2, want)
+
+
 def test_spatial_masker_tie_keeps(ops):
     x = torch.rand(1, 2, 2, 4, device=DEV)
     mask, _ = ops.spatial_masker(x, torch.zeros(2, 4, device=DEV), torch.zeros(2, device=DEV), 1, 2)

@@ -137,12 +137,16 @@ def test_block_index_lists(name):
 
 
 # ------------------------------------------------------------------ L3 full tiny models
-def _build_full(fx):
+def _build_full(fx, damp=None):
     layers = [3, 4, 6, 3] if fx["factory"] == "uni_resnet50" else [3, 4, 23, 3]
     model = TR.ResNetRef(layers, **fx["kw"]).eval()
     assert list(model.state_dict().keys()) == fx["keys"], "state_dict keys must equal the reference's"
-    assert sum(p.numel() for p in model.parameters()) == fx["n_params"]
-    model.load_state_dict(fill_state_dict(model.state_dict(), fx["seed"]))
+    assert "n_params" not in fx or sum(p.numel() for p in model.parameters()) == fx["n_params"]
+    sd = fill_state_dict(model.state_dict(), fx["seed"])
+    if damp is not None:
+        from fill import damp_residual_branches
+        sd = damp_residual_branches(sd, damp)
+    model.load_state_dict(sd)
     x = seeded_randn((fx["batch"], 3, fx["kw"]["input_size"], fx["kw"]["input_size"]), fx["x_seed"])
     return model, x
 
@@ -168,6 +172,28 @@ def test_full_models_injected(name):
     with torch.no_grad():
         got = model(x, 1.0)
     assert_tuple_close(got, fx["injected_run"], atol=2e-4, rtol=1e-5, what=name)
+
+
+# damped twins (tests/golden/make_full_damped_golden.py: bn3.weight * 0.3, logits O(1)): PLAIN absolute tolerances
+FULL_DAMPED = load_golden("full_tiny_damped.pt")
+
+
+@pytest.mark.parametrize("name", sorted(FULL_DAMPED))
+def test_full_models_damped(name):
+    fx = FULL_DAMPED[name]
+    model, x = _build_full(fx, damp=fx["damp"])
+    assert float(fx["injected_run"][0].abs().max()) < 5.0          # the recipe keeps the logits O(1)
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got, fx["masker_run"], atol=1e-5, rtol=1e-5, what=name + " masker run")
+    blocks = full_model_blocks(model)
+    masks = injected_masks_for(blocks, fx["batch"], fx["mask_seed"])
+    for bname, blk in blocks:
+        blk.forced_spatial_mask = masks[bname].get("spatial")
+        blk.forced_channel_mask = masks[bname].get("channel")
+    with torch.no_grad():
+        got = model(x, 1.0)
+    assert_tuple_close(got, fx["injected_run"], atol=1e-5, rtol=1e-5, what=name + " injected run")
 
 
 # ------------------------------------------------------------------ LAD-RegNet (torchvision containers restated)

@@ -140,6 +140,45 @@ def bench_adavit(args):
     print(json.dumps(result))
 
 
+SECONDARY = ("spatial", "layer", "regnet", "adavit")     # BASELINE.json configs[2], the layer-skip ResNet, configs[3] (per-GPU shard), configs[4]
+
+
+def run_secondary(args):
+    """The other BASELINE configs, timed in the SAME invocation as the headline: each one is this script
+    again (`--workload W --steps 10 --warmup 5 --brief`, its own process on the same GPU, after the headline's timed region and legs
+    are done) -- 5 warm-up + 10 timed forwards at batch 256, masks produced by the maskers in the timed region, the oracle's dense
+    emulation on the same GPU and the same-mask parity beside it.  Values are per-workload JSON lines reduced to the judged keys."""
+    import subprocess
+    out = {}
+    for w in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "10", "--warmup", "5", "--batch", str(args.batch), "--brief"]
+        t0 = time.perf_counter()
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in pr.stdout.splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            de = d.get("dense_emulation_gpu", {})
+            roof = d.get("roofline") or {}
+            out[w] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                      "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"].split(" ")[0],
+                      "mean_block_flops_ratio": d["config"].get("mean_block_flops_ratio", d["config"].get("kept_token_fraction")),
+                      "dense_emulation_gpu_ms_per_step": de.get("ms_per_step"),
+                      "realised_speedup_vs_dense_emulation": d.get("realised_speedup_vs_dense_emulation"),
+                      "max_abs_diff_vs_oracle_same_masks": de.get("max_abs_logit_diff_vs_hip_same_masks", de.get("max_abs_diff_vs_hip_same_masks")),
+                      "output_scale": de.get("logit_scale", de.get("output_scale")),
+                      "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches")} if roof else None,
+                      "parity": d["config"].get("parity", "pinned (reference-generated fixtures, tests/golden)"),
+                      "wall_s": round(time.perf_counter() - t0, 1)}
+            for k in ("roofline_rows_3x3", "mi355x_model", "predicted_speedup"):
+                if k in d:
+                    v = d[k]
+                    out[w][k] = ({kk: v.get(kk) for kk in ("bound", "achieved", "peak", "unit", "frac", "frac_executed", "frac_mfma_executed", "avg_launch_us", "launches")}
+                                 if k.startswith("roofline") else v)
+        except Exception as e:   # a secondary workload must never take the headline line down
+            out[w] = {"error": repr(e)[:300], "wall_s": round(time.perf_counter() - t0, 1)}
+    return out
+
+
 def two_floor(kernel, n, ms, flops, nbytes, mfma_mult):
     """HBM floor (algorithmic bytes at 8 TB/s) vs matrix floor (mfma_mult executed MFMA products per algorithmic product at
     the bf16 peak); `bound` = the larger floor, `frac` against it."""
@@ -454,6 +493,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-legs", action="store_true", help="product path only: no fp32 leg, no dense emulation, no CPU baseline (profiling)")
     ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--brief", action="store_true", help="product path + roofline leg + dense emulation with same-mask parity only (no fp32 / "
+                    "keep-1.0 / hipGraph legs, no decision audits, no CPU baseline): what the headline run uses for its `secondary` workloads")
+    ap.add_argument("--no-secondary", action="store_true", help="headline run: do not append the `secondary` dict (BASELINE configs 3-5 "
+                    "timed in the same invocation)")
     ap.add_argument("--graph", action="store_true", help="time the forward replayed as one hipGraph (same kernels, no launch "
                     "gaps; per-launch HIP events, hence the roofline, need eager launches -- the default run reports the graph "
                     "replay as the extra leg `hipgraph_replay`)")
@@ -468,6 +511,8 @@ def main():
     args = ap.parse_args()
     if args.no_legs:
         args.no_dense = args.no_cpu = True
+    if args.brief:
+        args.no_cpu = True
     if args.workload == "adavit":
         return bench_adavit(args)
 
@@ -725,7 +770,7 @@ def main():
 
     result["block_densities"] = block_densities
     result.setdefault("roofline", None)   # workloads whose hot kernels are not timed per launch (RegNet grouped conv, --graph)
-    if rank == 0 and world == 1 and not args.graph and not args.no_legs:
+    if rank == 0 and world == 1 and not args.graph and not args.no_legs and not args.brief:
         # same forward, same kernels, replayed as one hipGraph (launch gaps removed)
         try:
             from laudnet_amd.laud_resnet import GraphedForward
@@ -747,7 +792,7 @@ def main():
                 hb.last_channel_mask, hb.last_spatial_mask = cm, sm
         except Exception as e:   # informative only
             result["hipgraph_replay"] = {"error": repr(e)[:200]}
-    if rank == 0 and world == 1 and args.math != "fp32" and not args.no_legs and not args.graph:
+    if rank == 0 and world == 1 and args.math != "fp32" and not args.no_legs and not args.graph and not args.brief:
         # the same workload with fp32 operands on v_mfma_f32_32x32x2_f32 (reported beside the headline, not as `value`)
         def grab_masks():
             return [m for hb, _ in blocks_of(model) for m in (getattr(hb, "last_channel_mask", None), getattr(hb, "last_spatial_mask", None))
@@ -774,7 +819,8 @@ def main():
         ops.set_math_mode(args.math)
         out = step()   # leave the modules' last_*_mask in the headline mode for the same-mask parity leg below
         torch.cuda.synchronize()
-    if rank == 0 and world == 1 and not args.no_legs and not args.graph and (wl["p_channel"] is not None or wl["p_spatial"] is not None):
+    if (rank == 0 and world == 1 and not args.no_legs and not args.graph and not args.brief
+            and (wl["p_channel"] is not None or wl["p_spatial"] is not None)):
         # the SAME kernels with every unit kept (maskers recalibrated to keep 1.0): what the dynamic masks buy on this implementation
         try:
             calibrate_maskers(model, x, 1.0 if wl["p_channel"] is not None else None, 1.0 if wl["p_spatial"] is not None else None)
@@ -829,14 +875,15 @@ def main():
                 result["realised_speedup_vs_dense_emulation"] = result["value"] / (args.batch / dt)
                 if "fp32_mfma_mode" in result:   # like-for-like: fp32 multiply on both sides
                     result["realised_speedup_fp32_mode"] = result["fp32_mfma_mode"]["value"] / (args.batch / dt)
-                try:
-                    result["masker_decision_audit"] = audit_masker_decisions(model, refg, x, ops, args.math)
-                except Exception as e:   # informative only
-                    result["masker_decision_audit"] = {"error": repr(e)[:200]}
-                try:
-                    result["masker_decision_audit"]["free_running"] = free_running_decisions(model, refg, x, ops, args.math)
-                except Exception as e:   # informative only
-                    result["masker_decision_audit"]["free_running"] = {"error": repr(e)[:200]}
+                if not args.brief:
+                    try:
+                        result["masker_decision_audit"] = audit_masker_decisions(model, refg, x, ops, args.math)
+                    except Exception as e:   # informative only
+                        result["masker_decision_audit"] = {"error": repr(e)[:200]}
+                    try:
+                        result["masker_decision_audit"]["free_running"] = free_running_decisions(model, refg, x, ops, args.math)
+                    except Exception as e:   # informative only
+                        result["masker_decision_audit"]["free_running"] = {"error": repr(e)[:200]}
                 ref = ref.cpu()
             except Exception as e:  # the baseline is informative only
                 result["dense_emulation_gpu"] = {"error": repr(e)[:200]}
@@ -919,6 +966,9 @@ def main():
                 "calibration": P.cal.source}
         except Exception as e:   # informative only
             result["mi355x_model"] = {"error": repr(e)[:200]}
+    if (rank == 0 and world == 1 and args.workload == "channel" and not args.no_legs and not args.brief and not args.graph
+            and not args.no_secondary and args.keep is None and args.target_flops is None and args.math == "bf16x3"):
+        result["secondary"] = run_secondary(args)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -225,6 +225,23 @@ int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int
                         const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale2,
                         const float* shift2_tab, const float* post_sub2, const float* shift3, const float* residual,
                         int ldr, float* out, int ldo, float* colsum, void* stream);
+/* The same tail with the block's PROJECTION SHORTCUT folded into conv3 (laud_resnet.py:138-141 with a stride-1 1x1 downsample: the first
+ * block of stage 1, whose input is the stem's 64 channels): out = relu(w3 . u + wd . x + shift3d), shift3d = shift3 + bn_d's shift --
+ * 64 more K values of the same GEMM instead of a projection launch that writes the identity tensor and a tail that reads it back.
+ *   x_split  the block INPUT pre-split to bf16 hi / lo, written by ldn_bottleneck_head_split beside h1 (conv1 splits x anyway), in tiles
+ *            of 32 consecutive pixels of the flat [B*HW] batch: [tile][cin/16 K16 steps][2 octets of the step][hi | lo][32 pixels][8 bf16]
+ *            (a consumer wave's fragment load -- lane = pixel -- is then two contiguous 512-byte runs); ldn_x_split_bytes(B*HW, cin) bytes;
+ *   wd_pairs [cin/2][cout][8 B] = w3_pairs' layout of bn_d.scale * downsample.weight;
+ *   stride 1, width 64, cin 64 (ldn_bottleneck_tail_proj_fits says whether a map qualifies). */
+size_t ldn_x_split_bytes(size_t pixels, int cin);
+int ldn_bottleneck_head_split(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
+                              const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
+                              const float* post_sub1, void* h1_split, int ldh, void* x_split, void* stream);
+int ldn_bottleneck_tail_proj_fits(int H, int Wd, int width, int cin);
+int ldn_bottleneck_tail_proj(const void* h1_split, int ldh, int B, int H, int Wd, int width, const void* w2_pairs,
+                             const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale2,
+                             const float* shift2_tab, const float* post_sub2, const float* shift3d, const void* x_split,
+                             int cin, const void* wd_pairs, float* out, int ldo, float* colsum, void* stream);
 
 /* ---- a7 (channel mode, bf16x3): a WHOLE stride-1 identity-shortcut bottleneck on a SMALL map (H * Wd <= 64 pixels: the 7x7 maps of
  * stage 4, laud_resnet.py:115-144 on the image's active channels) as ONE launch, one workgroup per image: conv1 -> bn1 + ReLU ->
@@ -280,6 +297,11 @@ int ldn_bottleneck_chain(const float* x_in, float* x_work, int ldx, int B, int H
 size_t ldn_stem_weight_bytes(int cout);
 int ldn_stem_conv_pool(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout, float* out,
                        int Hp, int Wp, void* stream);
+/* The same launch also leaving the channel sums of its output for the first block's channel masker (a2): gap [B][ldn_stem_gap_splits(H, W)][cout]
+ * = per tile of 8 x 7 pooled pixels, the sum of out over the tile's pixels (ldn_channel_masker's gap_partial). */
+int ldn_stem_gap_splits(int H, int W);
+int ldn_stem_conv_pool_gap(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout,
+                           float* out, int Hp, int Wp, float* gap, void* stream);
 
 /* ---- a10: the static stem of LAD_RegNet.forward in eval mode (laud_regnet.py:59-71 SimpleStemIN: conv 3x3 stride 2 pad 1 -> BN ->
  * ReLU) as ONE launch, bf16x3 arithmetic: the image is read once, the output written once.

@@ -49,8 +49,14 @@ SIGNATURES = {
     "ldn_bottleneck_head": ([_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P], _I),
     "ldn_bottleneck_tail_splits": ([_I, _I, _I, _I], _I),
     "ldn_bottleneck_tail": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
+    "ldn_x_split_bytes": ([C.c_size_t, _I], C.c_size_t),
+    "ldn_bottleneck_head_split": ([_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P], _I),
+    "ldn_bottleneck_tail_proj_fits": ([_I, _I, _I, _I], _I),
+    "ldn_bottleneck_tail_proj": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P], _I),
     "ldn_stem_weight_bytes": ([_I], C.c_size_t),
     "ldn_stem_conv_pool": ([_P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P], _I),
+    "ldn_stem_gap_splits": ([_I, _I], _I),
+    "ldn_stem_conv_pool_gap": ([_P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P, _P], _I),
     "ldn_stem3_weight_bytes": ([_I], C.c_size_t),
     "ldn_stem3_conv": ([_P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P], _I),
     "ldn_packed_mha": ([_P, _I, _P, _P, _I, _I, _I, _I, C.c_float, _P, _I, _P], _I),

@@ -38,6 +38,7 @@ struct StemArgs {
     const float* shift;                               // [C]
     float* out; int C, Hc, Wc, Hp, Wp;                // NHWC [B, Hp, Wp, C]
     int tiles_y, tiles_x, ntiles;
+    float* gap;                                       // optional [B][tiles_y * tiles_x][C]: per-tile channel sums of out (the first block's channel masker)
 };
 
 template <int NSUB>   // C = 32 * NSUB
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
     unsigned char* const s_w = smem;                                           // weight fragments
     float* const s_patch = reinterpret_cast<float*>(smem + WF_BYTES);          // [40][105] (+ tail)
     float* const s_conv = s_patch + round_up(S_PATCH, 4);                      // [256][C]
+    float* const s_gs = s_conv + 256 * C;                                      // [2][8 waves][C] channel sums of the tile's pooled pixels (gap only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,10 +89,20 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
         }
     };
 
-    int t = blockIdx.x;
+    // the per-wave channel sums of tile t are combined (in wave order) and stored behind the NEXT barrier the loop has anyway
+    auto flush_gap = [&](int tprev, int slot) {
+        if (tid < C) {
+            float v = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) v += s_gs[(slot * 8 + w8) * C + tid];
+            p.gap[(size_t)tprev * C + tid] = v;     // tile index t = b * tiles_per_image + r: exactly the [B][tiles][C] layout
+        }
+    };
+    int t = blockIdx.x, it = 0;
     if (t < p.ntiles) fetch(t);
-    for (; t < p.ntiles; t += gridDim.x) {
+    for (; t < p.ntiles; t += gridDim.x, ++it) {
         __syncthreads();           // every wave has left the previous tile's patch and conv tile (and, first, the weights are staged)
+        if (p.gap && it > 0) flush_gap(t - (int)gridDim.x, (it - 1) & 1);
 #pragma unroll
         for (int i = 0; i < S_LOADS; ++i) {
             const int e = i * 512 + tid;
@@ -162,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
         int b, py0, px0;
         tile_origin(t, b, py0, px0);
         constexpr int QUADS = C / 4;
+        f32x4 gs = {0.f, 0.f, 0.f, 0.f};           // this thread's channel quad (tid % QUADS: 512 % QUADS == 0) summed over its pooled pixels
         for (int w = tid; w < S_PH * S_PW * QUADS; w += 512) {
             const int cq = w % QUADS, pp = w / QUADS;
             const int ly = pp / S_PW, lx = pp - ly * S_PW;
@@ -183,7 +196,23 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e] + sh[e], 0.f);
             __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(p.out + (((size_t)b * p.Hp + py) * p.Wp + px) * C + cq * 4));
+            gs += m;
         }
+        if (p.gap) {   // lanes with the same lane % QUADS hold the same channel quad: fold them, one LDS row per wave
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = gs[e];
+                if constexpr (QUADS <= 32) v += __shfl_xor(v, 32, 64);
+                if constexpr (QUADS <= 16) v += __shfl_xor(v, 16, 64);
+                if constexpr (QUADS <= 8) v += __shfl_xor(v, 8, 64);
+                gs[e] = v;
+            }
+            if (lane < QUADS) *reinterpret_cast<f32x4*>(s_gs + (((it & 1) * 8 + wave) * C) + lane * 4) = gs;
+        }
+    }
+    if (p.gap && it > 0) {
+        __syncthreads();
+        flush_gap(t - (int)gridDim.x, (it - 1) & 1);
     }
 }
 
@@ -191,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
 template <int NSUB>
 static int launch_stem(const StemArgs& a, int cus, hipStream_t st) {
     constexpr int C = 32 * NSUB;
-    const size_t lds = (size_t)NSUB * S_KSTEPS * 64 * 32 + (size_t)round_up(S_PATCH, 4) * 4 + (size_t)256 * C * 4;
+    const size_t lds = (size_t)NSUB * S_KSTEPS * 64 * 32 + (size_t)round_up(S_PATCH, 4) * 4 + (size_t)256 * C * 4 + (size_t)2 * 8 * C * 4;
     LDN_REQUIRE(lds <= 160 * 1024, "ldn_stem_conv_pool: %zu B of LDS exceed 160 KiB", lds);
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_stem<NSUB>), lds), "k_stem: cannot reserve %zu B of LDS", lds);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
@@ -331,8 +360,24 @@ using namespace ldn;
 
 extern "C" size_t ldn_stem_weight_bytes(int cout) { return cout > 0 && cout % 32 == 0 ? (size_t)(cout / 32) * S_KSTEPS * 64 * 32 : 0; }
 
+static int stem_conv_pool_impl(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout,
+                               float* out, int Hp, int Wp, float* gap, void* stream);
 extern "C" int ldn_stem_conv_pool(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout,
                                   float* out, int Hp, int Wp, void* stream) {
+    return stem_conv_pool_impl(x, B, H, W, w_frag, shift, cout, out, Hp, Wp, nullptr, stream);
+}
+extern "C" int ldn_stem_gap_splits(int H, int W) {
+    if (H < 1 || W < 1) return 0;
+    const int Hp = (((H - 1) / 2 + 1) - 1) / 2 + 1, Wp = (((W - 1) / 2 + 1) - 1) / 2 + 1;
+    return ceil_div(Hp, S_PH) * ceil_div(Wp, S_PW);
+}
+extern "C" int ldn_stem_conv_pool_gap(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout,
+                                      float* out, int Hp, int Wp, float* gap, void* stream) {
+    LDN_REQUIRE(gap && (uintptr_t)gap % 16 == 0, "ldn_stem_conv_pool_gap: gap must be a 16-byte aligned [B][ldn_stem_gap_splits(H, W)][cout] buffer");
+    return stem_conv_pool_impl(x, B, H, W, w_frag, shift, cout, out, Hp, Wp, gap, stream);
+}
+static int stem_conv_pool_impl(const float* x, int B, int H, int W, const void* w_frag, const float* shift, int cout,
+                               float* out, int Hp, int Wp, float* gap, void* stream) {
     LDN_REQUIRE(x && w_frag && shift && out, "ldn_stem_conv_pool: null pointer");
     LDN_REQUIRE(B > 0 && H > 0 && W > 0, "ldn_stem_conv_pool: bad geometry");
     LDN_REQUIRE(cout == 32 || cout == 64, "ldn_stem_conv_pool: cout must be 32 or 64 (got %d)", cout);
@@ -347,6 +392,7 @@ extern "C" int ldn_stem_conv_pool(const float* x, int B, int H, int W, const voi
     a.tiles_y = ceil_div(a.Hp, S_PH); a.tiles_x = ceil_div(a.Wp, S_PW);
     LDN_REQUIRE((long)B * a.tiles_y * a.tiles_x < (1L << 31), "ldn_stem_conv_pool: too many tiles");
     a.ntiles = B * a.tiles_y * a.tiles_x;
+    a.gap = gap;
     int cus = 0;
     if (ldn_device_cus(&cus) != LDN_OK || cus <= 0) cus = 256;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -40,7 +40,12 @@ struct TailArgs {
     float* colsum;                                    // optional [B][mblocks*8][cout]
     int rows_per_blk, mblocks;                        // output rows per workgroup, workgroups per image
     int slice_bytes;                                  // bytes of one h1 slice slot (multiple of 1024)
+    // PROJ (k_tail<2, 1, true>): the block's projection shortcut (laud_resnet.py:138-141, stride 1) as 64 more K values of conv3 --
+    // out = W3' h2 + Wd' x + (shift3 + shift_d): pxs = the block INPUT pre-split by conv1's launch (32-pixel tiles,
+    // ldn_bottleneck_head_split), pw = Wd with its BN scale folded in, in W3's pair layout [cin / 2][cout] x 8 B.  No residual tensor is read.
+    const unsigned char* pxs; const unsigned char* pw;
 };
+constexpr int T_PROJ_CIN = 64;            // input channels of a folded projection (stage 1 of the ResNets: the stem's 64 channels)
 
 __device__ __attribute__((aligned(16))) float g_tail_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -133,8 +138,9 @@ constexpr int T_W2_SLOTS = 3;
 
 // NS = W / 32 (maximum n-subtiles / K slices of an image): 2, 4 or 8;  ST = stride of the 3x3 (1 or 2: the first block of a stage,
 // laud_resnet.py:123 with stride 2 -- the block's halo'd input region then holds 2 R + 1 input rows for R output rows)
-template <int NS, int ST = 1>
+template <int NS, int ST = 1, bool PROJ = false>
 __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const int mb, unsigned char* const smem, const int tid) {
+    static_assert(!PROJ || (NS == 2 && ST == 1), "the folded projection exists for the 64-wide stride-1 block (stage 1's first block)");
     constexpr int W = NS * 32;
     // NS == 2 (stage 1: 14 short blocks per image, all of them bound by the CU's memory pipe in their conv3 phase and idle on it in
     // their conv2 phase): ONE h1 slice slot and 128 registers, so that TWO workgroups fit a CU and overlap each other's phases.
@@ -144,11 +150,12 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     constexpr int SLICE_BUFS = ST == 2 ? 2 : (NS == 2 ? 1 : 2);
     constexpr int W2_ROW = NS * 256;                  // bytes of one k-pair row of the staged W2 tile: W entries of 8 B
     constexpr int W2_SLOT = 16 * W2_ROW;              // 16 k-pairs = one K slice of 32
-    constexpr int CW = NS == 8 ? 32 : 64;             // output channels per conv3 chunk
+    constexpr int CW = (NS == 8 || PROJ) ? 32 : 64;   // output channels per conv3 chunk (PROJ: the staged chunk also holds Wd's 32 k-pair rows)
     constexpr int NCS = CW / 32;
     constexpr int W3_ROW = CW * 8;                    // bytes of one k-pair row of the staged W3 chunk
     constexpr int RPI = 1024 / W3_ROW;                // rows per DMA instruction
-    constexpr int W3_SLOT = (W / 2) * W3_ROW;
+    constexpr int PROWS = PROJ ? T_PROJ_CIN / 2 : 0;  // k-pair rows of the folded projection, staged behind the image's W3 rows
+    constexpr int W3_SLOT = (W / 2 + PROWS) * W3_ROW;
     constexpr int NP = W;                             // table width
     int* const s_kidx = reinterpret_cast<int*>(smem);
     unsigned char* const s_h1 = smem + T_KIDX_BYTES;                      // 2 slice slots (conv2 phase)
@@ -406,6 +413,17 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
                                                 : reinterpret_cast<const unsigned char*>(g_tail_zero);
             dma16(src, slot + i * 1024);
         }
+        if constexpr (PROJ) {
+            // Wd's k-pair rows behind the image's Kp / 2 rows of W3.  Staged row 8 s + r of K16 step s holds source pair 8 s + PI[r]:
+            // an A fragment of lane half h reads staged rows 2 h + {0, 1, 4, 5} of the step, the B fragment (one octet of the pre-split
+            // input per lane) supplies channels 16 s + 8 h + {0 .. 7} = pairs 8 s + 4 h + {0 .. 3} -- PI = {0, 1, 4, 5, 2, 3, 6, 7}
+            for (int i = wave; i < PROWS / RPI; i += 8) {
+                const int u = RPI * i + lane / LPR;
+                const int r = u & 7;
+                const int sp = (u & ~7) | ((r & 1) | ((r & 2) << 1) | ((r & 4) >> 1));
+                dma16(p.pw + ((long)sp * p.cout + cc * CW + 2 * (lane % LPR)) * 8, slot + (Kp / (2 * RPI) + i) * 1024);
+            }
+        }
     };
     if (nchunk3 > 0) dma_w3(0);
 
@@ -474,12 +492,24 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
         for (int cs = 0; cs < NCS; ++cs) {
             const int c0 = cc * CW + cs * 32;
             // residual tile in the layout the epilogue stores in, requested before the K loop that hides its latency
-            f32x4 res[4];
+            f32x4 res[PROJ ? 1 : 4];
+            bf16x8 pjh[PROJ ? T_PROJ_CIN / 16 : 1], pjl[PROJ ? T_PROJ_CIN / 16 : 1];
+            if constexpr (PROJ) {
+                // the lane's pixel of the block input, pre-split: K16 step s = octet 2 s + h (8 hi | 8 lo); L2 hits after the first sub-pass
+                const long q = out_row0 + min(pm, npix - 1);
+                const unsigned char* xr = p.pxs + (q >> 5) * ((long)T_PROJ_CIN * 128) + (q & 31) * 16 + h * 1024;
+#pragma unroll
+                for (int s2 = 0; s2 < T_PROJ_CIN / 16; ++s2) {
+                    pjh[s2] = *reinterpret_cast<const bf16x8*>(xr + s2 * 2048);
+                    pjl[s2] = *reinterpret_cast<const bf16x8*>(xr + s2 * 2048 + 512);
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int prow = wave * 32 + trw + 8 * it;
                 const float* src = (p.residual && prow < npix) ? p.residual + (size_t)(out_row0 + prow) * p.ldr + c0 + tc * 4 : g_tail_zero;
                 res[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            }
             }
             f32x4 sh = *reinterpret_cast<const f32x4*>(p.sh3 + c0 + tc * 4);   // bn3 shift: requested with the residual
             f32x16 acc3;
@@ -510,6 +540,30 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
                     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                 }
             }
+            if constexpr (PROJ) {
+                if (active) {
+#pragma unroll
+                    for (int jj = 0; jj < T_PROJ_CIN / 32; ++jj) {
+                        u32x2 e[2][4];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                e[t][q] = *reinterpret_cast<const u32x2*>(ws + a3_lane + (Kp / 2 + 16 * jj + 8 * t + (q & 1) + 4 * (q >> 1)) * W3_ROW + cs * 256);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const u32x4 ahu = {e[t][0][0], e[t][1][0], e[t][2][0], e[t][3][0]};
+                            const u32x4 alu = {e[t][0][1], e[t][1][1], e[t][2][1], e[t][3][1]};
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
+                            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pjh[2 * jj + t], acc3, 0, 0, 0);
+                            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pjl[2 * jj + t], acc3, 0, 0, 0);
+                            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pjh[2 * jj + t], acc3, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    }
+                }
+            }
             TT(tb)
             TT_ADD(w3k, ta, tb)
             if (cs == NCS - 1) wait_vm<0>();   // this wave's share of W3(cc + 1) has landed (its earlier stores and the residual too);
@@ -517,7 +571,8 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
             // gfx9 counts loads and stores in ONE vmcnt and lets them complete out of order with each other: a residual register first
             // touched after a store has been issued makes hipcc wait vmcnt(0), i.e. for that store's acknowledgement -- four
             // serialised store latencies per tile.  Touch all of them here, before the first store.
-            asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sh));
+            if constexpr (PROJ) asm volatile("" : "+v"(sh));
+            else asm volatile("" : "+v"(res[0]), "+v"(res[PROJ ? 0 : 1]), "+v"(res[PROJ ? 0 : 2]), "+v"(res[PROJ ? 0 : 3]), "+v"(sh));
             TT(ta)
             TT_ADD(w3wait, tb, ta)
             // C layout (lane = pixel l31, register r = channel (r & 3) + 8 (r >> 2) + 4 h) -> rows of 32 channels per pixel,
@@ -534,7 +589,8 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
             for (int it = 0; it < 4; ++it) {
                 const int row = trw + 8 * it, prow = wave * 32 + row;
                 f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
-                x = x + sh + res[it];
+                if constexpr (PROJ) x = x + sh;
+                else x = x + sh + res[PROJ ? 0 : it];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
                 if (prow < npix) {
@@ -574,10 +630,10 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
 #endif
 }
 
-template <int NS, int ST>
+template <int NS, int ST, bool PROJ = false>
 __global__ __launch_bounds__(512, ((NS == 2 && ST == 1) ? 4 : 2)) void k_tail(const TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    tail_body<NS, ST>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, threadIdx.x);     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
+    tail_body<NS, ST, PROJ>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, threadIdx.x);     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
 }
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_tail)
@@ -613,19 +669,19 @@ static int tail_rows_per_block(int Hi, int Wi, int NS, int st, int* mblocks) {
     return ceil_div(Ho, mbk);
 }
 
-template <int NS, int ST>
+template <int NS, int ST, bool PROJ = false>
 static int launch_tail(TailArgs& a, hipStream_t st) {
     constexpr int W = NS * 32;
     const int R = a.rows_per_blk;
     const int nr = tail_region_pixels(R, a.Hi, a.Wi, ST);
     a.slice_bytes = round_up((round_up(nr, 8) + 1) * 128, 1024);
     const size_t lds2 = tail_lds2(R, a.Hi, a.Wi, NS, ST);
-    const size_t lds3 = (size_t)T_KIDX_BYTES + 2 * (size_t)(W / 2) * (NS == 8 ? 32 : 64) * 8 + (size_t)18 * W * 4 + 8 * 4096;
+    const size_t lds3 = (size_t)T_KIDX_BYTES + 2 * (size_t)(W / 2 + (PROJ ? T_PROJ_CIN / 2 : 0)) * ((NS == 8 || PROJ) ? 32 : 64) * 8 + (size_t)18 * W * 4 + 8 * 4096;
     const size_t lds = lds2 > lds3 ? lds2 : lds3;
     LDN_REQUIRE(lds <= 160 * 1024, "ldn_bottleneck_tail: %zu B of LDS exceed 160 KiB (map %dx%d, width %d)", lds, a.Ho, a.Wo, W);
     LDN_REQUIRE(ST == 2 || NS == 2 || round_up(nr, 8) / 8 <= 72, "ldn_bottleneck_tail: input region of %d pixels too large for the slice pipeline", nr);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_tail<NS, ST>), lds), "k_tail: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL((k_tail<NS, ST>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_tail<NS, ST, PROJ>), lds), "k_tail: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((k_tail<NS, ST, PROJ>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_tail");
     return LDN_OK;
 }
@@ -652,11 +708,44 @@ extern "C" int ldn_bottleneck_tail_splits(int H, int Wd, int width, int stride) 
     return mbk * 8;
 }
 
+static int bottleneck_tail_impl(const void* h1_split, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs,
+                                const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
+                                const float* scale2, const float* shift2_tab, const float* post_sub2,
+                                const float* shift3, const float* residual, int ldr, float* out, int ldo,
+                                float* colsum, const void* x_split, const void* wd_pairs, void* stream);
+
 extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs,
                                    const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
                                    const float* scale2, const float* shift2_tab, const float* post_sub2,
                                    const float* shift3, const float* residual, int ldr, float* out, int ldo,
                                    float* colsum, void* stream) {
+    return bottleneck_tail_impl(h1_split, ldh, B, H, Wd, stride, width, w2_pairs, w3_pairs, cout, ch_idx, ch_cnt, scale2, shift2_tab,
+                                post_sub2, shift3, residual, ldr, out, ldo, colsum, nullptr, nullptr, stream);
+}
+
+extern "C" int ldn_bottleneck_tail_proj_fits(int H, int Wd, int width, int cin) {
+    int mbk = 0;
+    if (H < 1 || Wd < 1 || Wd > 256 || width != 64 || cin != ldn::T_PROJ_CIN) return 0;
+    return ldn::tail_rows_per_block(H, Wd, 2, 1, &mbk) > 0 ? 1 : 0;
+}
+
+extern "C" int ldn_bottleneck_tail_proj(const void* h1_split, int ldh, int B, int H, int Wd, int width, const void* w2_pairs,
+                                        const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
+                                        const float* scale2, const float* shift2_tab, const float* post_sub2, const float* shift3d,
+                                        const void* x_split, int cin, const void* wd_pairs, float* out, int ldo,
+                                        float* colsum, void* stream) {
+    LDN_REQUIRE(x_split && wd_pairs, "ldn_bottleneck_tail_proj: null pointer");
+    LDN_REQUIRE(width == 64 && cin == ldn::T_PROJ_CIN, "ldn_bottleneck_tail_proj: the folded projection exists for width 64, cin 64 (got %d, %d; ldn_bottleneck_tail_proj_fits == 0)", width, cin);
+    LDN_REQUIRE((uintptr_t)x_split % 16 == 0 && (uintptr_t)wd_pairs % 16 == 0, "ldn_bottleneck_tail_proj: x_split / wd_pairs must be 16-byte aligned");
+    return bottleneck_tail_impl(h1_split, ldh, B, H, Wd, 1, width, w2_pairs, w3_pairs, cout, ch_idx, ch_cnt, scale2, shift2_tab,
+                                post_sub2, shift3d, nullptr, 0, out, ldo, colsum, x_split, wd_pairs, stream);
+}
+
+static int bottleneck_tail_impl(const void* h1_split, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs,
+                                const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
+                                const float* scale2, const float* shift2_tab, const float* post_sub2,
+                                const float* shift3, const float* residual, int ldr, float* out, int ldo,
+                                float* colsum, const void* x_split, const void* wd_pairs, void* stream) {
     LDN_REQUIRE(h1_split && w2_pairs && w3_pairs && ch_idx && ch_cnt && scale2 && shift2_tab && post_sub2 && shift3 && out,
                 "ldn_bottleneck_tail: null pointer");
     LDN_REQUIRE(width == 64 || width == 128 || width == 256, "ldn_bottleneck_tail: width must be 64, 128 or 256 (got %d)", width);
@@ -678,6 +767,7 @@ extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, 
     a.k_idx = ch_idx; a.k_cnt = ch_cnt;
     a.sc2 = scale2; a.sh2 = shift2_tab; a.ps2 = post_sub2; a.sh3 = shift3;
     a.residual = residual; a.ldr = ldr; a.out = out; a.ldo = ldo; a.colsum = colsum;
+    a.pxs = static_cast<const unsigned char*>(x_split); a.pw = static_cast<const unsigned char*>(wd_pairs);
     a.rows_per_blk = tail_rows_per_block(H, Wd, width / 32, stride, &a.mblocks);
     LDN_REQUIRE(a.rows_per_blk > 0, "ldn_bottleneck_tail: a %dx%d map of width %d (stride %d) does not fit the workgroup (ldn_bottleneck_tail_splits == 0)", H, Wd, width, stride);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -686,6 +776,7 @@ extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, 
         if (width == 128) return launch_tail<4, 2>(a, st);
         return launch_tail<8, 2>(a, st);
     }
+    if (x_split) return launch_tail<2, 1, true>(a, st);
     if (width == 64) return launch_tail<2, 1>(a, st);
     if (width == 128) return launch_tail<4, 1>(a, st);
     return launch_tail<8, 1>(a, st);
@@ -715,6 +806,7 @@ struct HeadArgs {
     const float* sc1; const float* sh1; const float* ps1;   // [W]
     unsigned char* h1; long h1_row_bytes;
     int pix_per_blk, mblocks;
+    unsigned char* xs;                                // optional: x itself written pre-split in 32-pixel tiles (ldn_bottleneck_head_split) for a folded projection
 };
 
 template <int N> __device__ __forceinline__ void wait_vm_n() {
@@ -864,6 +956,19 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
                 bl[half][e] = (__bf16)(v - (float)hb);
             }
         }
+        if (p.xs && (int)xrow < npix) {
+            // the split x fragments ARE whole octets of the pre-split format: lane (pixel, h), K16 half `half` of chunk c = octet 4 c + 2 half + h.
+            // (Stores share vmcnt with the LDS-DMA: the counted waits above then ask for MORE completions than they need -- safe.)
+            // TILED layout (tiles of 32 consecutive pixels of the flat batch): [tile][K16 step s][h][hi | lo][pixel % 32][16 B] -- the
+            // consumer's B-fragment load (lane = pixel, fixed s / h / plane) then covers two contiguous 512-byte runs
+            const long q = row0 + xrow;
+            unsigned char* xo_ = p.xs + (q >> 5) * ((long)p.cin * 128) + (q & 31) * 16 + h * 1024;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                *reinterpret_cast<bf16x8*>(xo_ + (2 * c + half) * 2048) = bh[half];
+                *reinterpret_cast<bf16x8*>(xo_ + (2 * c + half) * 2048 + 512) = bl[half];
+            }
+        }
         // The image's n-subtiles in DESCENDING order as ONE linear, software-pipelined sequence with an entry point per subtile count
         // (a switch that falls through: no duplicated code, every accumulator keeps its registers).  Step j = the two K16 halves of
         // subtile j; a weight fragment is two ds_read_b128 (8 hi | 8 lo of row 32 j + l31, no VALU), double-buffered in a0 / a1: the
@@ -983,9 +1088,28 @@ static int launch_head(HeadArgs& a, hipStream_t st) {
 
 }  // namespace ldn
 
+static int bottleneck_head_impl(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
+                                const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
+                                const float* post_sub1, void* h1_split, int ldh, void* x_split, void* stream);
+
 extern "C" int ldn_bottleneck_head(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
                                    const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
                                    const float* post_sub1, void* h1_split, int ldh, void* stream) {
+    return bottleneck_head_impl(x, ldx, B, HW, cin, w1_split, width, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1_split, ldh, nullptr, stream);
+}
+
+extern "C" size_t ldn_x_split_bytes(size_t pixels, int cin) { return ((pixels + 31) / 32) * (size_t)cin * 128; }
+
+extern "C" int ldn_bottleneck_head_split(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
+                                         const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
+                                         const float* post_sub1, void* h1_split, int ldh, void* x_split, void* stream) {
+    LDN_REQUIRE(x_split && (uintptr_t)x_split % 16 == 0, "ldn_bottleneck_head_split: x_split must be a 16-byte aligned buffer of ldn_x_split_bytes(B * HW, cin) bytes");
+    return bottleneck_head_impl(x, ldx, B, HW, cin, w1_split, width, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1_split, ldh, x_split, stream);
+}
+
+static int bottleneck_head_impl(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
+                                const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
+                                const float* post_sub1, void* h1_split, int ldh, void* x_split, void* stream) {
     using namespace ldn;
     LDN_REQUIRE(x && w1_split && ch_idx && ch_cnt && scale1 && shift1 && post_sub1 && h1_split, "ldn_bottleneck_head: null pointer");
     LDN_REQUIRE(width == 64 || width == 128 || width == 256, "ldn_bottleneck_head: width must be 64, 128 or 256 (got %d)", width);
@@ -997,6 +1121,7 @@ extern "C" int ldn_bottleneck_head(const float* x, int ldx, int B, int HW, int c
     a.w1s = static_cast<const unsigned char*>(w1_split);
     a.n_idx = ch_idx; a.n_cnt = ch_cnt; a.sc1 = scale1; a.sh1 = shift1; a.ps1 = post_sub1;
     a.h1 = static_cast<unsigned char*>(h1_split); a.h1_row_bytes = (long)ldh * 4;
+    a.xs = static_cast<unsigned char*>(x_split);
     a.mblocks = ceil_div(HW, 256);
     a.pix_per_blk = ceil_div(HW, a.mblocks);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1097,7 +1222,7 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
             ha.x = xin; ha.ldx = p.ldx; ha.B = p.B; ha.HW = HW; ha.cin = p.C; ha.W = W;
             ha.w1s = uniform_ptr(cb->w1s); ha.n_idx = idx_i; ha.n_cnt = cnt_i;
             ha.sc1 = uniform_ptr(cb->sc1); ha.sh1 = uniform_ptr(cb->sh1); ha.ps1 = uniform_ptr(cb->ps1);
-            ha.h1 = p.h1; ha.h1_row_bytes = p.h1_row_bytes; ha.pix_per_blk = HW; ha.mblocks = 1;
+            ha.h1 = p.h1; ha.h1_row_bytes = p.h1_row_bytes; ha.pix_per_blk = HW; ha.mblocks = 1; ha.xs = nullptr;
             head_body<NS>(ha, b, 0, smem, p.lds_total, opaque_tid());
         }
         CT(c3)
@@ -1110,7 +1235,7 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
             ta.w2p = uniform_ptr(cb->w2p); ta.w3p = uniform_ptr(cb->w3p); ta.k_idx = idx_i; ta.k_cnt = cnt_i;
             ta.sc2 = uniform_ptr(cb->sc2); ta.sh2 = uniform_ptr(cb->sh2); ta.ps2 = uniform_ptr(cb->ps2); ta.sh3 = uniform_ptr(cb->sh3);
             ta.residual = xin; ta.ldr = p.ldx; ta.out = p.x_work; ta.ldo = p.ldx; ta.colsum = p.colsum;
-            ta.rows_per_blk = p.H; ta.mblocks = 1; ta.slice_bytes = p.slice_bytes;
+            ta.rows_per_blk = p.H; ta.mblocks = 1; ta.slice_bytes = p.slice_bytes; ta.pxs = nullptr; ta.pw = nullptr;
             tail_body<NS, 1>(ta, b, 0, smem, opaque_tid());
         }
         CT(c5)

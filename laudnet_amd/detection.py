@@ -69,7 +69,7 @@ class LAD_MMDet_ResNet(ResNet):
             raise LdnError(f"LAD_MMDet_ResNet: input {in_shape[2]}x{in_shape[3]} must be a multiple of 32 (mmdet pads to size_divisor 32)")
         x = self._stem_forward(x)
         outs = []
-        x, stats, sizes = self._run_blocks(x, stage_outs=outs)
+        x, stats, sizes = self._run_blocks(x, stage_outs=outs, gap0=self.__dict__.pop("_stem_gap", None))
         st = self._stack_stats(stats, x.device)
         s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
         perc, flops = self.flops_from_sparsities(in_shape, s3, s2, s1, cs)

@@ -479,6 +479,7 @@ class Bottleneck(_PrepCache):
     use_fused_tail = True    # class-level switch (A/B measurements): False keeps the three-launch gathered execution
 
     use_strided_tail = os.environ.get("LDN_TAIL_STRIDE2", "1") != "0"   # the fused tail on the stride-2 first blocks (A/B switch)
+    use_folded_projection = os.environ.get("LDN_FOLD_PROJ", "1") != "0"   # stage 1's first block: the projection shortcut inside conv3 (A/B switch)
 
     def _tail_eligible(self, Hi, Wi, Ho, Wo, cout):
         """The fused conv2 -> conv3 launch (ldn_bottleneck_tail) covers: bf16x3 arithmetic, stride 1 or 2, an even channel
@@ -565,6 +566,27 @@ class Bottleneck(_PrepCache):
         dev = x.device
         cout = p["w3"].shape[2]
         side = None
+        fold_proj = (self.downsample is not None and self.use_folded_projection and self.stride == 1 and p.get("ds_stride") == 1
+                     and self.use_fused_head and self.width in self.fused_head_widths and self._tail_eligible(Hi, Wi, Ho, Wo, cout)
+                     and ops.bottleneck_tail_proj_fits(Hi, Wi, W, Cin))
+        if fold_proj:
+            # stage 1's first block: the projection shortcut is 64 more K values of conv3 (ldn_bottleneck_tail_proj) -- no projection
+            # launch, no identity tensor written and read back; conv1's launch leaves its input pre-split for it
+            if "wdp" not in p:
+                with torch.no_grad():
+                    p["wdp"] = ops.pack_w3_pairs(p["wd"].reshape(cout, Cin) * p["sd"].view(-1, 1))
+                    p["t3cd"] = (p["t3c"] + p["td"]).contiguous()
+            w2p, w3p = self.tail_weights(p)
+            h1 = torch.empty(B, Hi, Wi, W, device=dev, dtype=torch.float32)
+            xs = ops.x_split_buffer(B * Hi * Wi, Cin, dev)
+            out = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
+            ops.bottleneck_head(xn, p["w1s"], idx, cnt, p["s1"], p["t1"], p["c1"], h1, x_split=xs)
+            gap_out = (torch.empty(B, ops.bottleneck_tail_splits(Hi, Wi, W, 1), cout, device=dev, dtype=torch.float32) if want_gap else None)
+            ops.bottleneck_tail_proj(h1, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3cd"], xs, p["wdp"], out, colsum=gap_out)
+            self.last_channel_mask = mask
+            self.last_gap = gap_out
+            self.last_channel_cnt = cnt
+            return ops.from_nhwc(out), mask
         if self.downsample is not None:
             # the projection shortcut only depends on x: it runs on a side stream next to conv1 / conv2 and is joined
             # before conv3 (a fork/join that hipGraph capture records as such)
@@ -908,7 +930,7 @@ class ResNet(nn.Module):
         _eval_only(self, x)
         in_shape = tuple(x.shape)
         x = self._stem_forward(x)
-        x, stats, sizes = self._run_blocks(x)
+        x, stats, sizes = self._run_blocks(x, gap0=self.__dict__.pop("_stem_gap", None))
         st, perc, flops = self._forward_stats(stats, in_shape, x.device)   # st [n_blocks, 4] = s3, s2, s1, cs
         s3, s2, s1, cs = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
 
@@ -927,6 +949,12 @@ class ResNet(nn.Module):
         w, b = self._folded_stem()
         if self._stem_fused_ok(x):
             # one launch: conv 7x7 -> max-pool -> + shift -> ReLU; the full-resolution conv output never exists (ldn_stem_conv_pool)
+            first = self.layer1[0]
+            if (self.use_stem_gap and first.dyn_mode == "channel" and first.forced_channel_mask is None and self._tap is None
+                    and getattr(first.masker_channel, "accepts_fused_gap", False)):
+                # ... and leaves the channel sums of its output for the first block's channel masker (no pass over x for its GAP)
+                y, self._stem_gap = ops.stem_conv_pool(ops.as_nhwc(x), self._stem_frag, b, self.conv1.out_channels, want_gap=True)
+                return ops.from_nhwc(y)
             x = ops.from_nhwc(ops.stem_conv_pool(ops.as_nhwc(x), self._stem_frag, b, self.conv1.out_channels))
         else:
             x = F.conv2d(x, w, None, self.conv1.stride, self.conv1.padding)
@@ -934,7 +962,9 @@ class ResNet(nn.Module):
 
         return x
 
-    def _run_blocks(self, x, stage_outs=None):
+    use_stem_gap = os.environ.get("LDN_STEM_GAP", "1") != "0"   # the fused stem leaves the first channel masker's GAP partials (A/B switch)
+
+    def _run_blocks(self, x, stage_outs=None, gap0=None):
         """The four stages on the HIP path.  Returns (x, per-block stats, blocks per stage); stage_outs (a list) receives every
         stage's output map (the detection backbone's feature taps)."""
         # dynamic blocks: each returns its 4 sparsities as a device vector; the FLOPs bookkeeping of
@@ -944,7 +974,7 @@ class ResNet(nn.Module):
         sizes = [len(getattr(self, f"layer{i + 1}")) for i in range(4)]
         ends = set(itertools.accumulate(sizes))        # a stage's output = the output of its last block
         step_id = self._step_id = getattr(self, "_step_id", 0) + 1
-        gap = None
+        gap = gap0          # channel sums of the stem's output, when the fused stem left them (first block's masker)
         j = -1
         while j + 1 < len(blocks):
             j += 1

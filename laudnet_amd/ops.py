@@ -511,14 +511,25 @@ def pack_w1_split(conv1_weight_2d):
     return torch.stack((hi, lo), dim=-2).contiguous()
 
 
-def bottleneck_head(x_nhwc, w1_split, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1_split):
-    """conv1 of a channel-mode block on the image's active output channels, written pre-split (see ldn_bottleneck_head)."""
+def bottleneck_head(x_nhwc, w1_split, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1_split, x_split=None):
+    """conv1 of a channel-mode block on the image's active output channels, written pre-split (see ldn_bottleneck_head).
+    x_split (optional, x_split_buffer(B*H*W, cin)): receives x itself pre-split in 32-pixel tiles (ldn_bottleneck_head_split), the operand
+    of a projection shortcut folded into the tail (bottleneck_tail_proj)."""
     L.require_device(x_nhwc, w1_split, h1_split)
     lib = L.load()
     B, H, Wd, cin = x_nhwc.shape
     width = ch_idx.shape[1]
     if w1_split.dtype != torch.bfloat16 or not w1_split.is_contiguous():
         raise L.LdnError("bottleneck_head: w1_split must be the contiguous bf16 tensor of pack_w1_split")
+    if x_split is not None:
+        if x_split.dtype != torch.float32 or not x_split.is_contiguous() or x_split.numel() * 4 < lib.ldn_x_split_bytes(B * H * Wd, cin):
+            raise L.LdnError("bottleneck_head: x_split must be a contiguous fp32 buffer of x_split_buffer(B * H * W, cin)")
+        L.check(lib.ldn_bottleneck_head_split(L.ptr(_f32c(x_nhwc, "x")), cin, B, H * Wd, cin, L.ptr(w1_split), width,
+                                              L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")), L.ptr(_f32c(scale1, "scale1")),
+                                              L.ptr(_f32c(shift1, "shift1")), L.ptr(_f32c(post_sub1, "post_sub1")),
+                                              L.ptr(_f32c(h1_split, "h1")), h1_split.shape[-1], L.ptr(x_split),
+                                              L.stream_ptr(h1_split)), "ldn_bottleneck_head_split")
+        return h1_split
     L.check(lib.ldn_bottleneck_head(L.ptr(_f32c(x_nhwc, "x")), cin, B, H * Wd, cin, L.ptr(w1_split), width,
                                     L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")), L.ptr(_f32c(scale1, "scale1")),
                                     L.ptr(_f32c(shift1, "shift1")), L.ptr(_f32c(post_sub1, "post_sub1")),
@@ -604,6 +615,46 @@ def bottleneck_tail(h1_split, w2_pairs, w3_pairs, ch_idx, ch_cnt, scale2, shift2
     return out_nhwc
 
 
+def x_split_buffer(pixels, cin, dev):
+    """Storage of a pre-split activation tensor in 32-pixel tiles (ldn_x_split_bytes; see ldn_bottleneck_head_split)."""
+    return torch.empty(L.load().ldn_x_split_bytes(pixels, cin) // 4, device=dev, dtype=torch.float32)
+
+
+def decode_x_split(xs, pixels, cin):
+    """x_split buffer -> [pixels, cin] fp32 (hi + lo); test / debug helper."""
+    t = xs.view(torch.bfloat16).reshape(-1, cin // 16, 2, 2, 32, 8).float()       # [tile][s][h][hi | lo][pixel][8]
+    v = (t[:, :, :, 0] + t[:, :, :, 1]).permute(0, 3, 1, 2, 4).reshape(-1, cin)     # [tile * 32][s, h, 8] = channel 16 s + 8 h + i
+    return v[:pixels]
+
+
+def bottleneck_tail_proj_fits(H, W, width, cin):
+    """Can the fused tail fold this block's stride-1 projection shortcut into conv3 (ldn_bottleneck_tail_proj_fits)?"""
+    return bool(L.load().ldn_bottleneck_tail_proj_fits(H, W, width, cin))
+
+
+def bottleneck_tail_proj(h1_split, w2_pairs, w3_pairs, ch_idx, ch_cnt, scale2, shift2_tab, post_sub2, shift3d, x_split, wd_pairs,
+                         out_nhwc, *, colsum=None):
+    """The fused tail with the projection shortcut as 64 more K values of conv3 (see ldn_bottleneck_tail_proj): x_split from
+    bottleneck_head(..., x_split=...), wd_pairs = pack_w3_pairs(bn_d.scale * downsample.weight), shift3d = shift3 + bn_d.shift."""
+    L.require_device(h1_split, w2_pairs, w3_pairs, x_split, wd_pairs, out_nhwc)
+    lib = L.load()
+    B, H, Wd, ldh = h1_split.shape
+    width = ch_idx.shape[1]
+    cout = out_nhwc.shape[-1]
+    cin = wd_pairs.shape[0] * 2
+    if tuple(out_nhwc.shape) != (B, H, Wd, cout) or x_split.numel() * 4 < lib.ldn_x_split_bytes(B * H * Wd, cin) or not x_split.is_contiguous():
+        raise L.LdnError(f"bottleneck_tail_proj: out must be [B={B}, {H}, {Wd}, cout], x_split the buffer bottleneck_head filled")
+    for t in (w2_pairs, w3_pairs, wd_pairs):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise L.LdnError("bottleneck_tail_proj: w2_pairs / w3_pairs / wd_pairs must be the contiguous bf16 tensors of pack_w2_pairs / pack_w3_pairs")
+    L.check(lib.ldn_bottleneck_tail_proj(L.ptr(_f32c(h1_split, "h1")), ldh, B, H, Wd, width, L.ptr(w2_pairs), L.ptr(w3_pairs), cout,
+                                         L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")), L.ptr(_f32c(scale2, "scale2")),
+                                         L.ptr(_f32c(shift2_tab, "shift2_tab")), L.ptr(_f32c(post_sub2, "post_sub2")),
+                                         L.ptr(_f32c(shift3d, "shift3d")), L.ptr(x_split), cin, L.ptr(wd_pairs),
+                                         L.ptr(_f32c(out_nhwc, "out")), cout, L.ptr(colsum), L.stream_ptr(out_nhwc)), "ldn_bottleneck_tail_proj")
+    return out_nhwc
+
+
 def bottleneck_smallmap_fits(H, W, cin, width, cout):
     """Does a whole bottleneck on an H x W map fit one workgroup (ldn_bottleneck_smallmap_fits)?"""
     return bool(L.load().ldn_bottleneck_smallmap_fits(H, W, cin, width, cout))
@@ -652,8 +703,9 @@ def pack_stem_weights(w_scaled):
     return torch.stack((hi, lo), dim=-2).contiguous()                              # [j][s][lane][2][8]
 
 
-def stem_conv_pool(x_nhwc, w_frag, shift, cout):
-    """relu(maxpool3x3s2p1(conv7x7s2p3(x, w)) + shift) in one launch (see ldn_stem_conv_pool).  x_nhwc [B,H,W,3] -> [B,Hp,Wp,cout]."""
+def stem_conv_pool(x_nhwc, w_frag, shift, cout, want_gap=False):
+    """relu(maxpool3x3s2p1(conv7x7s2p3(x, w)) + shift) in one launch (see ldn_stem_conv_pool).  x_nhwc [B,H,W,3] -> [B,Hp,Wp,cout]
+    (want_gap: -> (out, gap [B, splits, cout]) with the per-tile channel sums of out, ldn_stem_conv_pool_gap)."""
     L.require_device(x_nhwc, w_frag, shift)
     lib = L.load()
     B, H, W, cin = x_nhwc.shape
@@ -664,6 +716,11 @@ def stem_conv_pool(x_nhwc, w_frag, shift, cout):
     Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
     out = torch.empty(B, Hp, Wp, cout, device=x_nhwc.device, dtype=torch.float32)
+    if want_gap:
+        gap = torch.empty(B, lib.ldn_stem_gap_splits(H, W), cout, device=x_nhwc.device, dtype=torch.float32)
+        L.check(lib.ldn_stem_conv_pool_gap(L.ptr(x_nhwc), B, H, W, L.ptr(w_frag), L.ptr(_f32c(shift, "shift")), cout, L.ptr(out), Hp, Wp,
+                                           L.ptr(gap), L.stream_ptr(out)), "ldn_stem_conv_pool_gap")
+        return out, gap
     L.check(lib.ldn_stem_conv_pool(L.ptr(x_nhwc), B, H, W, L.ptr(w_frag), L.ptr(_f32c(shift, "shift")), cout, L.ptr(out), Hp, Wp,
                                    L.stream_ptr(out)), "ldn_stem_conv_pool")
     return out

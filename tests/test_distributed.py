@@ -116,3 +116,22 @@ def test_shard_bounds():
     assert [D.shard_bounds(2048, r, 8) for r in (0, 7)] == [(0, 256), (1792, 2048)]
     with pytest.raises(ValueError):
         D.shard_bounds(10, 0, 4)
+
+
+@pytest.mark.gpu
+def test_rccl_two_rank_bench_line():
+    """VERDICT round 3, hygiene (b): RCCL itself (backend "nccl" on ROCm) runs laudnet_amd.distributed.gather_outputs_async through
+    `bench.py --gpus 2 --steps 2` when two GPUs are visible -- so that the driver's 8-GPU scaling run is not RCCL's first execution of
+    the exchange.  Skips on a one-GPU lease (the gloo tests above cover the arithmetic of the exchange on CPU)."""
+    import json
+    import subprocess
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one-GPU lease)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
+                         "--no-legs", "--keep", "0.62"], capture_output=True, text=True, timeout=900, env=env)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    line = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["backend"] == "nccl" and line["config"]["world_size"] == 2
+    assert line["config"]["global_batch"] == 64 and line["value"] > 0
+    assert 0.2 < line["config"]["mean_block_flops_ratio"] < 0.9     # the all-reduced sparsities are global-batch means, not garbage

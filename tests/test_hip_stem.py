@@ -59,6 +59,12 @@ def test_stem_vs_torch(B, H, W, cout):
     err = (got - want).abs()
     assert torch.isfinite(got).all()
     assert (err <= 1e-4 + 1e-5 * want.abs()).all(), f"max err {err.max().item():.3e}"
+    # the same launch leaving the first channel masker's GAP partials: identical output, per-tile sums add up to the output's sums
+    got_g, gap = ops.stem_conv_pool(xn, frag, shift, cout, want_gap=True)
+    assert torch.equal(got_g.permute(0, 3, 1, 2).cpu(), got)
+    assert gap.shape[0] == B and gap.shape[2] == cout and torch.isfinite(gap).all()
+    tot = got.double().sum(dim=(2, 3))
+    assert torch.allclose(gap.double().sum(dim=1).cpu(), tot, atol=1e-3, rtol=1e-5)
 
 
 @pytest.mark.gpu

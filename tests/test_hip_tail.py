@@ -100,3 +100,62 @@ def test_tail_vs_reference_algebra(ops, B, H, cin, W, gran, st):
     # in-place residual stream (out aliases residual): same result
     ops.bottleneck_tail(h1s, w2p, w3p, idx, cnt, p["s2"], p["t2_tab"], p["c2"], p["t3c"], idn, residual=idn, stride=st)
     assert torch.equal(idn, out)
+
+
+@pytest.mark.parametrize("B,H,Wd", [(3, 56, 56), (4, 12, 12), (2, 9, 20), (5, 28, 28)])
+def test_folded_projection_block_vs_reference(ops, B, H, Wd):
+    """Stage 1's first block (64 -> 64 -> 256, stride 1, projection shortcut): the shortcut folded into conv3's K loop
+    (ldn_bottleneck_head_split + ldn_bottleneck_tail_proj) against the reference algebra (laud_resnet.py:115-144 with the downsample of
+    :138-141) and against the unfolded execution (projection launch + residual read); x_split decodes to x."""
+    import torch.nn as nn
+    from laudnet_amd.laud_resnet import Bottleneck
+    cin, W, gran = 64, 64, 2
+    cout = 4 * W
+    mk = lambda cls: cls(cin, W, stride=1, downsample=nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout)),
+                         dyn_mode="channel", channel_dyn_granularity=gran, channel_masker="MLP", channel_masker_layers=2, output_size=H).eval()
+    ref = mk(TR.BottleneckRef)
+    TR.randomize_bn_(ref, 7)
+    with torch.no_grad():
+        for m in (ref.conv1, ref.conv2, ref.conv3, ref.downsample[0]):
+            m.weight.normal_(0, (2.0 / (m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3])) ** 0.5)
+    hb = mk(Bottleneck)
+    hb.load_state_dict(ref.state_dict())
+    hb = hb.to(DEV)
+    gm = seeded_bernoulli((B, W // gran), 0.62, 41 + H)
+    gm[0] = 0.0
+    gm[1] = 1.0
+    x = F.relu(seeded_randn((B, cin, H, Wd), 42))
+    ref.forced_channel_mask = gm
+    hb.forced_channel_mask = gm.to(DEV)
+    st0 = lambda t: (t, None, None, None, None, None, torch.tensor(0.0, device=t.device))
+    with torch.no_grad():
+        want = ref(st0(x), 1.0)[0]
+    assert ops.bottleneck_tail_proj_fits(H, Wd, W, cin)
+    ops.set_math_mode("bf16x3")
+    try:
+        outs = {}
+        for fold in (True, False):
+            hb.use_folded_projection = fold
+            seen = []
+            orig = ops.bottleneck_tail_proj
+            ops.bottleneck_tail_proj = lambda *a, **k: (seen.append(1), orig(*a, **k))[1]
+            try:
+                with torch.no_grad():
+                    outs[fold] = hb(st0(x.to(DEV)), 1.0)[0].cpu()
+            finally:
+                ops.bottleneck_tail_proj = orig
+            assert bool(seen) == fold, "the folded projection must run exactly when it is switched on"
+        # x_split of the head launch decodes to x
+        p = hb._prep
+        _, idx, cnt, _ = ops.channel_masker(None, None, None, None, None, W // gran, gran, mask_in=gm.to(DEV))
+        xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        h1 = torch.empty(B, H, Wd, W, device=DEV)
+        xs = ops.x_split_buffer(B * H * Wd, cin, DEV)
+        ops.bottleneck_head(xn, p["w1s"], idx, cnt, p["s1"], p["t1"], p["c1"], h1, x_split=xs)
+        assert torch.allclose(ops.decode_x_split(xs, B * H * Wd, cin).cpu(), xn.reshape(-1, cin).cpu(), atol=0.0, rtol=2e-5)      # hi + lo = x to 2^-17
+    finally:
+        ops.set_math_mode("fp32")
+    for fold in (True, False):
+        err = (outs[fold] - want).abs().max().item()
+        assert torch.allclose(outs[fold], want, atol=2e-4, rtol=1e-4), f"fold={fold}: max err {err:.3e}"
+    assert torch.allclose(outs[True], outs[False], atol=1e-4, rtol=1e-4)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# gpurun with retries on "no slot free" (exit 3).  usage: tools/experiments/gpu.sh <timeout> '<command>'
+T=$1; shift
+for i in 1 2 3 4 5 6 7 8; do
+  /usr/local/graft/bin/gpurun --timeout $T -- "$@"
+  rc=$?
+  [ $rc -ne 3 ] && exit $rc
+  sleep 60
+done
+exit 3

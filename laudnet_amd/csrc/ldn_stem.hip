@@ -24,11 +24,15 @@ namespace ldn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef LDN_STEM_ABLATE
+#define LDN_STEM_ABLATE 0   // tuning only (results are wrong): 1 = no MFMA loop, 2 = no pooling phase, 4 = no patch fetch, 8 = no conv-tile write
+#endif
 constexpr int S_PH = 8, S_PW = 7;                     // pooled pixels per tile
 constexpr int S_CH = 2 * S_PH + 1, S_CW = 2 * S_PW + 1;   // conv pixels per tile: 17 x 15 = 255
 constexpr int S_IH = 2 * (S_CH - 1) + 7, S_IW = 2 * (S_CW - 1) + 7;   // input patch: 39 x 35
-constexpr int S_ROWF = S_IW * 3;                      // floats per patch row (105)
-constexpr int S_PATCH = (S_IH + 1) * S_ROWF + 32;     // + one row and a tail: the zero-weight k slots read past the window
+constexpr int S_ROWF = S_IW * 3;                      // values per patch row (105)
+constexpr int S_ROWP = S_ROWF + 1;                    // ... padded to an even count: every k-octet of a lane then starts on a 4-byte boundary of the bf16 planes
+constexpr int S_PATCH = (S_IH + 1) * S_ROWP + 32;     // + one row and a tail: the zero-weight k slots read past the window
 constexpr int S_KSTEPS = 11;                          // 7 rows x 24 = 168 -> 11 steps of 16 (the last half step has zero weights)
 constexpr int S_LOADS = (S_IH * S_ROWF + 511) / 512;  // patch floats per thread (8)
 
@@ -47,8 +51,12 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
     constexpr int WF_BYTES = NSUB * S_KSTEPS * 64 * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const s_w = smem;                                           // weight fragments
-    float* const s_patch = reinterpret_cast<float*>(smem + WF_BYTES);          // [40][105] (+ tail)
-    float* const s_conv = s_patch + round_up(S_PATCH, 4);                      // [256][C]
+    // the input patch PRE-SPLIT into two bf16 planes (hi = bf16(x), lo = bf16(x - hi)), [40][106] (+ tail) each: an input value takes
+    // part in ~12 conv outputs, so splitting it once when the patch is staged instead of once per use removes ~300 VALU instructions
+    // per lane and tile from the MFMA loop (round 4; the products and their order are unchanged: bit-identical results)
+    __bf16* const s_ph = reinterpret_cast<__bf16*>(smem + WF_BYTES);
+    __bf16* const s_pl = s_ph + round_up(S_PATCH, 8);
+    float* const s_conv = reinterpret_cast<float*>(s_pl + round_up(S_PATCH, 8));   // [256][C]
     float* const s_gs = s_conv + 256 * C;                                      // [2][8 waves][C] channel sums of the tile's pooled pixels (gap only)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -57,13 +65,13 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
 
     for (int i = tid; i < WF_BYTES / 16; i += 512)
         reinterpret_cast<f32x4*>(s_w)[i] = reinterpret_cast<const f32x4*>(p.wf)[i];
-    for (int i = tid; i < S_PATCH; i += 512) s_patch[i] = 0.f;                 // the pad row / tail stay zero
+    for (int i = tid; i < 2 * round_up(S_PATCH, 8); i += 512) s_ph[i] = (__bf16)0.f;   // both planes: the pad column / row / tail stay zero
 
     // this lane's conv pixel of the tile and its patch offset (floats)
     const int pm = wave * 32 + l31;
     const int pmc = min(pm, S_CH * S_CW - 1);
     const int coy = pmc / S_CW, cox = pmc - coy * S_CW;
-    const int pbase = (2 * coy * S_IW + 2 * cox) * 3;
+    const int pbase = 2 * coy * S_ROWP + 2 * cox * 3;
 
     auto tile_origin = [&](int t, int& b, int& py0, int& px0) {
         const int per_img = p.tiles_y * p.tiles_x;
@@ -74,20 +82,34 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
         px0 = (r - ty * p.tiles_x) * S_PW;
     };
     float pre[S_LOADS];
+    auto fetch_one = [&](int b, int iy0, int ix0, int i) {      // patch value i of this thread for the tile whose window starts at (iy0, ix0)
+        const int e = i * 512 + tid;
+        const int r = e / S_ROWF, cc = e - r * S_ROWF;
+        const int iy = iy0 + r, ix = ix0 + cc / 3;
+        const bool ok = e < S_IH * S_ROWF && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const long off = (((long)b * p.H + iy) * p.W + ix0) * 3 + cc;       // >= 0 whenever ok
+#if LDN_STEM_ABLATE & 4
+        pre[i] = 0.f;
+#else
+        pre[i] = ok ? p.x[off] : 0.f;
+#endif
+    };
     auto fetch = [&](int t) {
         int b, py0, px0;
         tile_origin(t, b, py0, px0);
-        const int iy0 = 4 * py0 - 5, ix0 = 4 * px0 - 5;
 #pragma unroll
-        for (int i = 0; i < S_LOADS; ++i) {
-            const int e = i * 512 + tid;
-            const int r = e / S_ROWF, cc = e - r * S_ROWF;
-            const int iy = iy0 + r, ix = ix0 + cc / 3;
-            const bool ok = e < S_IH * S_ROWF && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const long off = (((long)b * p.H + iy) * p.W + ix0) * 3 + cc;       // >= 0 whenever ok
-            pre[i] = ok ? p.x[off] : 0.f;
-        }
+        for (int i = 0; i < S_LOADS; ++i) fetch_one(b, 4 * py0 - 5, 4 * px0 - 5, i);
     };
+    // The pooled values of a tile are STORED during the MFMA loop of the next tile, and the patch of the next tile is FETCHED one value
+    // per K step: issued in bursts between the phases, the 14 KB of stores and the 16 KB of loads of a tile cost the phase they sit in
+    // their issue time (a CU retires ~8 B/clk of stores: ablations of round 4, 103 + 72 us of a 398 us launch) while the matrix pipe idles.
+    constexpr int QUADS = C / 4;
+    constexpr int PI = (S_PH * S_PW * QUADS + 511) / 512;      // pooled (pixel, channel quad) items per thread and tile
+    static_assert(S_LOADS + PI <= S_KSTEPS, "one deferred load / store per K step");
+    f32x4 pv[PI];
+    float* pdst[PI];
+#pragma unroll
+    for (int k = 0; k < PI; ++k) pdst[k] = nullptr;
 
     // the per-wave channel sums of tile t are combined (in wave order) and stored behind the NEXT barrier the loop has anyway
     auto flush_gap = [&](int tprev, int slot) {
@@ -106,10 +128,17 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
 #pragma unroll
         for (int i = 0; i < S_LOADS; ++i) {
             const int e = i * 512 + tid;
-            if (e < S_IH * S_ROWF) s_patch[e] = pre[i];
+            if (e < S_IH * S_ROWF) {
+                const int r = e / S_ROWF, o = e + r;           // row r, column e - r * S_ROWF of the padded planes
+                const __bf16 hb = (__bf16)pre[i];
+                s_ph[o] = hb;
+                s_pl[o] = (__bf16)(pre[i] - (float)hb);
+            }
         }
         __syncthreads();
-        if (t + (int)gridDim.x < p.ntiles) fetch(t + gridDim.x);   // in flight during the MFMA loop
+        const bool have_next = t + (int)gridDim.x < p.ntiles;
+        int nb = 0, npy0 = 0, npx0 = 0;
+        if (have_next) tile_origin(t + gridDim.x, nb, npy0, npx0);
 
         f32x16 acc[NSUB];
 #pragma unroll
@@ -118,13 +147,16 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         // software-pipelined over the 11 K16 steps (schedule pinned): the 8 patch floats and the weight fragments of step s + 1 are
         // requested before the MFMAs of step s and split into bf16 hi / lo after them
-        float raw[2][8];
+        typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+        u32x4s rawh[2], rawl[2];
         bf16x8 fh[2][NSUB], fl[2][NSUB];
         auto request = [&](int s, int buf) {
-            const int q = 2 * s + h;                   // this lane's k8 group: patch row q / 3, floats 8 (q % 3) .. + 7 of the row window
-            const float* src = s_patch + pbase + (q / 3) * S_ROWF + 8 * (q % 3);
+            const int q = 2 * s + h;                   // this lane's k8 group: patch row q / 3, values 8 (q % 3) .. + 7 of the row window
+            const int off = pbase + (q / 3) * S_ROWP + 8 * (q % 3);        // even: four aligned dwords per plane
+            const unsigned* sh = reinterpret_cast<const unsigned*>(s_ph + off);
+            const unsigned* sl = reinterpret_cast<const unsigned*>(s_pl + off);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) raw[buf][e] = src[e];
+            for (int e = 0; e < 4; ++e) { rawh[buf][e] = sh[e]; rawl[buf][e] = sl[e]; }
 #pragma unroll
             for (int j = 0; j < NSUB; ++j) {
                 const unsigned char* wp = s_w + ((j * S_KSTEPS + s) * 64 + lane) * 32;
@@ -132,21 +164,16 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
                 fl[buf][j] = *reinterpret_cast<const bf16x8*>(wp + 16);
             }
         };
-        auto split = [&](int buf, bf16x8& bh, bf16x8& bl) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = raw[buf][e];
-                const __bf16 hb = (__bf16)v;
-                bh[e] = hb;
-                bl[e] = (__bf16)(v - (float)hb);
-            }
+        auto split = [&](int buf, bf16x8& bh, bf16x8& bl) {     // (nothing left to split: the planes hold the operands)
+            bh = __builtin_bit_cast(bf16x8, rawh[buf]);
+            bl = __builtin_bit_cast(bf16x8, rawl[buf]);
         };
         bf16x8 bh, bl;
         request(0, 0);
         split(0, bh, bl);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < S_KSTEPS; ++s) {
+        for (int s = 0; s < ((LDN_STEM_ABLATE & 1) ? 1 : S_KSTEPS); ++s) {
             if (s + 1 < S_KSTEPS) request(s + 1, (s + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -157,13 +184,17 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < S_KSTEPS) split((s + 1) & 1, bh, bl);
+            if (s < S_LOADS) { if (have_next) fetch_one(nb, 4 * npy0 - 5, 4 * npx0 - 5, s); }
+            else if (s - S_LOADS < PI) {
+                if (pdst[s - S_LOADS]) __builtin_nontemporal_store(pv[s - S_LOADS], reinterpret_cast<f32x4*>(pdst[s - S_LOADS]));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // C layout (lane = pixel l31, register r = channel (r & 3) + 8 (r >> 2) + 4 h of the subtile) -> s_conv[pixel][C]
 #pragma unroll
         for (int j = 0; j < NSUB; ++j)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
+            for (int q4 = 0; q4 < ((LDN_STEM_ABLATE & 8) ? 1 : 4); ++q4) {
                 const f32x4 v = {acc[j][4 * q4], acc[j][4 * q4 + 1], acc[j][4 * q4 + 2], acc[j][4 * q4 + 3]};
                 const int slot = 8 * j + 2 * q4 + h;
                 *reinterpret_cast<f32x4*>(s_conv + pm * C + ((slot ^ (pm & 7)) << 2)) = v;
@@ -173,29 +204,38 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
         // ---- max-pool 3x3 stride 2 pad 1 over the conv tile, + shift, ReLU
         int b, py0, px0;
         tile_origin(t, b, py0, px0);
-        constexpr int QUADS = C / 4;
         f32x4 gs = {0.f, 0.f, 0.f, 0.f};           // this thread's channel quad (tid % QUADS: 512 % QUADS == 0) summed over its pooled pixels
-        for (int w = tid; w < S_PH * S_PW * QUADS; w += 512) {
+#pragma unroll
+        for (int k = 0; k < PI; ++k) {
+            const int w = tid + 512 * k;
+            pdst[k] = nullptr;
+            if ((LDN_STEM_ABLATE & 2) || w >= S_PH * S_PW * QUADS) continue;
             const int cq = w % QUADS, pp = w / QUADS;
             const int ly = pp / S_PW, lx = pp - ly * S_PW;
             const int py = py0 + ly, px = px0 + lx;
             if (py >= p.Hp || px >= p.Wp) continue;
-            f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            // branch-free: all nine 16-byte reads are issued together (the tile-local window always exists in s_conv); a tap outside the
+            // conv map (the pool's -inf padding) is replaced by the centre value, which is always inside (max unchanged)
+            f32x4 v9[9];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int cy = 2 * py - 1 + dy, cx = 2 * px - 1 + dx;      // conv pixel (global); tile-local = (2 ly + dy, 2 lx + dx)
-                    if (cy < 0 || cy >= p.Hc || cx < 0 || cx >= p.Wc) continue;
-                    const int cp = (2 * ly + dy) * S_CW + 2 * lx + dx;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(s_conv + cp * C + ((cq ^ (cp & 7)) << 2));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+                    const bool ok = cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc;
+                    const int cp = ok ? (2 * ly + dy) * S_CW + 2 * lx + dx : (2 * ly + 1) * S_CW + 2 * lx + 1;
+                    v9[dy * 3 + dx] = *reinterpret_cast<const f32x4*>(s_conv + cp * C + ((cq ^ (cp & 7)) << 2));
                 }
+            f32x4 m = v9[4];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v9[k][e]);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + cq * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e] + sh[e], 0.f);
-            __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(p.out + (((size_t)b * p.Hp + py) * p.Wp + px) * C + cq * 4));
+            pv[k] = m;                             // stored during the next tile's MFMA loop (or after the last tile)
+            pdst[k] = p.out + (((size_t)b * p.Hp + py) * p.Wp + px) * C + cq * 4;
             gs += m;
         }
         if (p.gap) {   // lanes with the same lane % QUADS hold the same channel quad: fold them, one LDS row per wave
@@ -210,6 +250,9 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
             if (lane < QUADS) *reinterpret_cast<f32x4*>(s_gs + (((it & 1) * 8 + wave) * C) + lane * 4) = gs;
         }
     }
+#pragma unroll
+    for (int k = 0; k < PI; ++k)
+        if (pdst[k]) __builtin_nontemporal_store(pv[k], reinterpret_cast<f32x4*>(pdst[k]));
     if (p.gap && it > 0) {
         __syncthreads();
         flush_gap(t - (int)gridDim.x, (it - 1) & 1);
@@ -220,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void k_stem(const StemArgs p) {
 template <int NSUB>
 static int launch_stem(const StemArgs& a, int cus, hipStream_t st) {
     constexpr int C = 32 * NSUB;
-    const size_t lds = (size_t)NSUB * S_KSTEPS * 64 * 32 + (size_t)round_up(S_PATCH, 4) * 4 + (size_t)256 * C * 4 + (size_t)2 * 8 * C * 4;
+    const size_t lds = (size_t)NSUB * S_KSTEPS * 64 * 32 + (size_t)round_up(S_PATCH, 8) * 4 + (size_t)256 * C * 4 + (size_t)2 * 8 * C * 4;
     LDN_REQUIRE(lds <= 160 * 1024, "ldn_stem_conv_pool: %zu B of LDS exceed 160 KiB", lds);
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_stem<NSUB>), lds), "k_stem: cannot reserve %zu B of LDS", lds);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;

@@ -40,10 +40,11 @@ def _model(factory, width_mult, batch, seed=3):
 def _restore():
     from laudnet_amd import ops
     from laudnet_amd.laud_resnet import Bottleneck, ResNet
+    widths = Bottleneck.fused_head_widths          # the library default (LDN_HEAD_WIDTHS), whatever it is
     yield
     ops.set_math_mode("fp32")
     ResNet.use_chain = True
-    Bottleneck.fused_head_widths = (256,)
+    Bottleneck.fused_head_widths = widths
 
 
 def _blocks(m):

@@ -61,8 +61,10 @@ def _eval_only(module: nn.Module, x: torch.Tensor):
 
 _SIDE_STREAMS = {}
 # Projection shortcuts on a side stream next to conv1 / conv2?  Round 1: yes (the main chain's launches left CUs idle).  With the
-# one-workgroup-per-CU kernels of round 2 the overlap only steals their CUs: inline is 1.3 % faster end to end (16.05 vs 16.27 ms).
-_USE_SIDE_STREAM = __import__("os").environ.get("LDN_SIDE_STREAM", "0") == "1"
+# one-workgroup-per-CU kernels of round 2 the overlap only stole their CUs (inline 1.3 % faster: 16.05 vs 16.27 ms).  Round 4: the
+# first blocks of stages 2-4 are k_head + one strided tail launch whose conv2 phase leaves the memory pipe idle, and the projection
+# (k_dense) fills it: 12.16-12.19 -> 12.09 ms, four interleaved runs on one box.  LDN_SIDE_STREAM=0 runs it inline.
+_USE_SIDE_STREAM = __import__("os").environ.get("LDN_SIDE_STREAM", "1") == "1"
 
 
 def _side_stream(dev):

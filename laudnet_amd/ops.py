@@ -210,7 +210,7 @@ def forward_stats(terms, static_flops, *, cnt=None, denom=None, st_in=None):
 # ---------------------------------------------------------------------------------------- a7 rows
 _SPLIT_CACHE = {}   # (data_ptr, _version, shape) of an fp32 weight -> its pre-split n-major copy (ldn_conv_rows_split)
 DENSE_TAPS = tuple(int(t) for t in os.environ.get("LDN_DENSE_TAPS", "1,9").split(","))   # tuning: "1,9" sends the packed-row 3x3 to k_dense too
-DENSE_CHANNEL_3X3 = os.environ.get("LDN_DENSE_CHANNEL_3X3", "0") != "0"   # the 3x3 of the dense channel execution (stage 4) on k_dense (measured: no gain)
+DENSE_CHANNEL_3X3 = os.environ.get("LDN_DENSE_CHANNEL_3X3", "1") != "0"   # the 3x3 of the dense channel execution (stage 4's first block) on k_dense's neighbour-table form, mask and post-ReLU constant in its epilogue (round 2: no gain; round 4: -0.05 ms per step, no separate mask pass)
 DENSE_K_MULT = int(os.environ.get("LDN_DENSE_K_MULT", "8"))   # tuning: 32 keeps layers whose widths are not multiples of 32 (LAD-RegNet 144 / 784) on the round-1 kernels
 DENSE_N_MULT = 4 if DENSE_K_MULT == 8 else 32
 USE_DENSE_KERNEL = os.environ.get("LDN_DENSE_KERNEL", "1") != "0"   # tuning switch: off keeps every packed-row 1x1 on the round-1 kernels

@@ -679,9 +679,9 @@ def main():
     agg = timer.summary()
     if agg:
         # per-launch HBM traffic of the stage-3 instance of each kernel from the committed PMC passes (profiles/)
-        tj = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if not os.path.exists(tj):
-            tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        import glob
+        tjs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))   # the latest round's committed PMC pass
+        tj = tjs[-1] if tjs else ""
         traffic = json.load(open(tj)) if (args.workload == "channel" and args.batch == 256 and os.path.exists(tj)) else {}
         mode = args.math
 

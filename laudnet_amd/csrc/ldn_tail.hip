@@ -666,7 +666,17 @@ static int tail_rows_per_block(int Hi, int Wi, int NS, int st, int* mblocks) {
     if (!fits(R)) return 0;
     const int mbk = ceil_div(Ho, R);
     *mblocks = mbk;
-    return ceil_div(Ho, mbk);
+    // Rows per workgroup among the sizes that need mbk workgroups: the one with the fewest 32-pixel wave tiles over the image (the balanced
+    // split first on ties).  A 28x28 map as 4 x 7 rows is 4 x 7 waves with a nearly empty last one (196 = 6.1 tiles); as 8 + 8 + 8 + 4
+    // rows it is 7 + 7 + 7 + 4 full ones: 25 instead of 28 wave tiles of work for the same pixels (round 4).
+    int best = ceil_div(Ho, mbk), best_waves = 1 << 30;
+    for (int r = ceil_div(Ho, mbk); r <= R; ++r) {
+        if (r * (mbk - 1) >= Ho) break;                 // the last workgroup would be empty
+        int waves = 0;
+        for (int i = 0; i < mbk; ++i) waves += ceil_div(min(r, Ho - r * i) * Wo, 32);
+        if (waves < best_waves) { best_waves = waves; best = r; }
+    }
+    return best;
 }
 
 template <int NS, int ST, bool PROJ = false>
@@ -1124,6 +1134,9 @@ static int bottleneck_head_impl(const float* x, int ldx, int B, int HW, int cin,
     a.xs = static_cast<unsigned char*>(x_split);
     a.mblocks = ceil_div(HW, 256);
     a.pix_per_blk = ceil_div(HW, a.mblocks);
+    // whole 32-pixel wave tiles per workgroup where that still takes the same number of workgroups (784 pixels: 224 + 224 + 224 + 112
+    // instead of 4 x 196 with a nearly empty seventh wave each)
+    if (const int up = round_up(a.pix_per_blk, 32); up <= 256 && (long)up * (a.mblocks - 1) < HW) a.pix_per_blk = up;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (width == 64) return launch_head<2>(a, st);
     if (width == 128) return launch_head<4>(a, st);

@@ -889,7 +889,21 @@ def main():
                 result["dense_emulation_gpu"] = {"error": repr(e)[:200]}
         if not args.no_cpu:
             host_cores = os.cpu_count() or 1
-            cores = min(host_cores, 32)   # torch CPU convs stop scaling (and thrash) far below 256 threads
+            # thread count: measured, not assumed -- one forward of a small batch at 16 / 32 / 64 / 128 threads (torch CPU convs stop
+            # scaling far below 256 threads on this host), the fastest count runs the timed sample
+            for rb in ((b.f if hasattr(b, "f") else b) for _, b in ref.blocks()):
+                rb.forced_channel_mask = rb.forced_spatial_mask = None
+            ref = ref.cpu()
+            xs_ = x[: min(args.cpu_batch, 8)].cpu().contiguous()
+            sweep = {}
+            for n_thr in sorted({min(host_cores, c) for c in (16, 32, 64, 128)}):
+                torch.set_num_threads(n_thr)
+                with torch.no_grad():
+                    ref(xs_[:2], 1.0)
+                    t0 = time.perf_counter()
+                    ref(xs_, 1.0)
+                    sweep[n_thr] = xs_.shape[0] / (time.perf_counter() - t0)
+            cores = max(sweep, key=sweep.get)
             torch.set_num_threads(cores)
             try:
                 cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
@@ -909,6 +923,7 @@ def main():
                 dt = (time.perf_counter() - t0) / reps
             result["cpu_baseline"] = {"value": args.cpu_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
                                       "host": f"{host_cores} logical cores, {cpu_model}",
+                                      "thread_sweep_images_per_sec": {str(k): round(v, 1) for k, v in sweep.items()},
                                       "sample": f"{reps} forward passes of batch {args.cpu_batch} (same model/weights/inputs), "
                                                 f"oracle dense emulation in torch fp32 on {cores} threads"}
     # second half of the BASELINE metric: the reference's analytic predictor with MI355X parameters (tools/predict_speedup.py,

@@ -161,6 +161,30 @@ __device__ __forceinline__ void channel_mlp_body(const int b, const float* __res
             }
             __syncthreads();
         } else {
+        if (s_part && splits > 16 && C <= NT && NT % C == 0) {
+            // many partials of a narrow map (the fused stem's hand-off: 56 tiles x 64 channels): NT / C thread groups each sum a contiguous
+            // range of splits with all loads in flight, the group sums are added in group order (deterministic) -- one wave walking 56
+            // dependent loads was 30 us of pure latency in front of the first block
+            const int R = NT / C, r = tid / C, c = tid - r * C;
+            const int per = (splits + R - 1) / R;
+            const int k_lo = r * per, k_hi = min(splits, k_lo + per);
+            float sacc = 0.f;
+            for (int k0 = k_lo; k0 < k_hi; k0 += 8) {
+                float pv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pv[k] = k0 + k < k_hi ? partial[((size_t)b * splits + k0 + k) * C + c] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k0 + k < k_hi) sacc += pv[k];
+            }
+            s_part[(size_t)r * C + c] = sacc;
+            __syncthreads();
+            if (tid < C) {
+                float t = 0.f;
+                for (int r2 = 0; r2 < R; ++r2) t += s_part[(size_t)r2 * C + tid];
+                s_gap[tid] = t * inv;
+            }
+        } else
         for (int c = tid; c < C; c += NT) {
             float s = 0.f;
             for (int k = 0; k < splits; ++k) s += partial[((size_t)b * splits + k) * C + c];

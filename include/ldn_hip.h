@@ -140,6 +140,15 @@ int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps
                         int ldo, const float* post_sub, const float* chan_mask, int rows_per_image, int shift_classes,
                         const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride, const float* ln_stats,
                         const float* ln_c1, void* stream);
+/* The same kernel in TRUE fp32 arithmetic (v_mfma_f32_32x32x2_f32: fp32 multiply and accumulate, the `fp32` math mode): w is the plain
+ * row-major fp32 weight matrix [cout][taps * cin] (tap-major rows for taps == 9) -- no pre-split copy; every other argument as in
+ * ldn_conv_rows_split.  Five times the matrix time of the bf16x3 form per product, the same staging pipeline and epilogue. */
+int ldn_conv_rows_f32(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
+                        const float* w, int cin, int cout, const float* scale, const float* shift, int relu,
+                        const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr, float* out,
+                        int ldo, const float* post_sub, const float* chan_mask, int rows_per_image, int shift_classes,
+                        const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride, const float* ln_stats,
+                        const float* ln_c1, void* stream);
 /* stats[r] = {mean, 1 / sqrt(biased variance + eps)} of row r of x [rows][ld >= C] (nn.LayerNorm's statistics), C % 4 == 0, C <= 2048 */
 int ldn_row_stats(const float* x, int ld, int rows, int C, float eps, float* stats, void* stream);
 

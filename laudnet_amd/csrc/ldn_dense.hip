@@ -79,7 +79,11 @@ constexpr int D_ROW_RELU = 1 << 30;
 // NSUB = n-subtiles of 32 columns per workgroup (2, 4, 8); D = ring depth (2 for NSUB 8, 3 otherwise)
 // T9: 3x3 over a neighbour table (compiled apart: the 1x1 form carries none of its tables or branches); FULL: cout is a multiple of
 // the tile width, so every workgroup owns NSUB whole n-subtiles (compiled apart: no per-subtile branch in the K loop)
-template <int NSUB, bool T9, bool FULL>
+// F32: true-fp32 arithmetic (v_mfma_f32_32x32x2_f32, fp32 multiply and accumulate -- the `fp32` math mode of the library).  The byte
+// layouts coincide with the bf16x3 form: an element takes 4 bytes either way (bf16 hi + bf16 lo, or one float), so ws is then the plain
+// row-major fp32 weight matrix [cout][taps * cin] ([n][octet][8 floats]), the staging pipeline is the same, and a K16 step is eight
+// 32x32x2 instructions (instruction i pairs k-slot i of lane half 0 with k-slot i of lane half 1) instead of three 32x32x16 ones.
+template <int NSUB, bool T9, bool FULL, bool F32 = false>
 __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     constexpr int NT = NSUB * 32;
     constexpr int D = NSUB == 8 ? 2 : 3;
@@ -238,12 +242,16 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         const unsigned char* xs = s_ring + (c % D) * SLOT;
         const unsigned char* ws = xs + D_ROWS * 128;
         // B operands of both K16 steps of the chunk: the wave's 32 rows, split into bf16 hi / lo once for all n-subtiles
-        bf16x8 bh[2], bl[2];
+        bf16x8 bh[2], bl[2];       // F32: bh = the lane's k-slots 0-3, bl = k-slots 4-7 as raw floats (bit patterns)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const unsigned sl = 4u * half + 2u * h;
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
+            if constexpr (F32) {
+                bh[half] = __builtin_bit_cast(bf16x8, x0);
+                bl[half] = __builtin_bit_cast(bf16x8, x1);
+            } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = e < 4 ? x0[e] : x1[e - 4];
@@ -251,6 +259,19 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
                 bh[half][e] = hb;
                 bl[half][e] = (__bf16)(v - (float)hb);
             }
+            }
+        }
+        // one K16 step of n-subtile j_: bf16x3 = three 32x32x16 products of the hi / lo halves; F32 = eight 32x32x2 products of raw floats
+#define LDN_DENSE_STEP(ACC_, AH_, AL_, BH_, BL_) \
+        if constexpr (F32) { \
+            const f32x4 a0_ = __builtin_bit_cast(f32x4, AH_), a1_ = __builtin_bit_cast(f32x4, AL_); \
+            const f32x4 b0_ = __builtin_bit_cast(f32x4, BH_), b1_ = __builtin_bit_cast(f32x4, BL_); \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[i_], b0_[i_], ACC_, 0, 0, 0); \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[i_], b1_[i_], ACC_, 0, 0, 0); \
+        } else { \
+            ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL_, BH_, ACC_, 0, 0, 0); \
+            ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH_, BL_, ACC_, 0, 0, 0); \
+            ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH_, BH_, ACC_, 0, 0, 0); \
         }
 #ifdef LDN_TRACE
         asm volatile("" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
@@ -280,9 +301,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
 #if LDN_DENSE_ABLATE & 4
                 asm volatile("" : "+v"(acc[j]) : "v"(al[st & 1]), "v"(ah[st & 1]), "v"(bh[half]), "v"(bl[half]));
 #else
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st & 1], bh[half], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bl[half], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bh[half], acc[j], 0, 0, 0);
+                LDN_DENSE_STEP(acc[j], ah[st & 1], al[st & 1], bh[half], bl[half])
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (st < 4 + nwi) {                   // one DMA instruction of the next chunk behind this step's MFMAs
@@ -301,9 +320,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
                     if (j < nsub) {
                         bf16x8 ah, al;
                         frag(half * NSUB + j, ah, al);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[half], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[half], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[half], acc[j], 0, 0, 0);
+                        LDN_DENSE_STEP(acc[j], ah, al, bh[half], bl[half])
                     }
                 }
             }
@@ -314,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         a_wait += d1 - d0; a_bar += d2 - d1; a_issue += d3 - d2; a_prep += d4 - d3; a_mfma += d5 - d4;
 #endif
     }
+#undef LDN_DENSE_STEP
 #ifdef LDN_TRACE
     DT(d_loop)
 #endif
@@ -441,23 +459,23 @@ __global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, 
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_dense)
 
-template <int NSUB, bool T9, bool FULL>
+template <int NSUB, bool T9, bool FULL, bool F32 = false>
 static int launch_dense_f(DenseArgs& a, hipStream_t st) {
     constexpr int NT = NSUB * 32;
     constexpr int D = NSUB == 8 ? 2 : 3;
     const size_t lds = (size_t)(T9 ? 12 : 2) * D_ROWS * 4 + (size_t)D * (D_ROWS + NT) * 128;
     a.ntn = ceil_div(a.cout, NT);
     a.mtn = ceil_div(a.m_cap, D_ROWS);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB, T9, FULL>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB, T9, FULL, F32>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
     const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
-    hipLaunchKernelGGL((k_dense<NSUB, T9, FULL>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_dense<NSUB, T9, FULL, F32>), dim3(grid), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_dense");
     return LDN_OK;
 }
 
-template <int NSUB, bool T9>
+template <int NSUB, bool T9, bool F32 = false>
 static int launch_dense(DenseArgs& a, hipStream_t st) {
-    return a.cout % (NSUB * 32) == 0 ? launch_dense_f<NSUB, T9, true>(a, st) : launch_dense_f<NSUB, T9, false>(a, st);
+    return a.cout % (NSUB * 32) == 0 ? launch_dense_f<NSUB, T9, true, F32>(a, st) : launch_dense_f<NSUB, T9, false, F32>(a, st);
 }
 
 }  // namespace ldn
@@ -471,12 +489,39 @@ extern "C" int ldn_debug_set_dense_trace(void* buf) {
 }
 #endif
 
+static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
+                                const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
+                                const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
+                                float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
+                                int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
+                                const float* ln_stats, const float* ln_c1, bool f32, void* stream);
+
 extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                                    const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
                                    const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
                                    float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
                                    int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
                                    const float* ln_stats, const float* ln_c1, void* stream) {
+    return conv_rows_dense_impl(a, lda, a_rows, taps, m_count, m_cap, w_split, cin, cout, scale, shift, relu, relu_if_neg, out_rows, residual, ldr,
+                                out, ldo, post_sub, chan_mask, rows_per_image, shift_classes, pix_map, Hi, Wi, Ho, Wo, stride, ln_stats, ln_c1, false, stream);
+}
+
+extern "C" int ldn_conv_rows_f32(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
+                                 const float* w, int cin, int cout, const float* scale, const float* shift, int relu,
+                                 const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
+                                 float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
+                                 int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
+                                 const float* ln_stats, const float* ln_c1, void* stream) {
+    return conv_rows_dense_impl(a, lda, a_rows, taps, m_count, m_cap, w, cin, cout, scale, shift, relu, relu_if_neg, out_rows, residual, ldr,
+                                out, ldo, post_sub, chan_mask, rows_per_image, shift_classes, pix_map, Hi, Wi, Ho, Wo, stride, ln_stats, ln_c1, true, stream);
+}
+
+static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
+                                const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
+                                const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
+                                float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
+                                int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
+                                const float* ln_stats, const float* ln_c1, bool f32, void* stream) {
     LDN_REQUIRE(a && w_split && shift && out, "ldn_conv_rows_split: null pointer");
     LDN_REQUIRE((ln_stats == nullptr) == (ln_c1 == nullptr) && (!ln_stats || taps == 1), "ldn_conv_rows_split: ln_stats and ln_c1 go together (1x1 only)");
     LDN_REQUIRE((uintptr_t)ln_stats % 8 == 0 && (uintptr_t)ln_c1 % 16 == 0, "ldn_conv_rows_split: ln_stats / ln_c1 must be 8 / 16-byte aligned");
@@ -498,6 +543,14 @@ extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_row
     hipStream_t st = static_cast<hipStream_t>(stream);
     // columns per workgroup: as wide as the layer allows (fewer passes over the activation rows) while the grid still fills the chip
     const int mt = ceil_div(m_cap, D_ROWS);
+    if (f32) {   // true-fp32 MFMA: the same tile rules (the matrix time per tile is 5.3x longer, the staging the same)
+        if (taps == 9) return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true, true>(d, st) : launch_dense<2, true, true>(d, st);
+        if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8, false, true>(d, st);
+        if (cout % 128 == 0) return launch_dense<4, false, true>(d, st);
+        if (cout <= 64) return launch_dense<2, false, true>(d, st);
+        if (cout % 160 == 0 || (cout % 32 != 0 && cout > 128)) return launch_dense<5, false, true>(d, st);
+        return launch_dense<4, false, true>(d, st);
+    }
     if (taps == 9) return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true>(d, st) : launch_dense<2, true>(d, st);
     if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8, false>(d, st);
     if (cout % 128 == 0) return launch_dense<4, false>(d, st);

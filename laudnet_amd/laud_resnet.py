@@ -444,7 +444,7 @@ class Bottleneck(_PrepCache):
                               ).reshape(-1, 1, W).contiguous().to(dev)
         ix = self._dense_ix(B, Ho, Wo, dev)
         x2d = xn.reshape(B * Hi * Wi, Cin)
-        fused_mask = ops.get_math_mode() == "bf16x3" and Cin % 32 == 0 and W % 32 == 0 and ops.USE_DENSE_KERNEL
+        fused_mask = ops.dense_kernel_ok() and Cin % 32 == 0 and W % 32 == 0
         chm2d = chm.reshape(B, W).contiguous()
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
         if fused_mask:   # k_dense: the per-image channel mask and the post-ReLU constant are epilogue terms (no pass over h1)
@@ -539,7 +539,7 @@ class Bottleneck(_PrepCache):
         spans the batch (M tiles then hold rows of several images) instead of per-image tiles that would be mostly empty."""
         B, Hi, Wi, Cin = xn.shape
         _, Ho, Wo, cout = identity.shape
-        if Ho * Wo < 96 or (ops.get_math_mode() == "bf16x3" and ops.USE_DENSE_KERNEL and Cin % 32 == 0 and cout % 32 == 0):
+        if Ho * Wo < 96 or (ops.dense_kernel_ok() and Cin % 32 == 0 and cout % 32 == 0):
             # one list of strided pixel rows over the batch (k_dense in bf16x3 mode: pre-split shared weights, 256-row tiles)
             ops.conv_rows(xn.reshape(B * Hi * Wi, Cin), p["wd"], p["sd"], p["td"], identity.view(B * Ho * Wo, cout), taps=1,
                           m_cap=B * Ho * Wo, a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], xn.device), relu=0)

@@ -214,6 +214,18 @@ DENSE_CHANNEL_3X3 = os.environ.get("LDN_DENSE_CHANNEL_3X3", "1") != "0"   # the 
 DENSE_K_MULT = int(os.environ.get("LDN_DENSE_K_MULT", "8"))   # tuning: 32 keeps layers whose widths are not multiples of 32 (LAD-RegNet 144 / 784) on the round-1 kernels
 DENSE_N_MULT = 4 if DENSE_K_MULT == 8 else 32
 USE_DENSE_KERNEL = os.environ.get("LDN_DENSE_KERNEL", "1") != "0"   # tuning switch: off keeps every packed-row 1x1 on the round-1 kernels
+# fp32 math mode on k_dense's true-fp32 form (ldn_conv_rows_f32)?  Measured (round 4, bs256, one box): RegNet 7.12 -> 6.88 ms, but spatial
+# 27.5 -> 32.6 and layer 25.1 -> 29.0 ms: at fp32 MFMA rates every tile is matrix-bound, so the 256-row tiles' under-filled grids (98-196
+# workgroups on 256 CUs at stage 3) cost their full share while round 1's smaller tiles fill the chip -- off by default, kept as the
+# ABI's fp32 entry point with the epilogue features (channel mask, shift table, LayerNorm / GELU terms) round 1's kernel lacks
+USE_DENSE_F32 = os.environ.get("LDN_DENSE_F32", "0") != "0"
+
+
+def dense_kernel_ok():
+    """Does the current arithmetic mode run the shared-weight row convolutions on k_dense (bf16x3: ldn_conv_rows_split; fp32:
+    ldn_conv_rows_f32)?"""
+    mode = get_math_mode()
+    return USE_DENSE_KERNEL and (mode == "bf16x3" or (mode == "fp32" and USE_DENSE_F32))
 
 
 def split_rows_weight(w):
@@ -263,22 +275,25 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
     # SLOWER there than round 1's producer/consumer kernel (spatial 17.8 -> 19.1 ms); with the pinned schedule it is faster on the
     # packed-row paths (spatial 16.62 -> 16.31 ms, same box) and neutral on the dense channel execution of stage 4, which stays on
     # k_conv_bf3 (DENSE_CHANNEL_3X3).  LDN_DENSE_TAPS=1 restores the old dispatch.
-    dense_ok = (USE_DENSE_KERNEL and mode == "bf16x3" and taps in DENSE_TAPS and cin % DENSE_K_MULT == 0 and cout % DENSE_N_MULT == 0
-                and a2d.stride(0) >= cin)
+    # round 4: the same kernel in true-fp32 MFMA arithmetic (ldn_conv_rows_f32: plain fp32 weights, no split copy) -- the fp32 math mode
+    # no longer falls back to round 1's producer / consumer kernel on the shared-weight row paths
+    dense_ok = (USE_DENSE_KERNEL and (mode == "bf16x3" or (mode == "fp32" and USE_DENSE_F32)) and taps in DENSE_TAPS
+                and cin % DENSE_K_MULT == 0 and cout % DENSE_N_MULT == 0 and a2d.stride(0) >= cin)
     classes = 1 if shift.dim() == 1 else shift.shape[0]
     if (post_sub is not None or chan_mask is not None or classes != 1 or relu == 3 or ln_stats is not None) and not dense_ok:
-        raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table / the GELU and LayerNorm epilogues need the bf16x3 path (cin, cout multiples of 32)")
+        raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table / the GELU and LayerNorm epilogues need the k_dense path (cin % 8 == 0, cout % 4 == 0)")
     if dense_ok:
         hi, wi, ho, wo, stride = geom if geom is not None else (0, 0, 0, 0, 1)
-        L.check(lib.ldn_conv_rows_split(L.ptr(_f32rows(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")), taps,
-                                        L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(split_rows_weight(w)), cin, cout,
+        fn, wptr = ((lib.ldn_conv_rows_split, split_rows_weight(w)) if mode == "bf16x3" else (lib.ldn_conv_rows_f32, _f32c(w, "w")))
+        L.check(fn(L.ptr(_f32rows(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")), taps,
+                                        L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(wptr), cin, cout,
                                         L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,
                                         L.ptr(_i32c(relu_if_neg, "relu_if_neg")), L.ptr(_i32c(out_rows, "out_rows")),
                                         L.ptr(_f32rows(residual2d, "residual")), residual2d.stride(0) if residual2d is not None else 0,
                                         L.ptr(_f32rows(out2d, "out")), out2d.stride(0), L.ptr(_f32c(post_sub, "post_sub")),
                                         L.ptr(_f32c(chan_mask, "chan_mask")), rows_per_image, classes, L.ptr(_i32c(pix_map, "pix_map")),
                                         hi, wi, ho, wo, stride, L.ptr(_f32c(ln_stats, "ln_stats")), L.ptr(_f32c(ln_c1, "ln_c1")),
-                                        L.stream_ptr(out2d)), "ldn_conv_rows_split")
+                                        L.stream_ptr(out2d)), "ldn_conv_rows_split" if mode == "bf16x3" else "ldn_conv_rows_f32")
         return out2d
     L.check(lib.ldn_conv_rows(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")), taps,
                               L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(_f32c(w, "w")), cin, cout,

@@ -495,10 +495,10 @@ def test_expand_mask_module_vs_reference_fixtures(ops):
 
 @pytest.mark.parametrize("B,H,C,cout,stride", [(2, 14, 32, 64, 1), (3, 14, 64, 64, 2)])
 def test_dense_kernel_3x3_neighbour_table(ops, B, H, C, cout, stride, math_mode):
-    """k_dense's 3x3 form (ldn_conv_rows_split, taps == 9) is not dispatched by default (slower than the round-1 kernel) but is
-    part of the ABI: same result as the default path on the spatial-mode slice mask -> index -> 3x3 through the neighbour table."""
-    if math_mode != "bf16x3":
-        pytest.skip("k_dense is the bf16x3 kernel")
+    """k_dense's 3x3 form (ldn_conv_rows_split / ldn_conv_rows_f32, taps == 9): same result as round 1's kernel on the spatial-mode slice
+    mask -> index -> 3x3 through the neighbour table, in both arithmetic modes (round 4: the fp32 mode has its own k_dense form, opt-in)."""
+    f32_before = ops.USE_DENSE_F32
+    ops.USE_DENSE_F32 = True
     Ho = H // stride if stride > 1 else H
     patch = seeded_bernoulli((B, Ho, Ho), 0.5, 11)
     ix = ops.mask_to_index(patch.to(DEV), Ho, Ho, stride)
@@ -514,6 +514,7 @@ def test_dense_kernel_3x3_neighbour_table(ops, B, H, C, cout, stride, math_mode)
             outs.append(out.cpu())
         finally:
             ops.DENSE_TAPS = (1,)
+            ops.USE_DENSE_F32 = f32_before if taps_set == (1, 9) else True
     n = int(ix.cnt[0])
     assert torch.allclose(outs[0][:n], outs[1][:n], atol=1e-4, rtol=1e-4)
 
@@ -614,3 +615,41 @@ def test_dense_256_tiles_fullsize_rows_vs_fp64(ops, rows, cin, cout, count):
             assert torch.allclose(out2.cpu(), want2, atol=1e-4, rtol=1e-4)
     finally:
         ops.set_math_mode(None)
+
+
+@pytest.mark.parametrize("rows,cin,cout,taps", [(1000, 64, 256, 1), (700, 256, 64, 1), (513, 40, 144, 1), (600, 32, 128, 9)])
+def test_conv_rows_f32_kernel_vs_fp64(ops, rows, cin, cout, taps):
+    """ldn_conv_rows_f32 (k_dense in true-fp32 MFMA arithmetic, opt-in: ops.USE_DENSE_F32): gathered rows, ragged widths, the 3x3
+    neighbour-table form, residual + ReLU -- against fp64 at fp32 round-off."""
+    from laudnet_amd import ops as _o
+    before = (_o.USE_DENSE_F32, _o.get_math_mode())
+    _o.USE_DENSE_F32 = True
+    _o.set_math_mode("fp32")
+    try:
+        a = seeded_randn((rows, cin), 3)
+        w = seeded_randn((cout, taps, cin), 4) * (1.0 / (taps * cin)) ** 0.5
+        sh = seeded_randn((cout,), 5) * 0.1
+        res = seeded_randn((rows, cout), 6)
+        if taps == 1:
+            src = torch.randperm(rows, generator=torch.Generator().manual_seed(7)).to(torch.int32)
+            want = torch.relu(a.double()[src.long()] @ w.double().reshape(cout, cin).t() + sh.double() + res.double())
+            a_rows = src.to(DEV)
+        else:
+            nb = torch.randint(-1, rows, (rows, 9), generator=torch.Generator().manual_seed(8)).to(torch.int32)
+            g = torch.where(nb.unsqueeze(-1) >= 0, a.double()[nb.clamp(min=0).long()], torch.zeros(1, dtype=torch.float64))   # [rows, 9, cin]
+            want = torch.relu(torch.einsum("rtc,otc->ro", g, w.double()) + sh.double() + res.double())
+            a_rows = nb.to(DEV)
+        out = torch.zeros(rows, cout, device=DEV)
+        seen = []
+        lib = L_load()
+        _o.conv_rows(a.to(DEV), w.to(DEV), None, sh.to(DEV), out, a_rows=a_rows, taps=taps, m_cap=rows, relu=1, residual2d=res.to(DEV))
+        err = (out.cpu().double() - want).abs().max().item()
+        assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+    finally:
+        _o.USE_DENSE_F32 = before[0]
+        _o.set_math_mode(before[1])
+
+
+def L_load():
+    from laudnet_amd import _lib
+    return _lib.load()

@@ -120,6 +120,28 @@ def bench_adavit(args):
         roof = dict(two_floor("k_dense (the q/k/v, projection and MLP linears of the token-skip blocks over packed token rows, bf16x3; "
                               "averaged over all such launches of a forward)", n_, ms_, f_, by_, 3.0),
                     timed_ms_per_step=ms_ / 2, steps_bracketed=2)
+    # head + layer skipping on top (simulate_adavit.py:81-88,140-182): per-image head masks (keep 0.7) and attention / MLP sub-block
+    # decisions (keep 0.8), seeded; same trunk, same token masks
+    extra = {}
+    try:
+        hks = [seeded_bernoulli((args.batch, heads), 0.7, 3000 + i).to(dev) for i in range(depth)]
+        aks = [seeded_bernoulli((args.batch,), 0.8, 3100 + i).to(dev) for i in range(depth)]
+        mks = [seeded_bernoulli((args.batch,), 0.8, 3200 + i).to(dev) for i in range(depth)]
+        with torch.no_grad():
+            for _ in range(2):
+                o2 = hip(x, keeps, hks, aks, mks)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(2, args.steps // 2)):
+                o2 = hip(x, keeps, hks, aks, mks)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / max(2, args.steps // 2)
+            w2 = refg(x, keeps, hks, aks, mks)
+        extra["token_head_layer_skipping"] = {"value": args.batch / dt2, "unit": "images/sec", "ms_per_step": 1e3 * dt2,
+                                              "head_keep": 0.7, "attention_block_keep": 0.8, "mlp_block_keep": 0.8,
+                                              "max_abs_diff_vs_dense_restatement": (o2 - w2).abs().max().item()}
+    except Exception as e:   # informative only
+        extra["token_head_layer_skipping"] = {"error": repr(e)[:200]}
     kept = float(sum(k.sum().item() for k in keeps)) / (depth * args.batch * L)
     # algorithmic FLOPs per image: qkv on every token, attention / proj / MLP on the kept ones (simulate_adavit.py:77-182)
     lk = kept * L
@@ -136,7 +158,7 @@ def bench_adavit(args):
                                       "kind": "oracle/adavit_ref.py (dense masked attention, every token through every linear), PyTorch-ROCm fp32, same GPU",
                                       "max_abs_diff_vs_hip_same_masks": (out - want).abs().max().item(),
                                       "output_scale": want.abs().max().item()},
-              "realised_speedup_vs_dense_emulation": dtd / dt}
+              "realised_speedup_vs_dense_emulation": dtd / dt, **extra}
     print(json.dumps(result))
 
 

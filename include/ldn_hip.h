@@ -388,6 +388,10 @@ size_t ldn_se_packed_workspace_bytes(int B, int C, int max_rows_per_image);
  * heads concatenated.  bf16x3 products, fp32 softmax. */
 int ldn_packed_mha(const float* qkv, int ld_qkv, const int32_t* tok_rows, const int32_t* img_prefix, int B, int heads,
                    int head_dim, int max_tokens, float scale, float* out, int ldo, void* stream);
+/* ... with HEAD skipping (simulate_adavit.py:81-88: attention over the selected heads of every image): head_keep [B][heads] {0,1}; the
+ * workgroup of a dropped (image, head) writes zeros to its 64 output columns and computes nothing. */
+int ldn_packed_mha_heads(const float* qkv, int ld_qkv, const int32_t* tok_rows, const int32_t* img_prefix, int B, int heads,
+                         int head_dim, int max_tokens, float scale, const float* head_keep, float* out, int ldo, void* stream);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "ldn_stem3_weight_bytes": ([_I], C.c_size_t),
     "ldn_stem3_conv": ([_P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P], _I),
     "ldn_packed_mha": ([_P, _I, _P, _P, _I, _I, _I, _I, C.c_float, _P, _I, _P], _I),
+    "ldn_packed_mha_heads": ([_P, _I, _P, _P, _I, _I, _I, _I, C.c_float, _P, _P, _I, _P], _I),
     "ldn_bottleneck_chain_fits": ([_I, _I, _I, _I, _I, _I], _I),
     "ldn_bottleneck_smallmap_fits": ([_I, _I, _I, _I, _I], _I),
     "ldn_bottleneck_smallmap": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),

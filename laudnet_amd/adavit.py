@@ -5,7 +5,9 @@ The reference ships no model for this configuration, only the latency model of i
 MLP / residual updates on the selected tokens only.  This module executes that operator list on PACKED token lists with the
 kernels of libldn_hip.so: the keep mask becomes a row list (ldn_mask_to_index on a [B, L, 1] mask), the linears are the packed-row
 1x1 kernel (k_dense: gather rows in, scatter-add rows out, fused bias + residual), the attention is ldn_packed_mha (one workgroup
-per image and head over the image's kept tokens).  LayerNorm and GELU are epilogue terms of the linears (ldn_row_stats + the ln_* / relu-mode-3 arguments of ldn_conv_rows_split).  Parity is UNPINNED (there is
+per image and head over the image's kept tokens).  HEAD skipping (a per-image head mask: q / k / v masked in the linear's epilogue, the
+dropped heads' attention workgroups compute nothing) and LAYER skipping (per-image decisions for the attention and the MLP sub-block: the
+image has no tokens in that sub-block's list) of simulate_adavit.py:81-88,140-182 ride on the same lists.  LayerNorm and GELU are epilogue terms of the linears (ldn_row_stats + the ln_* / relu-mode-3 arguments of ldn_conv_rows_split).  Parity is UNPINNED (there is
 nothing in the reference to pin it to): tests compare against oracle/adavit_ref.py, a dense masked restatement of the same operator
 list.  Inference only; no CPU fallback."""
 from __future__ import annotations
@@ -61,33 +63,67 @@ class TokenSkipBlock(nn.Module):
                 self._w = (key, after_ln(self.qkv, self.norm1), plain(self.proj), after_ln(self.fc1, self.norm2), plain(self.fc2))
         return self._w[1:]
 
-    def run_packed(self, x2d, tok_rows, prefix, count, B, max_tokens):
-        """x2d [B*L, dim] fp32, updated IN PLACE on the kept tokens; tok_rows / prefix / count from ops.token_lists."""
+    def run_packed(self, x2d, tok_rows, prefix, count, B, max_tokens, head_keep=None, mlp_lists=None, qkv_rows=None):
+        """x2d [B*L, dim] fp32, updated IN PLACE on the kept tokens; tok_rows / prefix / count from ops.token_lists (the attention
+        sub-block's token list).  Head and layer skipping (simulate_adavit.py:81-88,140-182), all optional:
+          head_keep [B, heads] {0,1}  heads each image attends with: q / k / v of a dropped head are masked in the linear's epilogue,
+                                      its attention workgroup computes nothing and contributes zeros to the projection;
+          mlp_lists (rows, prefix, count)  the MLP sub-block's own token list (layer skipping decides the two sub-blocks separately:
+                                      an image whose attention / MLP is skipped simply has no tokens in that list);
+          qkv_rows (rows, count)      token rows q / k / v are computed for (default: every token; with layer skipping: the tokens
+                                      of the images whose attention sub-block runs)."""
         if self.training:
             raise LdnError("laudnet_amd implements the eval-mode (inference) hot path only")
         if ops.get_math_mode() != "bf16x3":
             raise LdnError("TokenSkipBlock runs in the bf16x3 arithmetic mode (ops.set_math_mode('bf16x3'))")
         (wq, bq, cq), (wp, bp), (w1, b1, c1), (w2, b2) = self._weights(x2d.device)
         rows = x2d.shape[0]
+        Lt = rows // B
         st = ops.row_stats(x2d, self.norm1.eps)                                                 # {mean, rstd} of every token (norm1)
         qkv = torch.empty(rows, 3 * self.dim, device=x2d.device, dtype=torch.float32)
-        ops.conv_rows(x2d, wq, None, bq, qkv, taps=1, m_cap=rows, relu=0, ln_stats=st, ln_c1=cq)    # norm1 + q / k / v for every token
-        att = ops.packed_mha(qkv, tok_rows, prefix, B, self.heads, max_tokens)                  # [capacity, dim], packed
+        hk3 = None
+        if head_keep is not None:     # [B, 3 * dim]: the head's decision over its 64 channels of q, k and v
+            hk = head_keep.float().reshape(B, self.heads)
+            hk3 = hk.repeat_interleave(self.dim // self.heads, dim=1).repeat(1, 3).contiguous()
+        if qkv_rows is None:
+            ops.conv_rows(x2d, wq, None, bq, qkv, taps=1, m_cap=rows, relu=0, ln_stats=st, ln_c1=cq, chan_mask=hk3,
+                          rows_per_image=Lt if hk3 is not None else 0)                           # norm1 + q / k / v for every token
+        else:
+            ops.conv_rows(x2d, wq, None, bq, qkv, a_rows=qkv_rows[0], out_rows=qkv_rows[0], taps=1, m_count=qkv_rows[1], m_cap=rows, relu=0,
+                          ln_stats=st, ln_c1=cq, chan_mask=hk3, rows_per_image=Lt if hk3 is not None else 0)
+        att = ops.packed_mha(qkv, tok_rows, prefix, B, self.heads, max_tokens,
+                             head_keep=None if head_keep is None else head_keep.float().reshape(B, self.heads).contiguous())   # [capacity, dim], packed
         ops.conv_rows(att, wp, None, bp, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d)
+        m_rows, _, m_count = mlp_lists if mlp_lists is not None else (tok_rows, prefix, count)
         st = ops.row_stats(x2d, self.norm2.eps)                                                 # norm2 (after the attention update)
         hid = torch.empty(rows, w1.shape[0], device=x2d.device, dtype=torch.float32)
-        ops.conv_rows(x2d, w1, None, b1, hid, a_rows=tok_rows, taps=1, m_count=count, m_cap=rows, relu=3, ln_stats=st, ln_c1=c1)   # norm2 + fc1 + GELU
-        ops.conv_rows(hid, w2, None, b2, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d)
+        ops.conv_rows(x2d, w1, None, b1, hid, a_rows=m_rows, taps=1, m_count=m_count, m_cap=rows, relu=3, ln_stats=st, ln_c1=c1)   # norm2 + fc1 + GELU
+        ops.conv_rows(hid, w2, None, b2, x2d, taps=1, m_count=m_count, m_cap=rows, relu=0, out_rows=m_rows, residual2d=x2d)
         return x2d
 
-    def forward(self, x, keep):
-        """x [B, L, dim], keep [B, L] {0,1} -> new [B, L, dim] (kept tokens updated, the others passed through)."""
+    @staticmethod
+    def skip_lists(keep, attn_keep=None, mlp_keep=None):
+        """Token lists of a block under token + layer skipping: keep [B, L] {0,1}; attn_keep / mlp_keep [B] {0,1} (None = run).
+        -> (attention list (rows, prefix, count), MLP list or None, q/k/v rows (rows, count) or None)."""
+        B, Lt = keep.shape
+        ka = keep if attn_keep is None else keep * attn_keep.view(B, 1).to(keep.dtype)
+        a_list = ops.token_lists(ka.contiguous())
+        m_list = None if mlp_keep is None else ops.token_lists((keep * mlp_keep.view(B, 1).to(keep.dtype)).contiguous())
+        q_rows = None
+        if attn_keep is not None:
+            r, _, c = ops.token_lists(attn_keep.view(B, 1).to(keep.dtype).expand(B, Lt).contiguous())
+            q_rows = (r, c)
+        return a_list, m_list, q_rows
+
+    def forward(self, x, keep, head_keep=None, attn_keep=None, mlp_keep=None):
+        """x [B, L, dim], keep [B, L] {0,1} -> new [B, L, dim] (kept tokens updated, the others passed through).  head_keep [B, heads],
+        attn_keep / mlp_keep [B]: head and layer skipping (see run_packed)."""
         B, Lt, D = x.shape
         if Lt > 256:    # ldn_packed_mha holds at most 256 kept tokens of an image in LDS: more would be dropped silently
             raise LdnError("TokenSkipBlock: at most 256 tokens per image (ldn_packed_mha)")
         x2d = x.reshape(B * Lt, D).clone()
-        tok_rows, prefix, count = ops.token_lists(keep)
-        self.run_packed(x2d, tok_rows, prefix, count, B, Lt)
+        (tok_rows, prefix, count), m_list, q_rows = self.skip_lists(keep, attn_keep, mlp_keep)
+        self.run_packed(x2d, tok_rows, prefix, count, B, Lt, head_keep=head_keep, mlp_lists=m_list, qkv_rows=q_rows)
         return x2d.view(B, Lt, D)
 
 
@@ -99,12 +135,14 @@ class TokenSkipViT(nn.Module):
         super().__init__()
         self.blocks = nn.ModuleList(TokenSkipBlock(dim, heads, mlp_ratio) for _ in range(depth))
 
-    def forward(self, x, keeps):
+    def forward(self, x, keeps, head_keeps=None, attn_keeps=None, mlp_keeps=None):
+        """keeps[i] [B, L]; optional per-block head_keeps[i] [B, heads], attn_keeps[i] / mlp_keeps[i] [B] (head / layer skipping)."""
         B, Lt, D = x.shape
         if Lt > 256:
             raise LdnError("TokenSkipViT: at most 256 tokens per image (ldn_packed_mha)")
         x2d = x.reshape(B * Lt, D).clone()
-        for blk, keep in zip(self.blocks, keeps):
-            tok_rows, prefix, count = ops.token_lists(keep)
-            blk.run_packed(x2d, tok_rows, prefix, count, B, Lt)
+        pick = lambda seq, i: None if seq is None else seq[i]
+        for i, (blk, keep) in enumerate(zip(self.blocks, keeps)):
+            (tok_rows, prefix, count), m_list, q_rows = blk.skip_lists(keep, pick(attn_keeps, i), pick(mlp_keeps, i))
+            blk.run_packed(x2d, tok_rows, prefix, count, B, Lt, head_keep=pick(head_keeps, i), mlp_lists=m_list, qkv_rows=q_rows)
         return x2d.view(B, Lt, D)

@@ -28,6 +28,7 @@ struct MhaArgs {
     float scale;
     float* out; int ldo;                // packed rows [N][ldo]
     int vs;                             // row stride of V^T in LDS (floats): multiple of 4, = 4 mod 32
+    const float* head_keep;             // optional [B][heads] {0,1}: head skipping (simulate_adavit.py:81-88) -- a dropped head's output is 0
 };
 
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
@@ -46,6 +47,11 @@ __global__ __launch_bounds__(512, 2) void k_packed_mha(const MhaArgs p) {
     const int n0 = p.prefix[b];
     const int Lb = min(p.prefix[b + 1] - n0, A_MAXTOK);
     if (Lb <= 0) return;
+    if (p.head_keep && p.head_keep[(size_t)b * p.heads + hd] < 0.5f) {   // head skipped for this image: its 64 output columns are zero
+        for (int i = threadIdx.x; i < Lb * 16; i += 512)
+            *reinterpret_cast<f32x4*>(p.out + (size_t)(n0 + (i >> 4)) * p.ldo + hd * A_D + (i & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int Lp = round_up(Lb, 32);
     float* const s_k = reinterpret_cast<float*>(smem);                   // [Lp][A_KS]
     float* const s_vt = s_k + (size_t)Lp * A_KS;                         // [64][vs]
@@ -173,8 +179,19 @@ __global__ __launch_bounds__(512, 2) void k_packed_mha(const MhaArgs p) {
 
 using namespace ldn;
 
+static int packed_mha_impl(const float* qkv, int ld_qkv, const int32_t* tok_rows, const int32_t* img_prefix, int B, int heads,
+                           int head_dim, int max_tokens, float scale, const float* head_keep, float* out, int ldo, void* stream);
 extern "C" int ldn_packed_mha(const float* qkv, int ld_qkv, const int32_t* tok_rows, const int32_t* img_prefix, int B, int heads,
                               int head_dim, int max_tokens, float scale, float* out, int ldo, void* stream) {
+    return packed_mha_impl(qkv, ld_qkv, tok_rows, img_prefix, B, heads, head_dim, max_tokens, scale, nullptr, out, ldo, stream);
+}
+extern "C" int ldn_packed_mha_heads(const float* qkv, int ld_qkv, const int32_t* tok_rows, const int32_t* img_prefix, int B, int heads,
+                                    int head_dim, int max_tokens, float scale, const float* head_keep, float* out, int ldo, void* stream) {
+    LDN_REQUIRE(head_keep, "ldn_packed_mha_heads: null head_keep");
+    return packed_mha_impl(qkv, ld_qkv, tok_rows, img_prefix, B, heads, head_dim, max_tokens, scale, head_keep, out, ldo, stream);
+}
+static int packed_mha_impl(const float* qkv, int ld_qkv, const int32_t* tok_rows, const int32_t* img_prefix, int B, int heads,
+                           int head_dim, int max_tokens, float scale, const float* head_keep, float* out, int ldo, void* stream) {
     LDN_REQUIRE(qkv && tok_rows && img_prefix && out, "ldn_packed_mha: null pointer");
     LDN_REQUIRE(head_dim == A_D, "ldn_packed_mha: head_dim must be 64 (got %d)", head_dim);
     LDN_REQUIRE(B > 0 && heads > 0 && max_tokens > 0 && max_tokens <= A_MAXTOK, "ldn_packed_mha: at most %d kept tokens per image (got %d)", A_MAXTOK, max_tokens);
@@ -183,7 +200,7 @@ extern "C" int ldn_packed_mha(const float* qkv, int ld_qkv, const int32_t* tok_r
     LDN_REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0, "ldn_packed_mha: qkv / out must be 16-byte aligned");
     MhaArgs a{};
     a.qkv = qkv; a.ld = ld_qkv; a.tok_rows = tok_rows; a.prefix = img_prefix; a.B = B; a.heads = heads; a.dim = dim;
-    a.scale = scale; a.out = out; a.ldo = ldo;
+    a.scale = scale; a.out = out; a.ldo = ldo; a.head_keep = head_keep;
     const int Lp = round_up(max_tokens, 32);
     a.vs = Lp + 4;                                                        // = 4 mod 32: the 32 d-rows of a fragment read hit distinct banks
     const size_t lds = ((size_t)Lp * A_KS + (size_t)A_D * a.vs) * 4;

@@ -779,9 +779,9 @@ def token_lists(keep):
     return ix.idx3, ix.pre3, ix.cnt[0:1]
 
 
-def packed_mha(qkv2d, tok_rows, prefix, B, heads, max_tokens, scale=None):
+def packed_mha(qkv2d, tok_rows, prefix, B, heads, max_tokens, scale=None, head_keep=None):
     """Multi-head attention among the kept tokens of every image (see ldn_packed_mha).  qkv2d [B*L, 3*dim]; returns the packed
-    rows [B*L (capacity), dim]: row n belongs to token tok_rows[n]."""
+    rows [B*L (capacity), dim]: row n belongs to token tok_rows[n].  head_keep [B, heads] {0,1}: head skipping (ldn_packed_mha_heads)."""
     L.require_device(qkv2d, tok_rows, prefix)
     lib = L.load()
     rows, three_dim = qkv2d.shape
@@ -790,6 +790,13 @@ def packed_mha(qkv2d, tok_rows, prefix, B, heads, max_tokens, scale=None):
     if three_dim != 3 * dim or dim != heads * d or qkv2d.dtype != torch.float32 or qkv2d.stride(1) != 1:
         raise L.LdnError("packed_mha: qkv must be fp32 [rows, 3 * heads * head_dim]")
     out = torch.empty(rows, dim, device=qkv2d.device, dtype=torch.float32)
+    if head_keep is not None:
+        if tuple(head_keep.shape) != (B, heads):
+            raise L.LdnError("packed_mha: head_keep must be [B, heads]")
+        L.check(lib.ldn_packed_mha_heads(L.ptr(qkv2d), qkv2d.stride(0), L.ptr(_i32c(tok_rows, "tok_rows")), L.ptr(_i32c(prefix, "prefix")), B,
+                                         heads, d, max_tokens, float(scale if scale is not None else d ** -0.5),
+                                         L.ptr(_f32c(head_keep, "head_keep")), L.ptr(out), dim, L.stream_ptr(out)), "ldn_packed_mha_heads")
+        return out
     L.check(lib.ldn_packed_mha(L.ptr(qkv2d), qkv2d.stride(0), L.ptr(_i32c(tok_rows, "tok_rows")), L.ptr(_i32c(prefix, "prefix")), B, heads,
                                d, max_tokens, float(scale if scale is not None else d ** -0.5), L.ptr(out), dim, L.stream_ptr(out)),
             "ldn_packed_mha")

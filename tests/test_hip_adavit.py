@@ -155,3 +155,47 @@ def test_layernorm_and_gelu_as_epilogue_terms(rows, cin, cout, gather):
         assert err < 2e-4, err
     finally:
         ops.set_math_mode(None)
+
+
+@pytest.mark.parametrize("B,L,dim,heads", [(5, 40, 128, 2), (4, 197, 384, 6)])
+def test_head_and_layer_skipping_vs_oracle(B, L, dim, heads):
+    """Head skipping (per-image head masks) and layer skipping (per-image decisions for the attention and the MLP sub-block) of
+    simulate_adavit.py:81-88,140-182 on top of token skipping, against the dense masked restatement (self-consistency: parity unpinned);
+    images with no head / all heads, with one or both sub-blocks skipped (both: the image passes through bit-exactly)."""
+    from laudnet_amd import ops
+    from laudnet_amd.adavit import TokenSkipBlock, TokenSkipViT
+    depth = 3
+    ref = AR.TokenSkipViTRef(depth, dim, heads).eval()
+    torch.manual_seed(13)
+    for p_ in ref.parameters():
+        if p_.dim() > 1:
+            torch.nn.init.normal_(p_, std=0.05)
+    hip = TokenSkipViT(depth, dim, heads).eval()
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(DEV)
+    x = seeded_randn((B, L, dim), 51)
+    keeps = [_keep(B, L, 0.5, 60 + i) for i in range(depth)]
+    hks, aks, mks = [], [], []
+    for i in range(depth):
+        hk = seeded_bernoulli((B, heads), 0.6, 70 + i)
+        hk[0] = 0.0                                  # an image that drops every head
+        hk[1] = 1.0                                  # ... keeps every head
+        ak, mk = seeded_bernoulli((B,), 0.7, 80 + i), seeded_bernoulli((B,), 0.7, 90 + i)
+        ak[2], mk[2] = 0.0, 0.0                      # image 2 skips both sub-blocks of every block
+        ak[3], mk[3] = 1.0, 0.0
+        hks.append(hk); aks.append(ak); mks.append(mk)
+    with torch.no_grad():
+        want = ref(x, keeps, hks, aks, mks)
+    ops.set_math_mode("bf16x3")
+    try:
+        with torch.no_grad():
+            got = hip(x.to(DEV), [k.to(DEV) for k in keeps], [h.to(DEV) for h in hks], [a.to(DEV) for a in aks], [m.to(DEV) for m in mks]).cpu()
+            # one block, module-level call
+            one = hip.blocks[0](x.to(DEV), keeps[0].to(DEV), head_keep=hks[0].to(DEV), attn_keep=aks[0].to(DEV), mlp_keep=mks[0].to(DEV)).cpu()
+            want1 = ref.blocks[0](x, keeps[0], hks[0], aks[0], mks[0])
+    finally:
+        ops.set_math_mode("fp32")
+    assert torch.equal(got[2], x[2])                                  # both sub-blocks skipped in every block: untouched
+    scale = max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() < 2e-4 * scale, (got - want).abs().max().item()
+    assert (one - want1).abs().max().item() < 1e-4 * max(1.0, want1.abs().max().item())

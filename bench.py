@@ -911,14 +911,15 @@ def main():
                 result["dense_emulation_gpu"] = {"error": repr(e)[:200]}
         if not args.no_cpu:
             host_cores = os.cpu_count() or 1
-            # thread count: measured, not assumed -- one forward of a small batch at 16 / 32 / 64 / 128 threads (torch CPU convs stop
-            # scaling far below 256 threads on this host), the fastest count runs the timed sample
+            # thread count: measured, not assumed -- one forward of a small batch at 8 / 16 / 32 / 64 / 128 threads (torch CPU convs stop
+            # scaling far below 256 threads on this host: 16 threads beat 32 by 1.8x on the EPYC 9575F box), the fastest count runs the
+            # timed sample
             for rb in ((b.f if hasattr(b, "f") else b) for _, b in ref.blocks()):
                 rb.forced_channel_mask = rb.forced_spatial_mask = None
             ref = ref.cpu()
             xs_ = x[: min(args.cpu_batch, 8)].cpu().contiguous()
             sweep = {}
-            for n_thr in sorted({min(host_cores, c) for c in (16, 32, 64, 128)}):
+            for n_thr in sorted({min(host_cores, c) for c in (8, 16, 32, 64, 128)}):
                 torch.set_num_threads(n_thr)
                 with torch.no_grad():
                     ref(xs_[:2], 1.0)

@@ -55,6 +55,7 @@ __device__ __attribute__((aligned(16))) float g_tail_zero[4] = {0.f, 0.f, 0.f, 0
 #ifdef LDN_TRACE   // tuning only: per-workgroup phase timestamps of every wave (tools/trace_tail.py)
 __device__ unsigned long long* g_tail_trace = nullptr;
 __device__ unsigned long long* g_chain_trace = nullptr;   // k_chain: [B][4] = masker, conv1, conv2+conv3, fences (cycles summed over the run)
+__device__ unsigned long long* g_head_trace = nullptr;    // k_head: [workgroup][8 waves][8] = vmcnt wait, barrier, DMA issue, x split, MFMA, total, chunks
 #define TT(x) x = __builtin_amdgcn_s_memtime();
 #define TT_ADD(acc, a, b) acc += (b) - (a);
 #else
@@ -705,6 +706,10 @@ extern "C" int ldn_debug_set_chain_trace(void* buf) {
     unsigned long long* q = static_cast<unsigned long long*>(buf);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
 }
+extern "C" int ldn_debug_set_head_trace(void* buf) {
+    unsigned long long* q = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_head_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
+}
 extern "C" int ldn_debug_set_tail_trace(void* buf) {
     unsigned long long* q = static_cast<unsigned long long*>(buf);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tail_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
@@ -944,10 +949,21 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
     // list row n = 32 j + l31 is row n % 8 of piece n / 64 of wave (n % 64) / 8: LDS row ((4 (j & 1) + (l31 >> 3)) * nw + (j >> 1)) * 8 + (l31 & 7)
     const unsigned wrow_e = (unsigned)((((l31 >> 3)) * nw * 8 + (l31 & 7)) * 128);            // even j
     const unsigned wrow_o = (unsigned)((((4 + (l31 >> 3))) * nw * 8 + (l31 & 7)) * 128);      // odd j
+#ifdef LDN_TRACE
+    unsigned long long h0, h1, h2, h3, h4, h5, hw = 0, hb = 0, hi_ = 0, hs = 0, hm = 0, hstart;
+    TT(hstart)
+#endif
     for (int c = 0; c < nchunks; ++c) {
+        TT(h0)
         wait_vm_rt(per_chunk * (D - 2));     // chunk c has landed; the D - 2 chunks issued after it may still fly
+        TT(h1)
         lds_barrier();                       // ... for every wave; every wave has left chunk c - 1
+        TT(h2)
+        // (Round 4, tried: the SIMDs' second waves issuing this AFTER their MFMA steps, so that one wave's DMA issue overlaps the other's
+        // matrix time -- the K loop stayed at 4.4 k cycles per chunk and the step got 0.15 ms slower; profiles/r04_trace_head.txt)
         if (c + D - 1 < nchunks) dma_chunk(c + D - 1); else dma_dummy(c + D - 1);
+        TT(h3)
+        TT_ADD(hw, h0, h1) TT_ADD(hb, h1, h2) TT_ADD(hi_, h2, h3)
         if (!active) continue;
         const unsigned char* xs = s_ring + (c % D) * slot_bytes;
         const unsigned char* ws = xs + xrows * 128;
@@ -966,6 +982,11 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
                 bl[half][e] = (__bf16)(v - (float)hb);
             }
         }
+#ifdef LDN_TRACE
+        asm volatile("" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
+        TT(h4)
+        TT_ADD(hs, h3, h4)
+#endif
         if (p.xs && (int)xrow < npix) {
             // the split x fragments ARE whole octets of the pre-split format: lane (pixel, h), K16 half `half` of chunk c = octet 4 c + 2 half + h.
             // (Stores share vmcnt with the LDS-DMA: the counted waits above then ask for MORE completions than they need -- safe.)
@@ -1039,7 +1060,20 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
             }
         }
 #undef LDN_HEAD_STEP
+#ifdef LDN_TRACE
+        asm volatile("" : "+v"(acc[0]));
+        TT(h5)
+        TT_ADD(hm, h4, h5)
+#endif
     }
+#ifdef LDN_TRACE
+    if (g_head_trace && lane == 0) {
+        unsigned long long hend;
+        TT(hend)
+        unsigned long long* r = g_head_trace + (((size_t)mb * p.B + b) * 8 + wave) * 8;
+        r[0] = hw; r[1] = hb; r[2] = hi_; r[3] = hs; r[4] = hm; r[5] = hend - hstart; r[6] = nchunks; r[7] = nsub;
+    }
+#endif
     wait_vm_n<0>();      // no LDS-DMA may be in flight when the workgroup's LDS is released
 
     // ---- epilogue: bn1 + ReLU - c1, split, pair the half-waves, 16-byte stores of [8 hi] (lanes 0-31) / [8 lo] (lanes 32-63)

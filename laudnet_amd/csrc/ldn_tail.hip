@@ -165,9 +165,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     float* const s_tab = reinterpret_cast<float*>(s_w3 + 2 * W3_SLOT);    // sc2[NP], ps2[NP], sh2[16][NP] (conversion)
     unsigned char* const s_scr = reinterpret_cast<unsigned char*>(s_tab + 18 * NP);   // 8 x 4 KiB transpose scratch
 
-    const int lane = tid & 63;
+    int lane = tid & 63;                    // (not const: made opaque again in front of the conv3 phase, see there)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
+    int l31 = lane & 31, h = lane >> 5;
 #ifdef LDN_TRACE
     unsigned long long tr0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0, ta = 0, tb = 0, w2wait = 0, w3wait = 0, w3bar = 0, w3epi = 0, w3k = 0;
     TT(tr0)
@@ -398,6 +398,12 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     wait_vm<0>();
     lds_barrier();         // every wave is out of the conv2 loop: the slice / W2 regions are free
     TT(tr2)
+    // The lane index behind an optimisation barrier: left alone, hipcc computes the conv3 phase's per-lane addresses (store rows, scratch
+    // slots, fragment offsets) at the top of the kernel and keeps them alive -- or spills them -- through the whole conv2 phase
+    // (k_tail<2>: 22 spilled registers at its 128-register budget = ~150 MB of scratch writes per stage-1 launch, r04_pmc_stage12.txt)
+    asm volatile("" : "+v"(lane));
+    l31 = lane & 31;
+    h = lane >> 5;
 
     // ======================================================================================================== conv3 (1x1)
     // Output channels are walked in chunks of CW (64; 32 for the widest layer, whose h2 operand alone takes 128 registers and
@@ -497,7 +503,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
             bf16x8 pjh[PROJ ? T_PROJ_CIN / 16 : 1], pjl[PROJ ? T_PROJ_CIN / 16 : 1];
             if constexpr (PROJ) {
                 // the lane's pixel of the block input, pre-split: K16 step s = octet 2 s + h (8 hi | 8 lo); L2 hits after the first sub-pass
-                const long q = out_row0 + min(pm, npix - 1);
+                const long q = out_row0 + min(wave * 32 + l31, npix - 1);
                 const unsigned char* xr = p.pxs + (q >> 5) * ((long)T_PROJ_CIN * 128) + (q & 31) * 16 + h * 1024;
 #pragma unroll
                 for (int s2 = 0; s2 < T_PROJ_CIN / 16; ++s2) {

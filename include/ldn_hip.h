@@ -229,6 +229,19 @@ int ldn_conv_image(const float* a, int lda, int B, int Hi, int Wi, int ksize, in
 int ldn_bottleneck_head(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
                         const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
                         const float* post_sub1, void* h1_split, int ldh, void* stream);
+/* The same three kernels in TRUE fp32 arithmetic (v_mfma_f32_32x32x2_f32: fp32 multiply and accumulate, the library's `fp32` math mode).
+ * An element takes 4 bytes as a bf16 hi + lo pair and as a float, so every pre-split layout above read as plain floats IS its fp32 twin:
+ *   w1 [width][cin] fp32 row-major;  h1 [B*HW][ldh] plain fp32 rows (left-packed columns, zero-filled to a multiple of 32);
+ *   w2_pairs_f32 [9][width/2][width/2][2 n][w(n, 2kp), w(n, 2kp + 1)] fp32;  w3_pairs_f32 [width/2][cout][w3(c, 2kp), w3(c, 2kp + 1)] fp32.
+ * Same staging pipelines, eight 32x32x2 products per K16 step instead of three 32x32x16 ones; every other argument as in the bf16x3 forms
+ * (ldn_bottleneck_chain_f32: the blocks' w1s / w2p / w3p fields point at the fp32 twins). */
+int ldn_bottleneck_head_f32(const float* x, int ldx, int B, int HW, int cin, const float* w1, int width,
+                            const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
+                            const float* post_sub1, float* h1, int ldh, void* stream);
+int ldn_bottleneck_tail_f32(const void* h1, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs_f32,
+                            const void* w3_pairs_f32, int cout, const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale2,
+                            const float* shift2_tab, const float* post_sub2, const float* shift3, const float* residual,
+                            int ldr, float* out, int ldo, float* colsum, void* stream);
 int ldn_bottleneck_tail_splits(int H, int Wd, int width, int stride);   /* H x Wd = conv2's INPUT map; 0 = this map / width does not fit the fused tail */
 int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs,
                         const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale2,
@@ -292,6 +305,10 @@ int ldn_bottleneck_chain_fits(int H, int Wd, int C, int width, int hidden, int G
 int ldn_bottleneck_chain(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
                          const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran, const float* gap_in,
                          int gap_splits, float* colsum, float* masks, int32_t* ch_idx, int32_t* ch_cnt, void* h1_split,
+                         int ldh, void* stream);
+int ldn_bottleneck_chain_f32(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
+                         const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran, const float* gap_in,
+                         int gap_splits, float* colsum, float* masks, int32_t* ch_idx, int32_t* ch_cnt, float* h1,
                          int ldh, void* stream);
 
 /* ---- a8: the static stem of ResNet.forward in eval mode (laud_resnet.py:316-326: conv1 7x7 stride 2 pad 3 -> bn1 -> ReLU ->

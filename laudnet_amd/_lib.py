@@ -49,8 +49,10 @@ SIGNATURES = {
     "ldn_conv_image": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I,
                         _P, _I, _P, _I, _P, _I, _I, _P], _I),
     "ldn_bottleneck_head": ([_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P], _I),
+    "ldn_bottleneck_head_f32": ([_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P], _I),
     "ldn_bottleneck_tail_splits": ([_I, _I, _I, _I], _I),
     "ldn_bottleneck_tail": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
+    "ldn_bottleneck_tail_f32": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
     "ldn_x_split_bytes": ([C.c_size_t, _I], C.c_size_t),
     "ldn_bottleneck_head_split": ([_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P], _I),
     "ldn_bottleneck_tail_proj_fits": ([_I, _I, _I, _I], _I),
@@ -67,6 +69,7 @@ SIGNATURES = {
     "ldn_bottleneck_smallmap_fits": ([_I, _I, _I, _I, _I], _I),
     "ldn_bottleneck_smallmap": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P], _I),
     "ldn_bottleneck_chain": ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P], _I),
+    "ldn_bottleneck_chain_f32": ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P], _I),
 }
 
 _lib = None

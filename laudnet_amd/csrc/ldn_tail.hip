@@ -91,6 +91,23 @@ __device__ __forceinline__ void split2(float v, __bf16& hi, __bf16& lo) {
     lo = (__bf16)(v - (float)hi);
 }
 
+// One K16 step of a 32 x 32 tile.  bf16x3: three v_mfma_f32_32x32x16_bf16 of the hi / lo halves (AH_ / AL_ = 8 hi | 8 lo of the A rows,
+// BH_ / BL_ likewise).  F32 (true-fp32 arithmetic, the library's `fp32` math mode): an element takes the same 4 bytes as a bf16 hi + lo
+// pair, so every pre-split layout of this file read as plain floats IS the fp32 layout -- AH_ / AL_ then hold the lane's k-slots 0-3 /
+// 4-7 as raw floats (BH_ / BL_ likewise) and the step is eight v_mfma_f32_32x32x2_f32 (instruction i pairs k-slot i of lane half 0 with
+// k-slot i of lane half 1 on both operands).
+#define LDN_K16(F32_, ACC_, AH_, AL_, BH_, BL_) \
+    if constexpr (F32_) { \
+        const f32x4 ka0_ = __builtin_bit_cast(f32x4, AH_), ka1_ = __builtin_bit_cast(f32x4, AL_); \
+        const f32x4 kb0_ = __builtin_bit_cast(f32x4, BH_), kb1_ = __builtin_bit_cast(f32x4, BL_); \
+        _Pragma("unroll") for (int ki_ = 0; ki_ < 4; ++ki_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ka0_[ki_], kb0_[ki_], ACC_, 0, 0, 0); \
+        _Pragma("unroll") for (int ki_ = 0; ki_ < 4; ++ki_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ka1_[ki_], kb1_[ki_], ACC_, 0, 0, 0); \
+    } else { \
+        ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL_, BH_, ACC_, 0, 0, 0); \
+        ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH_, BL_, ACC_, 0, 0, 0); \
+        ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH_, BH_, ACC_, 0, 0, 0); \
+    }
+
 constexpr int T_KIDX_BYTES = 1280;        // int[W + 32] channel list (W <= 256)
 constexpr int T_W2_SLOTS = 3;
 
@@ -115,21 +132,19 @@ constexpr int T_W2_SLOTS = 3;
                     for (int q = 0; q < 4; ++q) e0[q] = *reinterpret_cast<const u32x2*>(ws + a_lane + q * W2_ROW + j * 256); \
     _Pragma("unroll") \
                     for (int q = 0; q < 4; ++q) e1[q] = *reinterpret_cast<const u32x2*>(ws + a_lane + (8 + q) * W2_ROW + j * 256); \
+                    /* bf16x3: an entry = {hi k0, hi k1 | lo k0, lo k1}: dword 0 of the four entries = the 8 hi halves, dword 1 = the 8 lo halves. */ \
+                    /* F32: an entry = {w[k0], w[k1]} as floats: entries 0, 1 = k-slots 0-3, entries 2, 3 = k-slots 4-7.                         */ \
                     { \
-                        const u32x4 ahu = {e0[0][0], e0[1][0], e0[2][0], e0[3][0]}; \
-                        const u32x4 alu = {e0[0][1], e0[1][1], e0[2][1], e0[3][1]}; \
+                        const u32x4 ahu = F32 ? u32x4{e0[0][0], e0[0][1], e0[1][0], e0[1][1]} : u32x4{e0[0][0], e0[1][0], e0[2][0], e0[3][0]}; \
+                        const u32x4 alu = F32 ? u32x4{e0[2][0], e0[2][1], e0[3][0], e0[3][1]} : u32x4{e0[0][1], e0[1][1], e0[2][1], e0[3][1]}; \
                         const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu); \
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[j], 0, 0, 0); \
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[j], 0, 0, 0); \
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[j], 0, 0, 0); \
+                        LDN_K16(F32, acc[j], ah, al, bh[0], bl[0]) \
                     } \
                     { \
-                        const u32x4 ahu = {e1[0][0], e1[1][0], e1[2][0], e1[3][0]}; \
-                        const u32x4 alu = {e1[0][1], e1[1][1], e1[2][1], e1[3][1]}; \
+                        const u32x4 ahu = F32 ? u32x4{e1[0][0], e1[0][1], e1[1][0], e1[1][1]} : u32x4{e1[0][0], e1[1][0], e1[2][0], e1[3][0]}; \
+                        const u32x4 alu = F32 ? u32x4{e1[2][0], e1[2][1], e1[3][0], e1[3][1]} : u32x4{e1[0][1], e1[1][1], e1[2][1], e1[3][1]}; \
                         const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu); \
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[j], 0, 0, 0); \
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[j], 0, 0, 0); \
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[j], 0, 0, 0); \
+                        LDN_K16(F32, acc[j], ah, al, bh[1], bl[1]) \
                     } \
                     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); \
                     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); \
@@ -139,9 +154,10 @@ constexpr int T_W2_SLOTS = 3;
 
 // NS = W / 32 (maximum n-subtiles / K slices of an image): 2, 4 or 8;  ST = stride of the 3x3 (1 or 2: the first block of a stage,
 // laud_resnet.py:123 with stride 2 -- the block's halo'd input region then holds 2 R + 1 input rows for R output rows)
-template <int NS, int ST = 1, bool PROJ = false>
+template <int NS, int ST = 1, bool PROJ = false, bool F32 = false>
 __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const int mb, unsigned char* const smem, const int tid) {
     static_assert(!PROJ || (NS == 2 && ST == 1), "the folded projection exists for the 64-wide stride-1 block (stage 1's first block)");
+    static_assert(!(PROJ && F32), "the folded projection is a bf16x3 form");
     constexpr int W = NS * 32;
     // NS == 2 (stage 1: 14 short blocks per image, all of them bound by the CU's memory pipe in their conv3 phase and idle on it in
     // their conv2 phase): ONE h1 slice slot and 128 registers, so that TWO workgroups fit a CU and overlap each other's phases.
@@ -463,6 +479,11 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
             for (int e = 0; e < 4; ++e)
                 v[4 * q4 + e] = fmaxf(acc[j][4 * q4 + e] * sc[e] + sh[e], 0.f) - ps[e];   // columns without a channel: 0 * 0 + 0
         }
+        if constexpr (F32) {
+            // true fp32: h2 stays fp32 in the accumulator registers -- k-slot e of conv3's K16 step t is register 8 t + e, as in the split form
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = v[r];
+        } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -473,6 +494,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
                 acc[j][8 * t + d] = __builtin_bit_cast(float, hi);
                 acc[j][8 * t + 4 + d] = __builtin_bit_cast(float, lo);
             }
+        }
         // compiler memory barrier + scheduling barrier: left alone, hipcc hoists the table reads of ALL subtiles to the top
         // (96 ds_read_b128 = 384 registers) and spills them
         asm volatile("" : "+v"(acc[j]) :: "memory");
@@ -535,13 +557,11 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
                             e[t][q] = *reinterpret_cast<const u32x2*>(ws + a3_lane + (16 * j + 8 * t + (q & 1) + 4 * (q >> 1)) * W3_ROW + cs * 256);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const u32x4 ahu = {e[t][0][0], e[t][1][0], e[t][2][0], e[t][3][0]};
-                        const u32x4 alu = {e[t][0][1], e[t][1][1], e[t][2][1], e[t][3][1]};
+                        const u32x4 ahu = F32 ? u32x4{e[t][0][0], e[t][0][1], e[t][1][0], e[t][1][1]} : u32x4{e[t][0][0], e[t][1][0], e[t][2][0], e[t][3][0]};
+                        const u32x4 alu = F32 ? u32x4{e[t][2][0], e[t][2][1], e[t][3][0], e[t][3][1]} : u32x4{e[t][0][1], e[t][1][1], e[t][2][1], e[t][3][1]};
                         const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
-                        const bf16x8 hb = frag_hi(j, t), lb = frag_lo(j, t);
-                        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, hb, acc3, 0, 0, 0);
-                        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, lb, acc3, 0, 0, 0);
-                        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, hb, acc3, 0, 0, 0);
+                        const bf16x8 hb = frag_hi(j, t), lb = frag_lo(j, t);      // F32: registers 8 t .. + 3 / 8 t + 4 .. + 7 = k-slots 0-3 / 4-7 as floats
+                        LDN_K16(F32, acc3, ah, al, hb, lb)
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
@@ -637,10 +657,10 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
 #endif
 }
 
-template <int NS, int ST, bool PROJ = false>
+template <int NS, int ST, bool PROJ = false, bool F32 = false>
 __global__ __launch_bounds__(512, ((NS == 2 && ST == 1) ? 4 : 2)) void k_tail(const TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    tail_body<NS, ST, PROJ>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, threadIdx.x);     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
+    tail_body<NS, ST, PROJ, F32>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, threadIdx.x);     // image-fastest: with B % 8 == 0 image b stays on XCD b % 8
 }
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_tail)
@@ -686,7 +706,7 @@ static int tail_rows_per_block(int Hi, int Wi, int NS, int st, int* mblocks) {
     return best;
 }
 
-template <int NS, int ST, bool PROJ = false>
+template <int NS, int ST, bool PROJ = false, bool F32 = false>
 static int launch_tail(TailArgs& a, hipStream_t st) {
     constexpr int W = NS * 32;
     const int R = a.rows_per_blk;
@@ -697,8 +717,8 @@ static int launch_tail(TailArgs& a, hipStream_t st) {
     const size_t lds = lds2 > lds3 ? lds2 : lds3;
     LDN_REQUIRE(lds <= 160 * 1024, "ldn_bottleneck_tail: %zu B of LDS exceed 160 KiB (map %dx%d, width %d)", lds, a.Ho, a.Wo, W);
     LDN_REQUIRE(ST == 2 || NS == 2 || round_up(nr, 8) / 8 <= 72, "ldn_bottleneck_tail: input region of %d pixels too large for the slice pipeline", nr);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_tail<NS, ST, PROJ>), lds), "k_tail: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL((k_tail<NS, ST, PROJ>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_tail<NS, ST, PROJ, F32>), lds), "k_tail: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((k_tail<NS, ST, PROJ, F32>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_tail");
     return LDN_OK;
 }
@@ -733,7 +753,7 @@ static int bottleneck_tail_impl(const void* h1_split, int ldh, int B, int H, int
                                 const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
                                 const float* scale2, const float* shift2_tab, const float* post_sub2,
                                 const float* shift3, const float* residual, int ldr, float* out, int ldo,
-                                float* colsum, const void* x_split, const void* wd_pairs, void* stream);
+                                float* colsum, const void* x_split, const void* wd_pairs, bool f32, void* stream);
 
 extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs,
                                    const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
@@ -741,7 +761,17 @@ extern "C" int ldn_bottleneck_tail(const void* h1_split, int ldh, int B, int H, 
                                    const float* shift3, const float* residual, int ldr, float* out, int ldo,
                                    float* colsum, void* stream) {
     return bottleneck_tail_impl(h1_split, ldh, B, H, Wd, stride, width, w2_pairs, w3_pairs, cout, ch_idx, ch_cnt, scale2, shift2_tab,
-                                post_sub2, shift3, residual, ldr, out, ldo, colsum, nullptr, nullptr, stream);
+                                post_sub2, shift3, residual, ldr, out, ldo, colsum, nullptr, nullptr, false, stream);
+}
+
+/* true-fp32 arithmetic (v_mfma_f32_32x32x2_f32): the same kernel, operands in the fp32 twins of the pre-split layouts (include/ldn_hip.h) */
+extern "C" int ldn_bottleneck_tail_f32(const void* h1, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs_f32,
+                                       const void* w3_pairs_f32, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
+                                       const float* scale2, const float* shift2_tab, const float* post_sub2,
+                                       const float* shift3, const float* residual, int ldr, float* out, int ldo,
+                                       float* colsum, void* stream) {
+    return bottleneck_tail_impl(h1, ldh, B, H, Wd, stride, width, w2_pairs_f32, w3_pairs_f32, cout, ch_idx, ch_cnt, scale2, shift2_tab,
+                                post_sub2, shift3, residual, ldr, out, ldo, colsum, nullptr, nullptr, true, stream);
 }
 
 extern "C" int ldn_bottleneck_tail_proj_fits(int H, int Wd, int width, int cin) {
@@ -759,14 +789,14 @@ extern "C" int ldn_bottleneck_tail_proj(const void* h1_split, int ldh, int B, in
     LDN_REQUIRE(width == 64 && cin == ldn::T_PROJ_CIN, "ldn_bottleneck_tail_proj: the folded projection exists for width 64, cin 64 (got %d, %d; ldn_bottleneck_tail_proj_fits == 0)", width, cin);
     LDN_REQUIRE((uintptr_t)x_split % 16 == 0 && (uintptr_t)wd_pairs % 16 == 0, "ldn_bottleneck_tail_proj: x_split / wd_pairs must be 16-byte aligned");
     return bottleneck_tail_impl(h1_split, ldh, B, H, Wd, 1, width, w2_pairs, w3_pairs, cout, ch_idx, ch_cnt, scale2, shift2_tab,
-                                post_sub2, shift3d, nullptr, 0, out, ldo, colsum, x_split, wd_pairs, stream);
+                                post_sub2, shift3d, nullptr, 0, out, ldo, colsum, x_split, wd_pairs, false, stream);
 }
 
 static int bottleneck_tail_impl(const void* h1_split, int ldh, int B, int H, int Wd, int stride, int width, const void* w2_pairs,
                                 const void* w3_pairs, int cout, const int32_t* ch_idx, const int32_t* ch_cnt,
                                 const float* scale2, const float* shift2_tab, const float* post_sub2,
                                 const float* shift3, const float* residual, int ldr, float* out, int ldo,
-                                float* colsum, const void* x_split, const void* wd_pairs, void* stream) {
+                                float* colsum, const void* x_split, const void* wd_pairs, bool f32, void* stream) {
     LDN_REQUIRE(h1_split && w2_pairs && w3_pairs && ch_idx && ch_cnt && scale2 && shift2_tab && post_sub2 && shift3 && out,
                 "ldn_bottleneck_tail: null pointer");
     LDN_REQUIRE(width == 64 || width == 128 || width == 256, "ldn_bottleneck_tail: width must be 64, 128 or 256 (got %d)", width);
@@ -792,6 +822,17 @@ static int bottleneck_tail_impl(const void* h1_split, int ldh, int B, int H, int
     a.rows_per_blk = tail_rows_per_block(H, Wd, width / 32, stride, &a.mblocks);
     LDN_REQUIRE(a.rows_per_blk > 0, "ldn_bottleneck_tail: a %dx%d map of width %d (stride %d) does not fit the workgroup (ldn_bottleneck_tail_splits == 0)", H, Wd, width, stride);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (f32) {
+        LDN_REQUIRE(!x_split, "ldn_bottleneck_tail: the folded projection is a bf16x3 form");
+        if (stride == 2) {
+            if (width == 64) return launch_tail<2, 2, false, true>(a, st);
+            if (width == 128) return launch_tail<4, 2, false, true>(a, st);
+            return launch_tail<8, 2, false, true>(a, st);
+        }
+        if (width == 64) return launch_tail<2, 1, false, true>(a, st);
+        if (width == 128) return launch_tail<4, 1, false, true>(a, st);
+        return launch_tail<8, 1, false, true>(a, st);
+    }
     if (stride == 2) {
         if (width == 64) return launch_tail<2, 2>(a, st);
         if (width == 128) return launch_tail<4, 2>(a, st);
@@ -872,7 +913,7 @@ __device__ __forceinline__ const void* uniform_cptr(const void* v) {
 
 constexpr int H_XROWS = 256;                          // rows of the x tile of a ring slot (pixels of the block, padded)
 
-template <int NS>
+template <int NS, bool F32 = false>
 __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const int mb, unsigned char* const smem, const int lds_total, const int tid) {
     constexpr int W = NS * 32;
     int* const s_nidx = reinterpret_cast<int*>(smem);                    // [W + 32]
@@ -980,6 +1021,10 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
             const unsigned sl = 4u * half + 2u * h;          // logical 16-byte slot of this lane's 8 k values (x: fp32 k .. k+3, k+4 .. k+7)
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
+            if constexpr (F32) {     // raw floats: k-slots 0-3 / 4-7
+                bh[half] = __builtin_bit_cast(bf16x8, x0);
+                bl[half] = __builtin_bit_cast(bf16x8, x1);
+            } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = e < 4 ? x0[e] : x1[e - 4];
@@ -987,13 +1032,14 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
                 bh[half][e] = hb;
                 bl[half][e] = (__bf16)(v - (float)hb);
             }
+            }
         }
 #ifdef LDN_TRACE
         asm volatile("" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
         TT(h4)
         TT_ADD(hs, h3, h4)
 #endif
-        if (p.xs && (int)xrow < npix) {
+        if (!F32 && p.xs && (int)xrow < npix) {
             // the split x fragments ARE whole octets of the pre-split format: lane (pixel, h), K16 half `half` of chunk c = octet 4 c + 2 half + h.
             // (Stores share vmcnt with the LDS-DMA: the counted waits above then ask for MORE completions than they need -- safe.)
             // TILED layout (tiles of 32 consecutive pixels of the flat batch): [tile][K16 step s][h][hi | lo][pixel % 32][16 B] -- the
@@ -1027,15 +1073,11 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
 #define LDN_HEAD_STEP(J)                                                                                  \
         frag1(J);                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, bh[0], acc[J], 0, 0, 0);                    \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bl[0], acc[J], 0, 0, 0);                    \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bh[0], acc[J], 0, 0, 0);                    \
+        LDN_K16(F32, acc[J], a0h, a0l, bh[0], bl[0])                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         if (J > 0) frag0(J > 0 ? J - 1 : 0);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, bh[1], acc[J], 0, 0, 0);                    \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bl[1], acc[J], 0, 0, 0);                    \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bh[1], acc[J], 0, 0, 0);                    \
+        LDN_K16(F32, acc[J], a1h, a1l, bh[1], bl[1])                                                      \
         __builtin_amdgcn_sched_barrier(0);
         if (nsub > 0) {
             frag0(nsub - 1);
@@ -1095,6 +1137,13 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
             const f32x4 sc = *reinterpret_cast<const f32x4*>(s_tab + n0);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(s_tab + W + n0);
             const f32x4 ps = *reinterpret_cast<const f32x4*>(s_tab + 2 * W + n0);
+            if constexpr (F32) {   // true fp32: the lane's four channels 32 j + 8 q4 + 4 h .. + 3 as plain floats (the same 16 bytes of the row)
+                f32x4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = fmaxf(acc[j][4 * q4 + e] * sc[e] + sh[e], 0.f) - ps[e];
+                if (pm < npix) *reinterpret_cast<f32x4*>(orow + (4 * j + q4) * 32 + h * 16) = v4;
+                continue;
+            }
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             unsigned hi2[2], lo2[2];
 #pragma unroll
@@ -1121,17 +1170,17 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
     }
 }
 
-template <int NS>
+template <int NS, bool F32 = false>
 __global__ __launch_bounds__(512, 2) void k_head(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    head_body<NS>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, 160 * 1024, threadIdx.x);
+    head_body<NS, F32>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, 160 * 1024, threadIdx.x);
 }
 
-template <int NS>
+template <int NS, bool F32 = false>
 static int launch_head(HeadArgs& a, hipStream_t st) {
     const size_t lds = 160 * 1024;
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_head<NS>), lds), "k_head: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL((k_head<NS>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_head<NS, F32>), lds), "k_head: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((k_head<NS, F32>), dim3((unsigned)a.B * a.mblocks), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_head");
     return LDN_OK;
 }
@@ -1140,12 +1189,18 @@ static int launch_head(HeadArgs& a, hipStream_t st) {
 
 static int bottleneck_head_impl(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
                                 const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
-                                const float* post_sub1, void* h1_split, int ldh, void* x_split, void* stream);
+                                const float* post_sub1, void* h1_split, int ldh, void* x_split, bool f32, void* stream);
 
 extern "C" int ldn_bottleneck_head(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
                                    const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
                                    const float* post_sub1, void* h1_split, int ldh, void* stream) {
-    return bottleneck_head_impl(x, ldx, B, HW, cin, w1_split, width, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1_split, ldh, nullptr, stream);
+    return bottleneck_head_impl(x, ldx, B, HW, cin, w1_split, width, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1_split, ldh, nullptr, false, stream);
+}
+
+extern "C" int ldn_bottleneck_head_f32(const float* x, int ldx, int B, int HW, int cin, const float* w1, int width,
+                                       const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
+                                       const float* post_sub1, float* h1, int ldh, void* stream) {
+    return bottleneck_head_impl(x, ldx, B, HW, cin, w1, width, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1, ldh, nullptr, true, stream);
 }
 
 extern "C" size_t ldn_x_split_bytes(size_t pixels, int cin) { return ((pixels + 31) / 32) * (size_t)cin * 128; }
@@ -1154,12 +1209,12 @@ extern "C" int ldn_bottleneck_head_split(const float* x, int ldx, int B, int HW,
                                          const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
                                          const float* post_sub1, void* h1_split, int ldh, void* x_split, void* stream) {
     LDN_REQUIRE(x_split && (uintptr_t)x_split % 16 == 0, "ldn_bottleneck_head_split: x_split must be a 16-byte aligned buffer of ldn_x_split_bytes(B * HW, cin) bytes");
-    return bottleneck_head_impl(x, ldx, B, HW, cin, w1_split, width, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1_split, ldh, x_split, stream);
+    return bottleneck_head_impl(x, ldx, B, HW, cin, w1_split, width, ch_idx, ch_cnt, scale1, shift1, post_sub1, h1_split, ldh, x_split, false, stream);
 }
 
 static int bottleneck_head_impl(const float* x, int ldx, int B, int HW, int cin, const void* w1_split, int width,
                                 const int32_t* ch_idx, const int32_t* ch_cnt, const float* scale1, const float* shift1,
-                                const float* post_sub1, void* h1_split, int ldh, void* x_split, void* stream) {
+                                const float* post_sub1, void* h1_split, int ldh, void* x_split, bool f32, void* stream) {
     using namespace ldn;
     LDN_REQUIRE(x && w1_split && ch_idx && ch_cnt && scale1 && shift1 && post_sub1 && h1_split, "ldn_bottleneck_head: null pointer");
     LDN_REQUIRE(width == 64 || width == 128 || width == 256, "ldn_bottleneck_head: width must be 64, 128 or 256 (got %d)", width);
@@ -1178,6 +1233,11 @@ static int bottleneck_head_impl(const float* x, int ldx, int B, int HW, int cin,
     // instead of 4 x 196 with a nearly empty seventh wave each)
     if (const int up = round_up(a.pix_per_blk, 32); up <= 256 && (long)up * (a.mblocks - 1) < HW) a.pix_per_blk = up;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (f32) {
+        if (width == 64) return launch_head<2, true>(a, st);
+        if (width == 128) return launch_head<4, true>(a, st);
+        return launch_head<8, true>(a, st);
+    }
     if (width == 64) return launch_head<2>(a, st);
     if (width == 128) return launch_head<4>(a, st);
     return launch_head<8>(a, st);
@@ -1244,7 +1304,7 @@ template <typename T> __device__ __forceinline__ T uniform_ptr(T v) {
 #define CT(x)
 #endif
 
-template <int NS>
+template <int NS, bool F32 = false>
 __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArgs p) {
     constexpr int W = NS * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1276,7 +1336,7 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
             ha.w1s = uniform_ptr(cb->w1s); ha.n_idx = idx_i; ha.n_cnt = cnt_i;
             ha.sc1 = uniform_ptr(cb->sc1); ha.sh1 = uniform_ptr(cb->sh1); ha.ps1 = uniform_ptr(cb->ps1);
             ha.h1 = p.h1; ha.h1_row_bytes = p.h1_row_bytes; ha.pix_per_blk = HW; ha.mblocks = 1; ha.xs = nullptr;
-            head_body<NS>(ha, b, 0, smem, p.lds_total, opaque_tid());
+            head_body<NS, F32>(ha, b, 0, smem, p.lds_total, opaque_tid());
         }
         CT(c3)
         phase_fence();
@@ -1289,7 +1349,7 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
             ta.sc2 = uniform_ptr(cb->sc2); ta.sh2 = uniform_ptr(cb->sh2); ta.ps2 = uniform_ptr(cb->ps2); ta.sh3 = uniform_ptr(cb->sh3);
             ta.residual = xin; ta.ldr = p.ldx; ta.out = p.x_work; ta.ldo = p.ldx; ta.colsum = p.colsum;
             ta.rows_per_blk = p.H; ta.mblocks = 1; ta.slice_bytes = p.slice_bytes; ta.pxs = nullptr; ta.pw = nullptr;
-            tail_body<NS, 1>(ta, b, 0, smem, opaque_tid());
+            tail_body<NS, 1, false, F32>(ta, b, 0, smem, opaque_tid());
         }
         CT(c5)
         phase_fence();
@@ -1320,7 +1380,7 @@ static bool chain_fits(int H, int Wd, int width, int C, int hidden, int G) {
     return lds2 <= lds && lds3 <= lds && ldsm <= lds && lds1 <= lds && round_up(nr, 8) / 8 <= 72;
 }
 
-template <int NS>
+template <int NS, bool F32 = false>
 static int launch_chain(ChainArgs& a, hipStream_t st) {
     constexpr int W = NS * 32;
     const int nr = a.H * a.Wd;
@@ -1328,8 +1388,8 @@ static int launch_chain(ChainArgs& a, hipStream_t st) {
     const size_t lds = 160 * 1024;
     LDN_REQUIRE(chain_fits(a.H, a.Wd, W, a.C, a.hidden, a.G), "ldn_bottleneck_chain: the phases need more than 160 KiB of LDS (map %dx%d, width %d; ldn_bottleneck_chain_fits == 0)", a.H, a.Wd, W);
     a.lds_total = (int)lds;
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_chain<NS>), lds), "k_chain: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL((k_chain<NS>), dim3((unsigned)a.B), dim3(512), lds, st, a);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_chain<NS, F32>), lds), "k_chain: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL((k_chain<NS, F32>), dim3((unsigned)a.B), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_chain");
     return LDN_OK;
 }
@@ -1341,10 +1401,29 @@ extern "C" int ldn_bottleneck_chain_fits(int H, int Wd, int C, int width, int hi
     return ldn::chain_fits(H, Wd, width, C, hidden, G) ? 1 : 0;
 }
 
+static int bottleneck_chain_impl(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
+                                 const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran,
+                                 const float* gap_in, int gap_splits, float* colsum, float* masks, int32_t* ch_idx,
+                                 int32_t* ch_cnt, void* h1_split, int ldh, bool f32, void* stream);
 extern "C" int ldn_bottleneck_chain(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
                                     const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran,
                                     const float* gap_in, int gap_splits, float* colsum, float* masks, int32_t* ch_idx,
                                     int32_t* ch_cnt, void* h1_split, int ldh, void* stream) {
+    return bottleneck_chain_impl(x_in, x_work, ldx, B, H, Wd, C, width, blocks, nblocks, hidden, G, gran, gap_in, gap_splits, colsum, masks,
+                                 ch_idx, ch_cnt, h1_split, ldh, false, stream);
+}
+/* true-fp32 arithmetic: every block's w1s / w2p / w3p in the fp32 twins of the pre-split layouts, h1 a plain fp32 scratch */
+extern "C" int ldn_bottleneck_chain_f32(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
+                                        const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran,
+                                        const float* gap_in, int gap_splits, float* colsum, float* masks, int32_t* ch_idx,
+                                        int32_t* ch_cnt, float* h1, int ldh, void* stream) {
+    return bottleneck_chain_impl(x_in, x_work, ldx, B, H, Wd, C, width, blocks, nblocks, hidden, G, gran, gap_in, gap_splits, colsum, masks,
+                                 ch_idx, ch_cnt, h1, ldh, true, stream);
+}
+static int bottleneck_chain_impl(const float* x_in, float* x_work, int ldx, int B, int H, int Wd, int C, int width,
+                                 const ldn_chain_block* blocks, int nblocks, int hidden, int G, int gran,
+                                 const float* gap_in, int gap_splits, float* colsum, float* masks, int32_t* ch_idx,
+                                 int32_t* ch_cnt, void* h1_split, int ldh, bool f32, void* stream) {
     using namespace ldn;
     LDN_REQUIRE(x_in && x_work && blocks && gap_in && colsum && masks && ch_idx && ch_cnt && h1_split, "ldn_bottleneck_chain: null pointer");
     LDN_REQUIRE(width == 64 || width == 128 || width == 256, "ldn_bottleneck_chain: width must be 64, 128 or 256 (got %d)", width);
@@ -1363,6 +1442,11 @@ extern "C" int ldn_bottleneck_chain(const float* x_in, float* x_work, int ldx, i
     a.masks = masks; a.ch_idx = ch_idx; a.ch_cnt = ch_cnt;
     a.h1 = static_cast<unsigned char*>(h1_split); a.h1_row_bytes = (long)ldh * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (f32) {
+        if (width == 64) return launch_chain<2, true>(a, st);
+        if (width == 128) return launch_chain<4, true>(a, st);
+        return launch_chain<8, true>(a, st);
+    }
     if (width == 64) return launch_chain<2>(a, st);
     if (width == 128) return launch_chain<4>(a, st);
     return launch_chain<8>(a, st);

@@ -487,7 +487,8 @@ class Bottleneck(_PrepCache):
         """The fused conv2 -> conv3 launch (ldn_bottleneck_tail) covers: bf16x3 arithmetic, stride 1 or 2, an even channel
         granularity, widths 64 / 128 / 256, output maps at most 256 wide.  Everything else keeps the three-launch execution."""
         st = self.stride
-        return (self.use_fused_tail and self.channel_exec in ("auto", "fused") and ops.get_math_mode() == "bf16x3"
+        return (self.use_fused_tail and self.channel_exec in ("auto", "fused") and ops.fused_kernel_ok()
+                and (ops.get_math_mode() != "fp32" or self.conv1.in_channels % 32 == 0)      # (the fp32 form has k_head as its only conv1)
                 and (st == 1 or (st == 2 and self.use_strided_tail)) and (Ho, Wo) == ((Hi - 1) // st + 1, (Wi - 1) // st + 1)
                 and self.channel_dyn_granularity % 2 == 0
                 and self.width in (64, 128, 256) and Wo <= 256 and cout % 64 == 0
@@ -524,7 +525,16 @@ class Bottleneck(_PrepCache):
 
     def tail_weights(self, p):
         """conv2 / conv3 weights in the pre-split pair-interleaved layouts of ldn_bottleneck_tail (built once, cached with the
-        other folded parameters)."""
+        other folded parameters).  In the fp32 math mode: their fp32 twins (ldn_bottleneck_*_f32), kept under their own keys."""
+        if ops.get_math_mode() == "fp32":
+            if "w2p32" not in p:
+                with torch.no_grad():
+                    dev = p["s3"].device
+                    p["w2p32"] = ops.pack_w2_pairs(self.conv2.weight.detach().float().to(dev), f32=True)
+                    w3 = self.conv3.weight.detach().float().reshape(-1, self.width).to(dev) * p["s3"].view(-1, 1)
+                    p["w3p32"] = ops.pack_w3_pairs(w3, f32=True)
+                    p["w1s32"] = ops.pack_w1_split(self.conv1.weight.detach().float().reshape(self.width, -1).to(dev), f32=True)
+            return p["w2p32"], p["w3p32"]
         if "w2p" not in p:
             with torch.no_grad():
                 dev = p["s3"].device
@@ -533,6 +543,10 @@ class Bottleneck(_PrepCache):
                 p["w3p"] = ops.pack_w3_pairs(w3)
                 p["w1s"] = ops.pack_w1_split(self.conv1.weight.detach().float().reshape(self.width, -1).to(dev))
         return p["w2p"], p["w3p"]
+
+    @staticmethod
+    def _w1s_key():
+        return "w1s32" if ops.get_math_mode() == "fp32" else "w1s"
 
     def _shortcut(self, xn, p, identity):
         """Projection shortcut (laud_resnet.py:138-141).  Maps of fewer than 96 pixels run as ONE list of strided pixel rows that
@@ -568,7 +582,7 @@ class Bottleneck(_PrepCache):
         dev = x.device
         cout = p["w3"].shape[2]
         side = None
-        fold_proj = (self.downsample is not None and self.use_folded_projection and self.stride == 1 and p.get("ds_stride") == 1
+        fold_proj = (self.downsample is not None and self.use_folded_projection and ops.get_math_mode() == "bf16x3" and self.stride == 1 and p.get("ds_stride") == 1
                      and self.use_fused_head and self.width in self.fused_head_widths and self._tail_eligible(Hi, Wi, Ho, Wo, cout)
                      and ops.bottleneck_tail_proj_fits(Hi, Wi, W, Cin))
         if fold_proj:
@@ -612,8 +626,10 @@ class Bottleneck(_PrepCache):
             w2p, w3p = self.tail_weights(p)
             # k_head (deep staging ring, one workgroup per CU) pays where an image fills a workgroup and K is long (stage 3);
             # the early stages stream many short blocks and stay on the general kernel, two workgroups per CU (measured)
-            if self.use_fused_head and Cin % 32 == 0 and self.width in self.fused_head_widths:
-                ops.bottleneck_head(xn, p["w1s"], idx, cnt, p["s1"], p["t1"], p["c1"], h1)
+            if (self.use_fused_head and Cin % 32 == 0 and self.width in self.fused_head_widths) or ops.get_math_mode() == "fp32":
+                if ops.get_math_mode() == "fp32" and Cin % 32:
+                    raise LdnError("Bottleneck: the fp32 fused path needs cin % 32 == 0")
+                ops.bottleneck_head(xn, p[self._w1s_key()], idx, cnt, p["s1"], p["t1"], p["c1"], h1)
             else:
                 ops.conv_image(xn, p["w1"], p["s1"], p["t1"], h1, n_idx=idx, n_cnt=cnt, post_sub=p["c1"], relu=1, out_split=True)
             if side is not None:
@@ -1059,7 +1075,8 @@ class ResNet(nn.Module):
         dev = x.device
         preps = [blk._prep if blk._cache_valid() else blk._prepare(dev) for blk in run]
         mws = [blk.masker_channel._weights() for blk in run]
-        key = (str(dev),) + tuple(blk._prep_gen for blk in run) + tuple(blk.masker_channel._prep_gen for blk in run)
+        f32 = ops.get_math_mode() == "fp32"
+        key = (str(dev), f32) + tuple(blk._prep_gen for blk in run) + tuple(blk.masker_channel._prep_gen for blk in run)
         cache = getattr(self, "_chain_cache", None)
         if cache is None:
             cache = self._chain_cache = {}
@@ -1068,7 +1085,7 @@ class ResNet(nn.Module):
             rows = []
             for blk, p, mw in zip(run, preps, mws):
                 w2p, w3p = blk.tail_weights(p)
-                rows.append((p["w1s"], p["s1"], p["t1"], p["c1"], w2p, w3p, p["s2"], p["t2_tab"], p["c2"], p["t3c"],
+                rows.append((p[blk._w1s_key()], p["s1"], p["t1"], p["c1"], w2p, w3p, p["s2"], p["t2_tab"], p["c2"], p["t3c"],
                              mw[0], mw[1], mw[2], mw[3]))
             ent = cache[id(run[0])] = (key, ops.chain_table(rows, dev), rows)     # rows: keeps the tensors alive
         first = run[0]
@@ -1077,7 +1094,7 @@ class ResNet(nn.Module):
         xn = ops.as_nhwc(x)
         work = xn if self.inplace_residual else torch.empty_like(xn)
         masks, idx, cnt, colsum = ops.bottleneck_chain(xn, work, ent[1], first.width, hidden, m.channel_dyn_group,
-                                                       first.channel_dyn_granularity, gap)
+                                                       first.channel_dyn_granularity, gap, f32=f32)
         stats = []
         denom = float(x.shape[0] * first.width)
         for i, blk in enumerate(run):

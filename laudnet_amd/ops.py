@@ -219,6 +219,8 @@ USE_DENSE_KERNEL = os.environ.get("LDN_DENSE_KERNEL", "1") != "0"   # tuning swi
 # workgroups on 256 CUs at stage 3) cost their full share while round 1's smaller tiles fill the chip -- off by default, kept as the
 # ABI's fp32 entry point with the epilogue features (channel mask, shift table, LayerNorm / GELU terms) round 1's kernel lacks
 USE_DENSE_F32 = os.environ.get("LDN_DENSE_F32", "0") != "0"
+# fp32 math mode on the fused channel-mode kernels (k_head / k_tail / k_chain in true-fp32 MFMA arithmetic: ldn_bottleneck_*_f32)
+USE_FUSED_F32 = os.environ.get("LDN_FUSED_F32", "1") != "0"
 
 
 def dense_kernel_ok():
@@ -226,6 +228,13 @@ def dense_kernel_ok():
     ldn_conv_rows_f32)?"""
     mode = get_math_mode()
     return USE_DENSE_KERNEL and (mode == "bf16x3" or (mode == "fp32" and USE_DENSE_F32))
+
+
+def fused_kernel_ok():
+    """Does the current arithmetic mode run channel-mode blocks on the fused kernels (k_head / k_tail / k_chain: bf16x3, or their
+    true-fp32 forms ldn_bottleneck_*_f32)?"""
+    mode = get_math_mode()
+    return mode == "bf16x3" or (mode == "fp32" and USE_FUSED_F32)
 
 
 def split_rows_weight(w):
@@ -500,27 +509,35 @@ def _hi_lo(w):
     return hi, lo
 
 
-def pack_w2_pairs(conv2_weight):
+def pack_w2_pairs(conv2_weight, f32=False):
     """conv2.weight [W(out n), W(in k), 3, 3] fp32 -> the pair-interleaved, pre-split layout of ldn_bottleneck_tail:
-    [9][W/2 kp][W/2 np][2 n][hi k0, hi k1, lo k0, lo k1] bf16 (one-time module preparation, include/ldn_hip.h)."""
+    [9][W/2 kp][W/2 np][2 n][hi k0, hi k1, lo k0, lo k1] bf16 (one-time module preparation, include/ldn_hip.h).
+    f32: the fp32 twin of ldn_bottleneck_tail_f32, [9][W/2 kp][W/2 np][2 n][w k0, w k1] fp32 -- the same 8 bytes per (n, k pair)."""
     W = conv2_weight.shape[0]
     w = conv2_weight.detach().float().permute(2, 3, 1, 0).reshape(9, W // 2, 2, W // 2, 2)   # [tap][kp][kk][np][nn]
     w = w.permute(0, 1, 3, 4, 2).contiguous()                                                 # [tap][kp][np][nn][kk]
+    if f32:
+        return w
     hi, lo = _hi_lo(w)
     return torch.stack((hi, lo), dim=-2).contiguous()                                         # [...][nn][hi/lo][kk]
 
 
-def pack_w3_pairs(w3_scaled):
-    """bn3.scale * conv3.weight as [cout, W] fp32 -> [W/2 kp][cout][hi k0, hi k1, lo k0, lo k1] bf16."""
+def pack_w3_pairs(w3_scaled, f32=False):
+    """bn3.scale * conv3.weight as [cout, W] fp32 -> [W/2 kp][cout][hi k0, hi k1, lo k0, lo k1] bf16 (f32: [W/2 kp][cout][w k0, w k1] fp32)."""
     cout, W = w3_scaled.shape
     w = w3_scaled.detach().float().t().reshape(W // 2, 2, cout).permute(0, 2, 1).contiguous()   # [kp][c][kk]
+    if f32:
+        return w
     hi, lo = _hi_lo(w)
     return torch.stack((hi, lo), dim=-2).contiguous()
 
 
-def pack_w1_split(conv1_weight_2d):
-    """conv1.weight as [W, cin] fp32 -> [W][cin/8][hi 8 | lo 8] bf16 (n-major rows, pre-split; ldn_bottleneck_head)."""
+def pack_w1_split(conv1_weight_2d, f32=False):
+    """conv1.weight as [W, cin] fp32 -> [W][cin/8][hi 8 | lo 8] bf16 (n-major rows, pre-split; ldn_bottleneck_head).  f32: the plain
+    contiguous fp32 matrix (ldn_bottleneck_head_f32: [n][octet][8 floats] IS row-major fp32)."""
     W, cin = conv1_weight_2d.shape
+    if f32:
+        return conv1_weight_2d.detach().float().contiguous()
     w = conv1_weight_2d.detach().float().reshape(W, cin // 8, 8)
     hi, lo = _hi_lo(w)
     return torch.stack((hi, lo), dim=-2).contiguous()
@@ -534,6 +551,14 @@ def bottleneck_head(x_nhwc, w1_split, ch_idx, ch_cnt, scale1, shift1, post_sub1,
     lib = L.load()
     B, H, Wd, cin = x_nhwc.shape
     width = ch_idx.shape[1]
+    if w1_split.dtype == torch.float32:      # true-fp32 arithmetic (pack_w1_split(..., f32=True))
+        if not w1_split.is_contiguous() or x_split is not None:
+            raise L.LdnError("bottleneck_head: the fp32 form takes a contiguous fp32 weight matrix and writes no x_split")
+        L.check(lib.ldn_bottleneck_head_f32(L.ptr(_f32c(x_nhwc, "x")), cin, B, H * Wd, cin, L.ptr(w1_split), width,
+                                            L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")), L.ptr(_f32c(scale1, "scale1")),
+                                            L.ptr(_f32c(shift1, "shift1")), L.ptr(_f32c(post_sub1, "post_sub1")),
+                                            L.ptr(_f32c(h1_split, "h1")), h1_split.shape[-1], L.stream_ptr(h1_split)), "ldn_bottleneck_head_f32")
+        return h1_split
     if w1_split.dtype != torch.bfloat16 or not w1_split.is_contiguous():
         raise L.LdnError("bottleneck_head: w1_split must be the contiguous bf16 tensor of pack_w1_split")
     if x_split is not None:
@@ -570,7 +595,7 @@ def chain_table(rows, device):
     return torch.tensor(flat, dtype=torch.int64).view(len(rows), CHAIN_BLOCK_FIELDS).to(device)
 
 
-def bottleneck_chain(x_in, x_work, table, width, hidden, G, gran, gap_in):
+def bottleneck_chain(x_in, x_work, table, width, hidden, G, gran, gap_in, f32=False):
     """A run of stride-1 channel-mode bottlenecks as one launch (see ldn_bottleneck_chain).  x_in / x_work [B,H,Wd,C] NHWC fp32
     (may be the same tensor); table = chain_table(...); gap_in [B,splits,C].
     Returns (masks [n,B,G], ch_idx [n,B,width], ch_cnt [n,B], colsum [B,8,C]); x_work holds the run's output."""
@@ -590,7 +615,7 @@ def bottleneck_chain(x_in, x_work, table, width, hidden, G, gran, gap_in):
     ch_cnt = torch.empty(n, B, device=dev, dtype=torch.int32)
     colsum = torch.empty(B, 8, C, device=dev, dtype=torch.float32)
     h1 = torch.empty(B, H, Wd, width, device=dev, dtype=torch.float32)
-    L.check(lib.ldn_bottleneck_chain(L.ptr(x_in), L.ptr(x_work), C, B, H, Wd, C, width, L.ptr(table), n, hidden, G, gran,
+    L.check((lib.ldn_bottleneck_chain_f32 if f32 else lib.ldn_bottleneck_chain)(L.ptr(x_in), L.ptr(x_work), C, B, H, Wd, C, width, L.ptr(table), n, hidden, G, gran,
                                      L.ptr(_f32c(gap_in, "gap_in")), gap_in.shape[1], L.ptr(colsum), L.ptr(masks), L.ptr(ch_idx),
                                      L.ptr(ch_cnt), L.ptr(h1), width, L.stream_ptr(x_work)), "ldn_bottleneck_chain")
     return masks, ch_idx, ch_cnt, colsum
@@ -619,9 +644,10 @@ def bottleneck_tail(h1_split, w2_pairs, w3_pairs, ch_idx, ch_cnt, scale2, shift2
     Ho, Wo = (H - 1) // stride + 1, (Wd - 1) // stride + 1
     if tuple(out_nhwc.shape) != (B, Ho, Wo, cout) or (residual is not None and tuple(residual.shape[:3]) != (B, Ho, Wo)):
         raise L.LdnError(f"bottleneck_tail: out / residual must be [B={B}, {Ho}, {Wo}, cout] for an {H}x{Wd} input at stride {stride}")
-    if w2_pairs.dtype != torch.bfloat16 or w3_pairs.dtype != torch.bfloat16 or not (w2_pairs.is_contiguous() and w3_pairs.is_contiguous()):
-        raise L.LdnError("bottleneck_tail: w2_pairs / w3_pairs must be the contiguous bf16 tensors of pack_w2_pairs / pack_w3_pairs")
-    L.check(lib.ldn_bottleneck_tail(L.ptr(_f32c(h1_split, "h1")), ldh, B, H, Wd, stride, width, L.ptr(w2_pairs), L.ptr(w3_pairs), cout,
+    if w2_pairs.dtype != w3_pairs.dtype or w2_pairs.dtype not in (torch.bfloat16, torch.float32) or not (w2_pairs.is_contiguous() and w3_pairs.is_contiguous()):
+        raise L.LdnError("bottleneck_tail: w2_pairs / w3_pairs must be the contiguous tensors of pack_w2_pairs / pack_w3_pairs (both bf16, or both fp32)")
+    fn = lib.ldn_bottleneck_tail if w2_pairs.dtype == torch.bfloat16 else lib.ldn_bottleneck_tail_f32
+    L.check(fn(L.ptr(_f32c(h1_split, "h1")), ldh, B, H, Wd, stride, width, L.ptr(w2_pairs), L.ptr(w3_pairs), cout,
                                     L.ptr(_i32c(ch_idx, "ch_idx")), L.ptr(_i32c(ch_cnt, "ch_cnt")), L.ptr(_f32c(scale2, "scale2")),
                                     L.ptr(_f32c(shift2_tab, "shift2_tab")), L.ptr(_f32c(post_sub2, "post_sub2")),
                                     L.ptr(_f32c(shift3, "shift3")), L.ptr(residual),

@@ -19,6 +19,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture(autouse=True)
+def _bf16x3_mode():
+    """k_smallmap is a bf16x3 kernel and Bottleneck.tail_weights follows the arithmetic mode (round 4: fp32 twins of the layouts)."""
+    from laudnet_amd import ops as _ops
+    _ops.set_math_mode("bf16x3")
+    yield
+    _ops.set_math_mode("fp32")
+
+
 def _block_pair(cin, W, gran, Ho):
     from laudnet_amd.laud_resnet import Bottleneck
     blk = TR.BottleneckRef(cin, W, stride=1, downsample=None, dyn_mode="channel", channel_dyn_granularity=gran,

@@ -35,6 +35,14 @@ def _decode_split(h1s):
                                                (3, 56, 256, 128, 2, 2), (3, 28, 512, 256, 2, 2), (2, 13, 64, 64, 2, 2),
                                                (2, 30, 64, 128, 4, 2), (2, 56, 32, 64, 2, 2), (5, 8, 64, 256, 2, 2)])
 def test_tail_vs_reference_algebra(ops, B, H, cin, W, gran, st):
+    ops.set_math_mode("bf16x3")      # the pre-split (bf16 hi | lo) formats are checked here; Bottleneck.tail_weights follows the mode
+    try:
+        _tail_vs_reference_algebra(ops, B, H, cin, W, gran, st)
+    finally:
+        ops.set_math_mode("fp32")
+
+
+def _tail_vs_reference_algebra(ops, B, H, cin, W, gran, st):
     G = W // gran
     gm = seeded_bernoulli((B, G), 0.62, 31 + H)
     gm[0] = 0.0          # an image with no active channel

@@ -13,7 +13,7 @@ for line in open(src):
     if line.startswith("=="):
         sec = line[2:].split("(")[0].split()
         continue
-    m = re.match(r"\d+ .*k_chain<\d+> \d+ (.*)", line)
+    m = re.match(r"\d+ .*k_chain<\d+(?:, \w+)?> \d+ (.*)", line)
     if m and sec:
         nums = [float(v) for v in m.group(1).split()]
         for name, v in zip(sorted(sec), nums):

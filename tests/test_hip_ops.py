@@ -640,8 +640,6 @@ def test_conv_rows_f32_kernel_vs_fp64(ops, rows, cin, cout, taps):
             want = torch.relu(torch.einsum("rtc,otc->ro", g, w.double()) + sh.double() + res.double())
             a_rows = nb.to(DEV)
         out = torch.zeros(rows, cout, device=DEV)
-        seen = []
-        lib = L_load()
         _o.conv_rows(a.to(DEV), w.to(DEV), None, sh.to(DEV), out, a_rows=a_rows, taps=taps, m_cap=rows, relu=1, residual2d=res.to(DEV))
         err = (out.cpu().double() - want).abs().max().item()
         assert err < 2e-5 * max(1.0, want.abs().max().item()), err
@@ -649,7 +647,3 @@ def test_conv_rows_f32_kernel_vs_fp64(ops, rows, cin, cout, taps):
         _o.USE_DENSE_F32 = before[0]
         _o.set_math_mode(before[1])
 
-
-def L_load():
-    from laudnet_amd import _lib
-    return _lib.load()

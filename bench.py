@@ -162,6 +162,49 @@ def bench_adavit(args):
     print(json.dumps(result))
 
 
+def measure_chain_traffic(keep, batch):
+    """HBM traffic of the dominant kernel (k_chain) measured ON THIS BOX: two separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE,
+    WRITE_SIZE: the guide's recipe -- one TCC counter set per pass, no other trace domains) over a short product-path run of this script,
+    read back from the rocpd database.  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B, MI355X_MICROARCH.md).  Returns
+    None when rocprofv3 is not usable here (the committed PMC pass of profiles/ is quoted then)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ldn_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
+                   "--warmup", "1", "--no-legs", "--batch", str(batch), "--keep", repr(float(keep))]
+            subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None
+            rows = sqlite3.connect(dbs[0]).execute("select dispatch_id, value from counters_collection where counter_name = ? and "
+                                                   "kernel_name like '%k_chain%'", (ctr,)).fetchall()
+            per = {}
+            for disp, v in rows:
+                per[disp] = per.get(disp, 0.0) + v
+            if not per:
+                return None
+            vals[ctr] = min(per.values())     # KiB per dispatch; steady-state launches (the first also pulls the weights from HBM)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"traffic_bytes_per_launch": int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "fetch_kib_raw": vals["FETCH_SIZE"],
+            "write_kib": vals["WRITE_SIZE"],
+            "scope": "whole k_chain launch = 22 stage-3 blocks (9.14 GB algorithmic: every block's input read once + output written once); "
+                     "FETCH_SIZE / WRITE_SIZE are counted at the L2-fabric boundary, so Infinity-Cache hits are included",
+            "source": "MEASURED IN THIS RUN on this box: two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE) over `bench.py --steps 2 "
+                      "--warmup 1 --no-legs` right after the timed region; FETCH_SIZE doubled per MI355X_MICROARCH.md"}
+
+
 SECONDARY = ("spatial", "layer", "regnet", "adavit")     # BASELINE.json configs[2], the layer-skip ResNet, configs[3] (per-GPU shard), configs[4]
 
 
@@ -517,6 +560,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--brief", action="store_true", help="product path + roofline leg + dense emulation with same-mask parity only (no fp32 / "
                     "keep-1.0 / hipGraph legs, no decision audits, no CPU baseline): what the headline run uses for its `secondary` workloads")
+    ap.add_argument("--no-pmc", action="store_true", help="headline run: quote the committed PMC pass of profiles/ for `roofline.traffic` instead of "
+                    "measuring it in this run (two rocprofv3 --pmc passes, ~1.5 min)")
     ap.add_argument("--no-secondary", action="store_true", help="headline run: do not append the `secondary` dict (BASELINE configs 3-5 "
                     "timed in the same invocation)")
     ap.add_argument("--graph", action="store_true", help="time the forward replayed as one hipGraph (same kernels, no launch "
@@ -705,6 +750,11 @@ def main():
         tjs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))   # the latest round's committed PMC pass
         tj = tjs[-1] if tjs else ""
         traffic = json.load(open(tj)) if (args.workload == "channel" and args.batch == 256 and os.path.exists(tj)) else {}
+        if (rank == 0 and world == 1 and args.workload == "channel" and args.math == "bf16x3" and not args.no_legs and not args.brief
+                and not args.no_pmc and "chain_fused" in agg):
+            live = measure_chain_traffic(keep_used, args.batch)      # the dominant kernel's traffic on THIS box (falls back to the committed pass)
+            if live is not None:
+                traffic = dict(traffic, chain_fused_bf16x3=live)
         mode = args.math
 
         def mfma_roofline(n, ms, flops, nbytes):

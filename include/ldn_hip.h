@@ -97,6 +97,26 @@ int ldn_mask_to_index(const float* patch_mask, int B, int Sy, int Sx, int Ho, in
                       int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work, void* stream);
 size_t ldn_mask_to_index_workspace_bytes(int B, int Ho, int Wo, int stride);
 
+/* ---- a1 + a4 in ONE launch (round 4): the fused spatial masker of a run of identity blocks (models/utils.py:47-65 +
+ * laud_resnet.py:96-110).  The lists, counts, prefixes and statistics of ldn_mask_to_index, from
+ *   patch_mask [B][S][Sx] {0,1}                                 (pool / w / bias / mask_out / logits unused), or
+ *   patch_mask == NULL: the pooled channel means pool [B][S*Sx][C] of the block's input (the `work` buffer of
+ *     ldn_spatial_masker, whose touched patches the previous block's ldn_conv_rows_pool refreshed) and the masker's 1x1 conv
+ *     w [2][C], bias [2] (one mask group): mask_out [B][1][S][Sx] = (l0 >= l1) exactly as ldn_spatial_masker decides from the
+ *     same means (same arithmetic order), logits [B][2][S][Sx] optional -- x is not read.
+ * patch_major = 1 (even grids: Ho % S == 0, Wo % Sx == 0): idx3 lists the kept pixels PATCH BY PATCH (row-major inside a patch,
+ * patches in row-major order) instead of row-major over the image -- the same set of rows, counts and prefixes; pos3 / nbr follow
+ * the order -- so that Ho/S * Wo/Sx consecutive packed rows are one patch (what ldn_conv_rows_pool needs).
+ * Images are processed one workgroup each; the prefix over the images is taken inside the launch (every workgroup publishes its
+ * counts and waits, bounded, for those of the workgroups dispatched in front of it);
+ * ldn_mask_plan_fits says whether the per-image tables fit one workgroup's LDS (else: ldn_mask_to_index, which builds by bands).
+ * work: int32 scratch of ldn_mask_to_index_workspace_bytes(B, Ho, Wo, stride). */
+int ldn_mask_plan_fits(int S, int Sx, int Ho, int Wo, int stride);
+int ldn_mask_plan(const float* patch_mask, const float* pool, int C, const float* w, const float* bias, float* mask_out,
+                  float* logits, int B, int S, int Sx, int Ho, int Wo, int stride, int patch_major, int32_t* idx3,
+                  int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt, int32_t* img_prefix3,
+                  int32_t* img_prefix1, float* stats, int32_t* work, void* stream);
+
 /* ---- K2/K5: stand-alone row gather / masked scatter-add (DyNetSimulator simulate_gather,
  * simulate_scatter_add; laud_resnet.py:133,143-144) ----------------------------------------- */
 /* packed[r,:] = src[rows[r],:] for r < *count (count==NULL -> cap) ; C % 4 == 0 */
@@ -149,6 +169,18 @@ int ldn_conv_rows_f32(const float* a, int lda, const int32_t* a_rows, int taps, 
                         int ldo, const float* post_sub, const float* chan_mask, int rows_per_image, int shift_classes,
                         const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride, const float* ln_stats,
                         const float* ln_c1, void* stream);
+
+/* ldn_conv_rows_split / ldn_conv_rows_f32 with taps == 1, plus a by-product: pool [B][S*Sx][cout] receives, for every patch
+ * this launch writes, the MEAN of the final output (after residual and ReLU) over the patch's Ho/S x Wo/Sx pixels (4 or 16) --
+ * the pooled means the next block's spatial masker needs (adaptive_avg_pool2d of models/utils.py:48-52 on an even grid), so
+ * that masker never reads x (ldn_mask_plan, patch_mask == NULL).  The packed rows must list whole patches, Ho/S * Wo/Sx
+ * consecutive rows each (ldn_mask_plan with patch_major = 1; the sums are a fixed-order register tree: deterministic);
+ * out_rows = flat pixel numbers b*Ho*Wo + y*Wo + x.  cout % 128 == 0.  math_mode LDN_MATH_FP32: w = plain [cout][cin] floats;
+ * LDN_MATH_BF16X3: w = the pre-split rows of ldn_conv_rows_split. */
+int ldn_conv_rows_pool(const float* a, int lda, const int32_t* a_rows, const int32_t* m_count, int m_cap, const void* w,
+                       int cin, int cout, const float* scale, const float* shift, int relu, const int32_t* relu_if_neg,
+                       const int32_t* out_rows, const float* residual, int ldr, float* out, int ldo, float* pool, int S,
+                       int Sx, int Ho, int Wo, int math_mode, void* stream);
 /* stats[r] = {mean, 1 / sqrt(biased variance + eps)} of row r of x [rows][ld >= C] (nn.LayerNorm's statistics), C % 4 == 0, C <= 2048 */
 int ldn_row_stats(const float* x, int ld, int rows, int C, float eps, float* stats, void* stream);
 

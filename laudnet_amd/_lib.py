@@ -24,6 +24,9 @@ SIGNATURES = {
     "ldn_spatial_masker_workspace_bytes": ([_I, _I, _I, _I, _I], C.c_size_t),
     "ldn_mask_to_index": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "ldn_mask_to_index_workspace_bytes": ([_I, _I, _I, _I], C.c_size_t),
+    "ldn_mask_plan_fits": ([_I, _I, _I, _I, _I], _I),
+    "ldn_mask_plan": ([_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "ldn_conv_rows_pool": ([_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P], _I),
     "ldn_gather_rows": ([_P, _I, _P, _P, _I, _I, _P, _I, _P], _I),
     "ldn_scatter_add_relu": ([_P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P], _I),
     "ldn_conv_rows": ([_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P], _I),
@@ -109,10 +112,25 @@ def stream_ptr(t=None):
     return C.c_void_p(torch.cuda.current_stream(t.device if t is not None else None).cuda_stream)
 
 
+_SYNC_CALLS = os.environ.get("LDN_SYNC_CALLS", "0") != "0"    # debugging: synchronize after every library call and name it on stderr
+_n_calls = 0
+
+
 def check(status: int, what: str):
     if status != 0:
         msg = load().ldn_last_error()
         raise LdnError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
+    if _SYNC_CALLS:
+        global _n_calls
+        import sys
+        import torch
+        _n_calls += 1
+        print(f"[ldn] {_n_calls} {what} ...", end="", file=sys.stderr, flush=True)
+        if torch.cuda.is_current_stream_capturing():
+            print(" (capturing)", file=sys.stderr, flush=True)
+            return
+        torch.cuda.synchronize()
+        print(" ok", file=sys.stderr, flush=True)
 
 
 def require_device(*tensors):

@@ -31,6 +31,9 @@ struct DenseArgs {
     int mtn, ntn;                                     // M tiles (of 256 rows), N tiles (of NT columns)
     const float* ln_stats; const float* ln_c1;        // optional LayerNorm of the A rows as an epilogue term: [rows_a][2] = {mean, rstd} of
                                                       // every SOURCE row, and c1[n] = sum_k w[n][k] (w carries the LayerNorm weight)
+    float* pool; int pool_gy, pool_gx, pool_Sx;       // optional [B][S * Sx][cout]: the mean of the FINAL output over every patch of gy x gx pixels
+                                                      // this launch writes (gy * gx = 4 or 16 consecutive packed rows = one patch: patch-major
+                                                      // lists of k_plan) -- the next spatial masker's pooled means (models/utils.py:48-52)
 };
 
 __device__ __attribute__((aligned(16))) float g_dense_zero[4] = {0.f, 0.f, 0.f, 0.f};
@@ -346,6 +349,21 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) orw[it] = s_orow[wave * 32 + trw + 8 * it];
     const bool gelu = p.relu == 3;
+    // pooled patch means (1x1, whole column tiles): which patch row of `pool` this lane stores, -1 = none.  16-pixel patches: the wave's
+    // rows 0-15 / 16-31; the lanes with row-in-octet 0 of each half store.  4-pixel patches: rows 4q .. 4q+3, every lane stores one.
+    long poff = -1;
+    const int pb3 = (lane >> 3) & 1, pb4 = (lane >> 4) & 1;
+    if constexpr (!T9 && FULL) {
+        if (p.pool) {
+            const int it_sel = p.pool_gy * p.pool_gx == 16 ? (lane >= 32 ? 2 : 0) : pb3 + 2 * pb4;
+            const int o = it_sel == 0 ? orw[0] : it_sel == 1 ? orw[1] : it_sel == 2 ? orw[2] : orw[3];
+            if (o >= 0 && (p.pool_gy * p.pool_gx == 4 || (lane & 0x18) == 0)) {
+                const int f = o & (D_ROW_RELU - 1), hw = p.Ho * p.Wo;
+                const int b = f / hw, pix = f - b * hw, y = pix / p.Wo, x = pix - y * p.Wo;
+                poff = ((long)b * (p.Ho / p.pool_gy) * p.pool_Sx + (y / p.pool_gy) * p.pool_Sx + x / p.pool_gx) * p.cout;
+            }
+        }
+    }
     auto load_res = [&](int j, f32x4 (&res)[4], f32x4& sc, f32x4& sh, f32x4& ps) {
         const int cb = n0 + 32 * j + tc * 4;
         const bool cok = FULL || cb < p.cout;                    // (a ragged last subtile: columns beyond cout are neither read nor stored)
@@ -393,6 +411,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         // for that store's acknowledgement)
         asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sc), "+v"(sh), "+v"(ps));
         asm volatile("" : "+v"(cm[0]), "+v"(cm[1]), "+v"(cm[2]), "+v"(cm[3]));
+        f32x4 xs4[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = trw + 8 * it;
@@ -411,6 +430,36 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
             x = (x - ps) * cm[it];
             if (orw[it] >= 0 && cok)
                 *reinterpret_cast<f32x4*>(p.out + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + tc * 4) = x;
+            xs4[it] = x;
+        }
+        if constexpr (!T9 && FULL) {
+            if (p.pool) {   // (wave-uniform) fixed-order sums over the rows of each patch: a register tree across the lanes that hold the patch
+                f32x4 m;
+                if (p.pool_gy * p.pool_gx == 16) {
+                    const bool up = lane >= 32;
+                    const f32x4 sa = xs4[0] + xs4[1], sb = xs4[2] + xs4[3];
+                    m = up ? sb : sa;
+                    const f32x4 give = up ? sa : sb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] += __shfl_xor(give[e], 32, 64);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] += __shfl_xor(m[e], 16, 64);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] += __shfl_xor(m[e], 8, 64);
+                    m *= 0.0625f;
+                } else {
+                    f32x4 k01 = pb3 ? xs4[1] : xs4[0], k23 = pb3 ? xs4[3] : xs4[2];
+                    const f32x4 g01 = pb3 ? xs4[0] : xs4[1], g23 = pb3 ? xs4[2] : xs4[3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { k01[e] += __shfl_xor(g01[e], 8, 64); k23[e] += __shfl_xor(g23[e], 8, 64); }
+                    m = pb4 ? k23 : k01;
+                    const f32x4 gg = pb4 ? k01 : k23;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] += __shfl_xor(gg[e], 16, 64);
+                    m *= 0.25f;
+                }
+                if (poff >= 0) *reinterpret_cast<f32x4*>(p.pool + poff + n0 + 32 * j + tc * 4) = m;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -494,7 +543,8 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
                                 const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
                                 float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
                                 int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
-                                const float* ln_stats, const float* ln_c1, bool f32, void* stream);
+                                const float* ln_stats, const float* ln_c1, bool f32, void* stream, float* pool = nullptr, int pool_S = 0,
+                                int pool_Sx = 0);
 
 extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                                    const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
@@ -516,13 +566,37 @@ extern "C" int ldn_conv_rows_f32(const float* a, int lda, const int32_t* a_rows,
                                 out, ldo, post_sub, chan_mask, rows_per_image, shift_classes, pix_map, Hi, Wi, Ho, Wo, stride, ln_stats, ln_c1, true, stream);
 }
 
+// The 1x1 form with the pooled patch means of its output as a by-product (the fused spatial masker): `pool`
+// [B][S * Sx][cout] receives, for every patch this launch writes, the mean of the final output (after residual and ReLU) over the
+// patch's Ho / S x Wo / Sx pixels (4 or 16).  The packed rows must list whole patches, Ho / S * Wo / Sx consecutive rows each
+// (ldn_mask_plan with patch_major = 1); out_rows are flat pixel indices b * Ho * Wo + y * Wo + x.  math_mode: 0 = fp32 weights /
+// arithmetic (w = plain [cout][cin] floats), 1 = bf16x3 (w = the pre-split rows of ldn_split_rows_weight).
+extern "C" int ldn_conv_rows_pool(const float* a, int lda, const int32_t* a_rows, const int32_t* m_count, int m_cap, const void* w,
+                                  int cin, int cout, const float* scale, const float* shift, int relu, const int32_t* relu_if_neg,
+                                  const int32_t* out_rows, const float* residual, int ldr, float* out, int ldo, float* pool, int S,
+                                  int Sx, int Ho, int Wo, int math_mode, void* stream) {
+    LDN_REQUIRE(pool, "ldn_conv_rows_pool: null pool");
+    LDN_REQUIRE(math_mode == 0 || math_mode == 1, "ldn_conv_rows_pool: math_mode must be 0 (fp32) or 1 (bf16x3)");
+    return conv_rows_dense_impl(a, lda, a_rows, 1, m_count, m_cap, w, cin, cout, scale, shift, relu, relu_if_neg, out_rows, residual, ldr,
+                                out, ldo, nullptr, nullptr, 0, 1, nullptr, 0, 0, Ho, Wo, 1, nullptr, nullptr, math_mode == 0, stream, pool, S, Sx);
+}
+
 static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                                 const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
                                 const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
                                 float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
                                 int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
-                                const float* ln_stats, const float* ln_c1, bool f32, void* stream) {
+                                const float* ln_stats, const float* ln_c1, bool f32, void* stream, float* pool, int pool_S, int pool_Sx) {
     LDN_REQUIRE(a && w_split && shift && out, "ldn_conv_rows_split: null pointer");
+    int pool_gy = 0, pool_gx = 0;
+    if (pool) {
+        LDN_REQUIRE(taps == 1 && cout % 128 == 0 && !post_sub && !chan_mask && !ln_stats && (uintptr_t)pool % 16 == 0,
+                    "ldn_conv_rows_pool: 1x1 only, cout a multiple of 128, no post_sub / chan_mask / LayerNorm terms");
+        LDN_REQUIRE(pool_S > 0 && pool_Sx > 0 && Ho > 0 && Wo > 0 && Ho % pool_S == 0 && Wo % pool_Sx == 0,
+                    "ldn_conv_rows_pool: the %dx%d map must split evenly into %dx%d patches", Ho, Wo, pool_S, pool_Sx);
+        pool_gy = Ho / pool_S; pool_gx = Wo / pool_Sx;
+        LDN_REQUIRE(pool_gy * pool_gx == 4 || pool_gy * pool_gx == 16, "ldn_conv_rows_pool: patches of 4 or 16 pixels (got %dx%d)", pool_gy, pool_gx);
+    }
     LDN_REQUIRE((ln_stats == nullptr) == (ln_c1 == nullptr) && (!ln_stats || taps == 1), "ldn_conv_rows_split: ln_stats and ln_c1 go together (1x1 only)");
     LDN_REQUIRE((uintptr_t)ln_stats % 8 == 0 && (uintptr_t)ln_c1 % 16 == 0, "ldn_conv_rows_split: ln_stats / ln_c1 must be 8 / 16-byte aligned");
     LDN_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 4 == 0, "ldn_conv_rows_split: cin must be a multiple of 8 and cout of 4 (got %d, %d)", cin, cout);
@@ -539,7 +613,7 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
     if (m_cap <= 0) return LDN_OK;
     DenseArgs d{a, lda, a_rows, m_count, m_cap, static_cast<const unsigned char*>(w_split), cin, cout, scale, shift, relu,
                 relu_if_neg, out_rows, residual, ldr, out, ldo, taps, shift_classes, pix_map, Hi, Wi, Ho > 0 ? Ho : 1, Wo > 0 ? Wo : 1,
-                stride, post_sub, chan_mask, rows_per_image > 0 ? rows_per_image : 1, 0, 0, ln_stats, ln_c1};
+                stride, post_sub, chan_mask, rows_per_image > 0 ? rows_per_image : 1, 0, 0, ln_stats, ln_c1, pool, pool_gy, pool_gx, pool_Sx};
     hipStream_t st = static_cast<hipStream_t>(stream);
     // columns per workgroup: as wide as the layer allows (fewer passes over the activation rows) while the grid still fills the chip
     const int mt = ceil_div(m_cap, D_ROWS);

@@ -42,6 +42,10 @@ __device__ __forceinline__ int block_rank(bool flag, int* s_w, int& chunk_total)
     return before + r;
 }
 
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) {   // one fixed contraction (shared by the masker heads of k_spatial_masker and k_plan: the same floats from the same means)
+    return fmaf(a[3], b[3], fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])));
+}
+
 // ---------------------------------------------------------------------------------------- a1
 // one wave per (image, patch); lanes stride over channels.
 __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict__ x, int B, int Hi, int Wi, int C,
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict_
             for (int o = 0; o < 8; ++o)
                 if (o < G2) {
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(w + o * C + c);
-                    acc[o] += wv[0] * s[0] + wv[1] * s[1] + wv[2] * s[2] + wv[3] * s[3];
+                    acc[o] += dot4(wv, s);
                 }
         }
     } else {
@@ -298,6 +302,231 @@ __global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ pa
             LDN_DCHECK(!inb || s_pos1[iy * g.Wi + ix] >= 0, 203);              // every in-bounds tap of an active pixel is in the dilated list
             nbr[(size_t)p * 9 + t] = inb ? s_pos1[iy * g.Wi + ix] : -1;
         }
+    }
+}
+
+// ---- round 4: decision + counts + prefix over the images + lists in ONE launch (k_plan) -------------------------------------------
+// k_mask_count + k_mask_index were two launches because image b's first packed position is the sum of the counts of the images in
+// front of it.  Here workgroup b publishes its three counts (+ 1, so that 0 means "not yet") and waits for the counts of the
+// workgroups in front of it, which were dispatched before it; the waiting loop is bounded (a failed wait leaves the lists
+// unwritten and the counts 0, never a hang).
+// Two extras of the fused spatial path (models/utils.py:47-65 behind conv3's epilogue):
+//   * decide mode (patch == nullptr): the patch decisions come from the POOLED CHANNEL MEANS [B][S*Sx][C] (the stand-alone masker's
+//     `pool_work`, refreshed by the previous block's conv3 epilogue) -- k_spatial_masker's head, same arithmetic, no read of x;
+//   * patch_major: idx3 lists the kept pixels patch by patch (row-major inside a patch) instead of row-major over the image, so
+//     that the rows of one patch are contiguous in the packed tensors (conv3's epilogue then owns whole patches).  Same SET of
+//     pixels, same counts / prefixes / statistics; pos3 / nbr follow the order.  Even grids only (Ho % S == 0, Wo % Sx == 0).
+struct PlanArgs {
+    IdxGeom g;
+    int patch_major;
+    const float* patch;
+    const float* pool; int C; const float* w; const float* bias; float* mask_out; float* logits;
+    int32_t* sync;                 // [1 + 3 B], zeroed in front of the launch: (unused word); per image count3 + 1, count1 + 1, patches + 1
+    int32_t *idx3, *pos3, *idx1, *pos1, *nbr, *cnt, *pre3, *pre1;
+    float* stats;
+};
+
+// (the flags are read and written with relaxed agent-scope atomics: the flag IS the payload, nothing else is published through it --
+// an acquire load per poll would invalidate the L2 under the workgroups that are still computing)
+__device__ __forceinline__ int wave_isum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// i / d for 0 <= i < 2^22 through the float reciprocal, corrected to the exact quotient
+__device__ __forceinline__ int idiv(int i, int d, float inv) {
+    int q = (int)(((float)i + 0.5f) * inv);
+    const int r = i - q * d;
+    q += r >= d ? 1 : (r < 0 ? -1 : 0);
+    return q;
+}
+
+__global__ __launch_bounds__(256) void k_zero_i32(int32_t* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+constexpr int kPlanThreads = 512;
+__global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
+    constexpr int NT = kPlanThreads, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_bytes[];
+    const IdxGeom g = a.g;
+    const int HWo = g.Ho * g.Wo, HWi = g.Hi * g.Wi, SS = g.S * g.Sx;
+    int* s_pos3 = reinterpret_cast<int*>(s_bytes);           // [HWo] pixel -> packed position or -1
+    int* s_pos1 = s_pos3 + HWo;                                // [HWi]
+    int* s_list = s_pos1 + HWi;                                // [HWo] k-th kept output pixel of this image
+    unsigned char* s_m3 = reinterpret_cast<unsigned char*>(s_list + HWo);   // [HWo]
+    unsigned char* s_m1 = s_m3 + HWo;                          // [HWi] dilated mask
+    unsigned char* s_patch = s_m1 + HWi;                       // [SS]
+    const float inv_wo = 1.f / (float)g.Wo, inv_wi = 1.f / (float)g.Wi;
+    __shared__ int s_w[NW];
+    __shared__ int s_red[3], s_base[3], s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // image = blockIdx.x: workgroups are dispatched in index order (per XCD), so the lowest unfinished image is always resident and
+    // waits on nothing unfinished -- progress by induction.  (A ticket from one atomic counter would make that independent of the
+    // dispatch order, but 256 device-scope atomics on one address serialise across the 8 XCDs: measured ~40 us per launch.)
+    if (tid == 0) s_fail = 0;
+    if (tid < 3) { s_red[tid] = 0; s_base[tid] = 0; }
+    __syncthreads();
+    const int b = blockIdx.x;
+
+    // 1. the patch decisions of this image
+    if (a.patch) {
+        for (int i = tid; i < SS; i += NT) s_patch[i] = a.patch[(size_t)b * SS + i] > 0.5f ? 1 : 0;
+    } else {
+        // a wave takes four patches at a time: their rows are in flight together (one patch after the other is one memory latency per
+        // patch and wave: 25 patches x ~2 us at stage 1); per patch the arithmetic order is k_spatial_masker's
+        const float b0 = a.bias[0], b1 = a.bias[1];
+        for (int p0 = wave * 4; p0 < SS; p0 += NW * 4) {
+            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = lane * 4; c < a.C; c += 256) {
+                f32x4 sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    sv[u] = p0 + u < SS ? *reinterpret_cast<const f32x4*>(a.pool + ((size_t)b * SS + p0 + u) * a.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.w + c), w1 = *reinterpret_cast<const f32x4*>(a.w + a.C + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a0[u] += dot4(w0, sv[u]); a1[u] += dot4(w1, sv[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float lk = wave_sum(a0[u]) + b0, ld = wave_sum(a1[u]) + b1;
+                const int pp = p0 + u;
+                if (lane == 0 && pp < SS) {
+                    const bool keep = lk >= ld;                  // ties keep (utils.py:60)
+                    s_patch[pp] = keep ? 1 : 0;
+                    a.mask_out[(size_t)b * SS + pp] = keep ? 1.f : 0.f;
+                    if (a.logits) {
+                        a.logits[((size_t)b * 2) * SS + pp] = lk;
+                        a.logits[((size_t)b * 2 + 1) * SS + pp] = ld;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 2. mask3 (nearest interpolation of the patch decisions), the three counts of this image
+    {
+        const float sh = (float)g.S / (float)g.Ho, sw = (float)g.Sx / (float)g.Wo;
+        for (int i = tid; i < HWo; i += NT) {
+            const int y = idiv(i, g.Wo, inv_wo), x = i - y * g.Wo;
+            s_m3[i] = s_patch[nearest_src(y, sh, g.S) * g.Sx + nearest_src(x, sw, g.Sx)];
+        }
+    }
+    __syncthreads();
+    {
+        int c3 = 0, c1 = 0, cp = 0;
+        for (int i = tid; i < HWo; i += NT) c3 += s_m3[i];
+        for (int i = tid; i < HWi; i += NT) {
+            const int iy = idiv(i, g.Wi, inv_wi), ix = i - iy * g.Wi;
+            const unsigned char f = mask1_at(s_m3, g, iy, ix) ? 1 : 0;
+            s_m1[i] = f;                                         // (the compaction pass reads the byte instead of dilating again)
+            c1 += f;
+        }
+        for (int i = tid; i < SS; i += NT) cp += s_patch[i];
+        c3 = wave_isum(c3); c1 = wave_isum(c1); cp = wave_isum(cp);
+        if (lane == 0) {            // one integer LDS atomic per wave (all lanes on one address serialise): order-independent
+            atomicAdd(&s_red[0], c3);
+            atomicAdd(&s_red[1], c1);
+            atomicAdd(&s_red[2], cp);
+        }
+    }
+    __syncthreads();
+    if (tid < 3) __hip_atomic_store(&a.sync[1 + tid * g.B + b], s_red[tid] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // 3. exclusive prefix over the images in front of this one
+    {
+        int a3 = 0, a1 = 0, ap = 0, failed = 0;
+        for (int i = tid; i < b; i += NT) {
+            int v3, v1, vp, n = 0;
+            for (;;) {             // the three loads are in flight together (each is a trip to the coherence point)
+                v3 = __hip_atomic_load(&a.sync[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v1 = __hip_atomic_load(&a.sync[1 + g.B + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vp = __hip_atomic_load(&a.sync[1 + 2 * g.B + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v3 != 0 && v1 != 0 && vp != 0) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (++n > (1 << 18)) { failed = 1; v3 = v1 = vp = 1; break; }
+            }
+            a3 += v3 - 1; a1 += v1 - 1; ap += vp - 1;
+        }
+        if (failed) s_fail = 1;
+        a3 = wave_isum(a3); a1 = wave_isum(a1); ap = wave_isum(ap);
+        if (lane == 0) {
+            atomicAdd(&s_base[0], a3);
+            atomicAdd(&s_base[1], a1);
+            atomicAdd(&s_base[2], ap);
+        }
+    }
+    __syncthreads();
+    if (s_fail) {                   // (never observed: a predecessor that did not publish within ~1 s) no list is written, the counts read 0
+        if (tid == 0) { a.cnt[0] = 0; a.cnt[1] = 0; }
+        return;
+    }
+    const int base3 = s_base[0], base1 = s_base[1], own3 = s_red[0];
+    if (tid == 0) {
+        a.pre3[b] = base3;
+        a.pre1[b] = base1;
+        if (b == g.B - 1) {
+            const int tot3 = base3 + own3, tot1 = base1 + s_red[1];
+            a.pre3[g.B] = tot3;
+            a.pre1[g.B] = tot1;
+            a.cnt[0] = tot3;
+            a.cnt[1] = tot1;
+            a.stats[0] = (float)(s_base[2] + s_red[2]) / (float)((long)g.B * SS);
+            a.stats[1] = (float)tot3 / (float)((long)g.B * HWo);
+            a.stats[2] = (float)tot1 / (float)((long)g.B * HWi);
+        }
+    }
+    // 4. ordered compaction of the kept output pixels (row-major, or patch by patch) and of the dilated input pixels
+    const int gy = g.Ho / g.S, gx = g.Wo / g.Sx, PP = gy * gx;
+    const float inv_pp = 1.f / (float)max(PP, 1), inv_sx = 1.f / (float)g.Sx, inv_gx = 1.f / (float)max(gx, 1);
+    int running = 0;
+    for (int i0 = 0; i0 < HWo; i0 += NT) {
+        const int e = i0 + tid;
+        int i = e;
+        if (a.patch_major && e < HWo) {
+            const int q = idiv(e, PP, inv_pp), l = e - q * PP;
+            const int py = idiv(q, g.Sx, inv_sx), px = q - py * g.Sx, ly = idiv(l, gx, inv_gx), lx = l - ly * gx;
+            i = (py * gy + ly) * g.Wo + px * gx + lx;
+        }
+        const bool f = e < HWo && s_m3[i];
+        int tot;
+        const int r = block_rank_n<NW>(f, s_w, tot);
+        if (e < HWo) {
+            s_pos3[i] = f ? base3 + running + r : -1;
+            if (f) s_list[running + r] = i;
+        }
+        running += tot;
+    }
+    running = 0;
+    for (int i0 = 0; i0 < HWi; i0 += NT) {
+        const int i = i0 + tid;
+        const bool f = i < HWi && s_m1[i];
+        int tot;
+        const int r = block_rank_n<NW>(f, s_w, tot);
+        if (i < HWi) {
+            const int p = f ? base1 + running + r : -1;
+            s_pos1[i] = p;
+            a.pos1[(size_t)b * HWi + i] = p;
+            LDN_DCHECK(!f || (p >= 0 && p < g.B * HWi), 202);
+            if (f) a.idx1[p] = b * HWi + i;
+        }
+        running += tot;
+    }
+    __syncthreads();
+    // 5. the lists, in packed order (coalesced; no thread idles on a dropped pixel)
+    for (int i = tid; i < HWo; i += NT) a.pos3[(size_t)b * HWo + i] = s_pos3[i];
+    for (int k = tid; k < own3; k += NT) {
+        LDN_DCHECK(base3 + k < g.B * HWo, 201);
+        a.idx3[base3 + k] = b * HWo + s_list[k];
+    }
+    for (int e = tid; e < own3 * 9; e += NT) {
+        const int k = e / 9, t = e - 9 * k;
+        const int i = s_list[k];
+        const int oy = idiv(i, g.Wo, inv_wo), ox = i - oy * g.Wo;
+        const int iy = oy * g.stride - 1 + t / 3, ix = ox * g.stride - 1 + t % 3;
+        const bool inb = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+        LDN_DCHECK(!inb || s_pos1[iy * g.Wi + ix] >= 0, 203);
+        a.nbr[(size_t)base3 * 9 + e] = inb ? s_pos1[iy * g.Wi + ix] : -1;
     }
 }
 
@@ -768,7 +997,7 @@ extern "C" size_t ldn_mask_to_index_workspace_bytes(int B, int Ho, int Wo, int s
     size_t lds = 0;
     const size_t whole = (size_t)Ho * Wo * 5 + (size_t)Ho * stride * Wo * stride * 4;
     if ((whole > kWholeImageLds || getenv("LDN_INDEX_BANDS")) && !index_bands(Ho, Wo, stride, &R, &nb, &lds)) nb = 1;
-    return (size_t)3 * B * nb * sizeof(int32_t);
+    return ((size_t)3 * B * nb + 4) * sizeof(int32_t);     // (+ a spare word: the flag array of the one-launch build, k_plan, starts at work[1])
 }
 extern "C" size_t ldn_channel_masker_workspace_bytes(int B, int HW, int C) {
     return (size_t)B * ldn_channel_masker_splits(HW) * C * sizeof(float);
@@ -810,6 +1039,46 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
     return LDN_OK;
 }
 
+// one launch (k_plan): patch decisions (given, or taken from pooled channel means) -> counts, prefixes, lists
+static size_t plan_lds(int S, int Sx, int Ho, int Wo, int stride) {
+    return (size_t)Ho * Wo * 9 + (size_t)Ho * stride * Wo * stride * 5 + (size_t)round_up(S * Sx, 16);
+}
+static int launch_plan(PlanArgs& a, int32_t* work, hipStream_t st) {
+    const IdxGeom& g = a.g;
+    const size_t lds = plan_lds(g.S, g.Sx, g.Ho, g.Wo, g.stride);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_plan), lds), "k_plan: cannot reserve %zu B of LDS", lds);
+    a.sync = work;
+    // the flag words are zeroed by a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph faulted on the second replay
+    // of the graph (ROCm 7.2, measured: tools/experiments/repro_graph.py), a kernel node replays fine
+    const int nsync = 3 * g.B + 1;
+    hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)ceil_div(nsync, 256)), dim3(256), 0, st, work, nsync);
+    LDN_CHECK_LAUNCH("k_zero_i32");
+    hipLaunchKernelGGL(k_plan, dim3((unsigned)g.B), dim3(kPlanThreads), lds, st, a);
+    LDN_CHECK_LAUNCH("k_plan");
+    return LDN_OK;
+}
+
+extern "C" int ldn_mask_plan_fits(int S, int Sx, int Ho, int Wo, int stride) {
+    return S > 0 && Sx > 0 && Ho > 0 && Wo > 0 && stride >= 1 && plan_lds(S, Sx, Ho, Wo, stride) <= kWholeImageLds ? 1 : 0;
+}
+
+extern "C" int ldn_mask_plan(const float* patch_mask, const float* pool, int C, const float* w, const float* bias, float* mask_out,
+                             float* logits, int B, int S, int Sx, int Ho, int Wo, int stride, int patch_major, int32_t* idx3,
+                             int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt, int32_t* img_prefix3,
+                             int32_t* img_prefix1, float* stats, int32_t* work, void* stream) {
+    LDN_REQUIRE(idx3 && pos3 && idx1 && pos1 && nbr && cnt && img_prefix3 && img_prefix1 && stats && work, "ldn_mask_plan: null pointer");
+    LDN_REQUIRE(B > 0 && S > 0 && Sx > 0 && Ho > 0 && Wo > 0 && stride >= 1, "ldn_mask_plan: bad shape");
+    LDN_REQUIRE((long)B * Ho * stride * Wo * stride < (1l << 31), "ldn_mask_plan: index space exceeds int32");
+    LDN_REQUIRE(patch_mask || (pool && w && bias && mask_out && C > 0 && C % 4 == 0),
+                "ldn_mask_plan: either the patch mask, or pooled means + masker weights (C a multiple of 4) + the mask output");
+    LDN_REQUIRE(patch_mask || ((uintptr_t)pool % 16 == 0 && (uintptr_t)w % 16 == 0), "ldn_mask_plan: pool / w must be 16-byte aligned");
+    LDN_REQUIRE(!patch_major || (Ho % S == 0 && Wo % Sx == 0), "ldn_mask_plan: patch-major lists need an even grid (%dx%d map, %dx%d patches)", Ho, Wo, S, Sx);
+    LDN_REQUIRE(ldn_mask_plan_fits(S, Sx, Ho, Wo, stride), "ldn_mask_plan: the per-image tables of a %dx%d map exceed one workgroup's LDS (use ldn_mask_to_index)", Ho * stride, Wo * stride);
+    PlanArgs a{IdxGeom{B, S, Sx, Ho, Wo, stride, Ho * stride, Wo * stride}, patch_major ? 1 : 0, patch_mask, pool, C, w, bias, mask_out, logits,
+               nullptr, idx3, pos3, idx1, pos1, nbr, cnt, img_prefix3, img_prefix1, stats};
+    return launch_plan(a, work, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, int Ho, int Wo, int stride, int32_t* idx3,
                                  int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
                                  int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work,
@@ -827,6 +1096,13 @@ extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, 
                            img_prefix3, img_prefix1, stats);
         LDN_CHECK_LAUNCH("k_layer_index");
         return LDN_OK;
+    }
+    const char* plan_env = getenv("LDN_INDEX_PLAN");                 // "0": the two-launch build (A/B, tests); read per call
+    const bool use_plan = !(plan_env && atoi(plan_env) == 0);
+    if (use_plan && !getenv("LDN_INDEX_BANDS") && ldn_mask_plan_fits(S, Sx, Ho, Wo, stride)) {   // whole image in one workgroup's LDS: one launch
+        PlanArgs a{g, 0, patch_mask, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, idx3, pos3, idx1, pos1, nbr, cnt,
+                   img_prefix3, img_prefix1, stats};
+        return launch_plan(a, work, st);
     }
     const size_t lds1 = (size_t)Ho * Wo;
     const size_t lds2 = (size_t)Ho * Wo * 5 + (size_t)g.Hi * g.Wi * 4;

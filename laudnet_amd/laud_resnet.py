@@ -162,6 +162,23 @@ class Masker_spatial(_PrepCache):
         out = (mask, mask.mean(), self.flops_for(x))
         return out + (logits,) if want_logits else out
 
+    def _wb(self):
+        if not self._cache_valid():
+            with torch.no_grad():
+                self._cache_store((self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1).float().contiguous(),
+                                   self.conv.bias.detach().float().contiguous()))
+        return self._prep
+
+    def decide_from_means(self, work, x_shape, out_hw, patch_major):
+        """The decision AND the packed lists of the block in one launch, from the pooled patch means the previous block's conv3
+        left in `work` (ldn_mask_plan; models/utils.py:47-65 without reading x).  Returns (mask [B,1,S,S], IndexSet)."""
+        B, C, H, W = x_shape
+        S = self.mask_size
+        w, b = self._wb()
+        mask, _, ix = ops.mask_plan(work.view(B, S, S, C), w, b, out_hw[0], out_hw[1], 1, patch_major=patch_major)
+        self.last_work = work
+        return mask, ix
+
     def decide(self, x, carry=None):
         """The mask alone (what the blocks of the HIP path consume; their sparsities come from ldn_mask_to_index): forward()
         without the mean over the mask, a reduction launch per block."""
@@ -656,6 +673,18 @@ class Bottleneck(_PrepCache):
         self.last_channel_cnt = cnt         # [B] active channels per image: mean(mask) = cnt.sum() / (B * width)
         return ops.from_nhwc(out), mask
 
+    use_fused_spatial_masker = os.environ.get("LDN_FUSED_SPATIAL_MASKER", "1") != "0"   # class-level switch (A/B, tests)
+
+    def _pool_eligible(self, Hi, Wi, Ho, Wo, cout):
+        """An identity spatial block of ONE mask group on an even patch grid of 4- or 16-pixel patches, on the k_dense path, with
+        in-place residual (the pixels it does not touch keep their values: their patches' means stay valid)."""
+        ms = self.masker_spatial
+        S = ms.mask_size
+        return (self.use_fused_spatial_masker and ms.mask_channel_group == 1 and self.forced_spatial_mask is None
+                and self.downsample is None and self.stride == 1 and self._inplace and 1 < S < Hi and Hi % S == 0 and Wi % S == 0
+                and (Hi // S) * (Wi // S) in (4, 16) and cout % 128 == 0 and ops.dense_kernel_ok()
+                and ops.mask_plan_fits(S, S, Ho, Wo, 1))
+
     def _run_spatial(self, x, p):
         B, Cin, Hi, Wi = x.shape
         W = self.width
@@ -664,8 +693,17 @@ class Bottleneck(_PrepCache):
         G = ms.mask_channel_group
         xn = ops.as_nhwc(x)
         carry_in, self._carry_in, self.last_carry = getattr(self, "_carry_in", None), None, None
+        # the fused spatial masker: an identity block whose successor decides on the same patch grid leaves the pooled
+        # means of the patches it rewrites in conv3's epilogue (pool_out: its lists are then patch-major); the successor decides and
+        # builds its lists from those means in ONE launch (ldn_mask_plan) -- no pass over x, no count launch
+        pool_out = bool(getattr(self, "_pool_next", False)) and self._pool_eligible(Hi, Wi, Ho, Wo, p["w3"].shape[0])
+        self._pool_next = False
+        ix = None
         if self.forced_spatial_mask is not None:
             patch = self.forced_spatial_mask.to(device=x.device, dtype=torch.float32).contiguous()
+        elif (carry_in is not None and len(carry_in) > 4 and carry_in[4] and carry_in[0] is not None
+              and tuple(carry_in[2] or ()) == (B, Hi, Wi, Cin, ms.mask_size) and self._pool_eligible(Hi, Wi, Ho, Wo, p["w3"].shape[0])):
+            patch, ix = ms.decide_from_means(carry_in[0], x.shape, (Ho, Wo), pool_out)
         else:
             patch = ms.decide(x, carry=carry_in)
         dev = x.device
@@ -673,13 +711,17 @@ class Bottleneck(_PrepCache):
         # ExpandMask ORs the groups (its dilation kernel is [g,g,k,k] ones), so conv1 / conv2 -- and the sparsities the
         # reference reports for them -- live on the UNION of the groups; only conv3's scatter is per group.
         union = patch[:, 0] if G == 1 else patch.amax(dim=1)
-        ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride)
+        if ix is None:
+            ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride, patch_major=pool_out)
+        pool = None
         if self.forced_spatial_mask is None and getattr(ms, "last_work", None) is not None:
             key = getattr(ms.last_work, "ldn_shape_key", None)
             if ms.mask_size == 1 and G == 1:
                 self.last_carry = (ms.last_work, ix.pre3, key)      # layer skip: which images this block leaves unchanged, and their channel sums
             elif ms.mask_size > 1:
-                self.last_carry = (ms.last_work, None, key, union.contiguous())   # patch masks: the patches this block touches, and every patch's pooled means
+                # patch masks: the patches this block touches, and every patch's pooled means; [4]: conv3 below refreshes the touched ones
+                pool = ms.last_work.view(B, ms.mask_size, ms.mask_size, Cin) if (pool_out and ix.patch_major) else None
+                self.last_carry = (ms.last_work, None, key, union.contiguous(), pool is not None)
         x2d = xn.reshape(B * Hi * Wi, Cin)
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
         ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
@@ -711,7 +753,8 @@ class Bottleneck(_PrepCache):
             resid, out2d = x2d, torch.relu(x2d)
         for ig, rows, cs in groups:
             ops.conv_rows(h2, p["w3"][cs], None, p["t3"][cs], out2d[:, cs], a_rows=rows, taps=1, m_count=ig.cnt[0:1],
-                          m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs])
+                          m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs], pool=pool,
+                          pool_grid=(ms.mask_size, ms.mask_size, Ho, Wo) if pool is not None else None)
         self.last_spatial_mask = patch
         if G > 1:   # sparsity of conv3 = mean over ALL group masks (Masker_spatial, utils.py:61); conv2 / conv1 = the union's
             ix.stats = torch.cat((patch.mean().reshape(1), ix.stats[1:]))
@@ -1025,6 +1068,10 @@ class ResNet(nn.Module):
                                                  # shortcut / stride 2 turns them into relu(downsample(x))
                                                  and prev.stride == 1 and prev.downsample is None
                                                  and getattr(prev, "_carry_step", -1) == step_id) else None)
+            blk._pool_next = (self.use_layer_carry and nxt is not None and blk.dyn_mode == "spatial" and nxt.dyn_mode == "spatial"
+                              and nxt.stride == 1 and nxt.downsample is None and nxt.forced_spatial_mask is None
+                              and nxt.masker_spatial.mask_size == blk.masker_spatial.mask_size
+                              and nxt.masker_spatial.mask_channel_group == 1)
             x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap, defer_stats=True, inplace=self.inplace_residual)
             blk._carry_step = step_id if getattr(blk, "last_carry", None) is not None else -1
             gap = getattr(blk, "last_gap", None) if want_gap else None

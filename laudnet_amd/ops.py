@@ -135,16 +135,11 @@ class IndexSet:
     stats: torch.Tensor    # [3] = {mean patch mask, mean mask2, mean mask1}
     cap3: int
     cap1: int
+    patch_major: bool = False     # idx3 lists the kept pixels patch by patch (ldn_mask_plan): whole patches are consecutive packed rows
 
 
-def mask_to_index(patch_mask, out_h, out_w, stride):
-    """patch_mask [B,Sy,Sx] float {0,1} -> packed index lists (see ldn_mask_to_index)."""
-    L.require_device(patch_mask)
+def _empty_index(B, out_h, out_w, stride, dev):
     lib = L.load()
-    if patch_mask.dim() != 3:
-        raise L.LdnError("mask_to_index: patch_mask must be [B,Sy,Sx]")
-    B, S, Sx = patch_mask.shape
-    dev = patch_mask.device
     cap3, cap1 = B * out_h * out_w, B * out_h * stride * out_w * stride
     i32 = dict(device=dev, dtype=torch.int32)
     ix = IndexSet(idx3=torch.empty(cap3, **i32), pos3=torch.empty(cap3, **i32), idx1=torch.empty(cap1, **i32),
@@ -152,11 +147,56 @@ def mask_to_index(patch_mask, out_h, out_w, stride):
                   pre3=torch.empty(B + 1, **i32), pre1=torch.empty(B + 1, **i32),
                   stats=torch.empty(3, device=dev, dtype=torch.float32), cap3=cap3, cap1=cap1)
     work = torch.empty(max(lib.ldn_mask_to_index_workspace_bytes(B, out_h, out_w, stride) // 4, 1), **i32)
+    return ix, work
+
+
+def mask_plan_fits(S, Sx, out_h, out_w, stride=1):
+    """Whether the one-launch list build (ldn_mask_plan) holds a map of this size (per-image tables in one workgroup's LDS)."""
+    return bool(L.load().ldn_mask_plan_fits(S, Sx, out_h, out_w, stride))
+
+
+def mask_to_index(patch_mask, out_h, out_w, stride, patch_major=False):
+    """patch_mask [B,Sy,Sx] float {0,1} -> packed index lists (see ldn_mask_to_index).  patch_major: the kept pixels patch by
+    patch instead of row-major over the image (ldn_mask_plan; even grids, maps that fit one workgroup's tables)."""
+    L.require_device(patch_mask)
+    lib = L.load()
+    if patch_mask.dim() != 3:
+        raise L.LdnError("mask_to_index: patch_mask must be [B,Sy,Sx]")
+    B, S, Sx = patch_mask.shape
+    ix, work = _empty_index(B, out_h, out_w, stride, patch_mask.device)
+    if patch_major:
+        ix.patch_major = True
+        L.check(lib.ldn_mask_plan(L.ptr(_f32c(patch_mask, "patch_mask")), None, 0, None, None, None, None, B, S, Sx, out_h, out_w,
+                                  stride, 1, L.ptr(ix.idx3), L.ptr(ix.pos3), L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr),
+                                  L.ptr(ix.cnt), L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr()),
+                "ldn_mask_plan")
+        return ix
     L.check(lib.ldn_mask_to_index(L.ptr(_f32c(patch_mask, "patch_mask")), B, S, Sx, out_h, out_w, stride, L.ptr(ix.idx3),
                                   L.ptr(ix.pos3), L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr), L.ptr(ix.cnt),
                                   L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr()),
             "ldn_mask_to_index")
     return ix
+
+
+def mask_plan(pool, weight, bias, out_h, out_w, stride=1, patch_major=True, want_logits=False):
+    """The fused spatial masker + list build of a block whose input's pooled patch means are already known (ldn_mask_plan, decide
+    mode): pool [B,S,Sx,C] (the `work` of spatial_masker, refreshed by the previous block's conv_rows(..., pool=...)), weight [2,C],
+    bias [2] (one mask group).  Returns (mask [B,1,S,Sx], logits [B,2,S,Sx] or None, IndexSet); x is not read."""
+    L.require_device(pool, weight, bias)
+    lib = L.load()
+    if pool.dim() != 4 or tuple(weight.shape) != (2, pool.shape[3]) or bias.numel() != 2:
+        raise L.LdnError("mask_plan: pool must be [B,S,Sx,C], weight [2,C], bias [2] (one mask group)")
+    B, S, Sx, C = pool.shape
+    dev = pool.device
+    ix, work = _empty_index(B, out_h, out_w, stride, dev)
+    ix.patch_major = bool(patch_major)
+    mask = torch.empty(B, 1, S, Sx, device=dev, dtype=torch.float32)
+    logits = torch.empty(B, 2, S, Sx, device=dev, dtype=torch.float32) if want_logits else None
+    L.check(lib.ldn_mask_plan(None, L.ptr(_f32c(pool, "pool")), C, L.ptr(_f32c(weight, "w")), L.ptr(_f32c(bias, "bias")), L.ptr(mask),
+                              L.ptr(logits), B, S, Sx, out_h, out_w, stride, 1 if patch_major else 0, L.ptr(ix.idx3), L.ptr(ix.pos3),
+                              L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr), L.ptr(ix.cnt), L.ptr(ix.pre3), L.ptr(ix.pre1),
+                              L.ptr(ix.stats), L.ptr(work), L.stream_ptr()), "ldn_mask_plan")
+    return mask, logits, ix
 
 
 # ---------------------------------------------------------------------------------------- K2/K5
@@ -268,7 +308,7 @@ def row_stats(x2d, eps=1e-5):
 
 def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None, m_cap=None, relu=1,
               relu_if_neg=None, out_rows=None, residual2d=None, math=None, post_sub=None, chan_mask=None, rows_per_image=0,
-              pix_map=None, geom=None, ln_stats=None, ln_c1=None):
+              pix_map=None, geom=None, ln_stats=None, ln_c1=None, pool=None, pool_grid=None):
     """Packed-row convolution (see ldn_conv_rows).  a2d [rows,lda>=cin]; w [cout,taps,cin]; out2d [rows,ldo].
     In bf16x3 mode the 1x1 form runs on k_dense (ldn_conv_rows_split) with a cached pre-split copy of the weights;
     post_sub / chan_mask (dense execution of channel mode) exist on that kernel only."""
@@ -291,6 +331,21 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
     classes = 1 if shift.dim() == 1 else shift.shape[0]
     if (post_sub is not None or chan_mask is not None or classes != 1 or relu == 3 or ln_stats is not None) and not dense_ok:
         raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table / the GELU and LayerNorm epilogues need the k_dense path (cin % 8 == 0, cout % 4 == 0)")
+    if pool is not None:
+        # the pooled patch means of the output as a by-product (ldn_conv_rows_pool): pool [B,S,Sx,cout], pool_grid = (S, Sx, Ho, Wo);
+        # the packed rows list whole patches (IndexSet.patch_major)
+        if not dense_ok or taps != 1 or post_sub is not None or chan_mask is not None or ln_stats is not None or classes != 1:
+            raise L.LdnError("conv_rows: pool= needs the 1x1 k_dense form without post_sub / chan_mask / LayerNorm terms")
+        S, Sx, ho, wo = pool_grid
+        wptr = split_rows_weight(w) if mode == "bf16x3" else _f32c(w, "w")
+        L.check(lib.ldn_conv_rows_pool(L.ptr(_f32rows(a2d, "a")), a2d.stride(0), L.ptr(_i32c(a_rows, "a_rows")),
+                                       L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(wptr), cin, cout, L.ptr(_f32c(scale, "scale")),
+                                       L.ptr(_f32c(shift, "shift")), relu, L.ptr(_i32c(relu_if_neg, "relu_if_neg")),
+                                       L.ptr(_i32c(out_rows, "out_rows")), L.ptr(_f32rows(residual2d, "residual")),
+                                       residual2d.stride(0) if residual2d is not None else 0, L.ptr(_f32rows(out2d, "out")),
+                                       out2d.stride(0), L.ptr(_f32c(pool, "pool")), S, Sx, ho, wo, 1 if mode == "bf16x3" else 0,
+                                       L.stream_ptr(out2d)), "ldn_conv_rows_pool")
+        return out2d
     if dense_ok:
         hi, wi, ho, wo, stride = geom if geom is not None else (0, 0, 0, 0, 1)
         fn, wptr = ((lib.ldn_conv_rows_split, split_rows_weight(w)) if mode == "bf16x3" else (lib.ldn_conv_rows_f32, _f32c(w, "w")))

@@ -77,7 +77,8 @@ def test_workspace_twins_without_gpu():
     assert lib.ldn_spatial_masker_workspace_bytes(4, 56, 56, 64, 14) == 4 * 14 * 14 * 64 * 4    # pooled to 14x14: the patches' pooled means (patch carry)
     assert lib.ldn_spatial_masker_workspace_bytes(4, 56, 56, 64, 56) == 0          # one logit per pixel: no scratch
     assert lib.ldn_spatial_masker_workspace_bytes(4, 56, 56, 64, 1) == 4 * splits * 64 * 4
-    assert lib.ldn_mask_to_index_workspace_bytes(256, 14, 14, 1) == 3 * 256 * 4
+    assert lib.ldn_mask_to_index_workspace_bytes(256, 14, 14, 1) == (3 * 256 + 4) * 4   # three counts per image (+ a spare word) for the one-launch build
+    assert lib.ldn_mask_plan_fits(14, 14, 56, 56, 1) == 1 and lib.ldn_mask_plan_fits(25, 25, 200, 304, 1) == 0
     assert lib.ldn_mask_to_index_workspace_bytes(2, 200, 304, 1) > 3 * 2 * 4          # banded build: one entry per (image, band)
     assert lib.ldn_se_packed_workspace_bytes(8, 320, 196) == 8 * (lib.ldn_channel_masker_splits(196) + 1) * 320 * 4
 

@@ -401,7 +401,7 @@ def test_patch_carry_is_bit_identical(gran, groups):
             assert torch.equal(a, b)
         assert 0.05 < float(torch.cat(outs[0][1]).mean()) < 0.95      # some patches dropped, some kept: the carry was exercised
         blk = m.layer3[2]
-        assert blk.last_carry is not None and len(blk.last_carry) == 4 and blk.last_carry[3].shape[0] == 6
+        assert blk.last_carry is not None and len(blk.last_carry) == 5 and blk.last_carry[3].shape[0] == 6
     finally:
         ops.set_math_mode("fp32")
 

@@ -111,6 +111,15 @@ size_t ldn_mask_to_index_workspace_bytes(int B, int Ho, int Wo, int stride);
  * counts and waits, bounded, for those of the workgroups dispatched in front of it);
  * ldn_mask_plan_fits says whether the per-image tables fit one workgroup's LDS (else: ldn_mask_to_index, which builds by bands).
  * work: int32 scratch of ldn_mask_to_index_workspace_bytes(B, Ho, Wo, stride). */
+/* Layer skip (mask_size 1, laud_resnet.py:91-94 / dyn_mode 'layer') on the same fusion: ldn_layer_index = the lists of
+ * ldn_mask_to_index for one decision per image (image_mask [B]), the kept images' pixels TILE BY TILE (tile_gy x tile_gx pixels
+ * each; 0, 0 = row-major) so that ldn_conv_rows_pool leaves every kept image's tile means; ldn_layer_head = the decision from those
+ * means (pool [B][nparts][C], nparts equal tiles per image: the global average pool is the mean of the tile means) -- x is not read. */
+int ldn_layer_index(const float* image_mask, int B, int Ho, int Wo, int stride, int tile_gy, int tile_gx, int32_t* idx3,
+                    int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt, int32_t* img_prefix3,
+                    int32_t* img_prefix1, float* stats, void* stream);
+int ldn_layer_head(const float* pool, int B, int nparts, int C, const float* w /*[2g,C]*/, const float* bias /*[2g]*/, int g,
+                   float* mask /*[B,g]*/, float* logits /*[B,2g] or NULL*/, void* stream);
 int ldn_mask_plan_fits(int S, int Sx, int Ho, int Wo, int stride);
 int ldn_mask_plan(const float* patch_mask, const float* pool, int C, const float* w, const float* bias, float* mask_out,
                   float* logits, int B, int S, int Sx, int Ho, int Wo, int stride, int patch_major, int32_t* idx3,

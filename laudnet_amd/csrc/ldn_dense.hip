@@ -76,7 +76,7 @@ __device__ __forceinline__ unsigned d_lds_off(const void* ptr) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)ptr;
 }
 
-constexpr int D_ROWS = 256;
+constexpr int D_ROWS_MAX = 256;
 constexpr int D_ROW_RELU = 1 << 30;
 
 // NSUB = n-subtiles of 32 columns per workgroup (2, 4, 8); D = ring depth (2 for NSUB 8, 3 otherwise)
@@ -86,12 +86,15 @@ constexpr int D_ROW_RELU = 1 << 30;
 // layouts coincide with the bf16x3 form: an element takes 4 bytes either way (bf16 hi + bf16 lo, or one float), so ws is then the plain
 // row-major fp32 weight matrix [cout][taps * cin] ([n][octet][8 floats]), the staging pipeline is the same, and a K16 step is eight
 // 32x32x2 instructions (instruction i pairs k-slot i of lane half 0 with k-slot i of lane half 1) instead of three 32x32x16 ones.
-template <int NSUB, bool T9, bool FULL, bool F32 = false>
-__global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
+// R: rows per workgroup -- 256 (eight waves), or 128 (four waves, ring depth 2: two workgroups per CU fit) for the launches whose grid
+// of 256-row tiles would leave CUs with one workgroup or none (the stage-3 3x3 of the spatial workload, stage 4)
+template <int NSUB, bool T9, bool FULL, bool F32 = false, int R = 256>
+__global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
     constexpr int NT = NSUB * 32;
-    constexpr int D = NSUB == 8 ? 2 : 3;
+    constexpr int D = (NSUB == 8 || R == 128) ? 2 : 3;
+    constexpr int D_ROWS = R, NTHR = 2 * R, WR = R / 4;     // WR: weight rows one DMA round of all waves covers (8 per wave)
     constexpr int SLOT = (D_ROWS + NT) * 128;
-    constexpr int NWI = (NT + 63) / 64;               // weight DMA instructions per wave and chunk (8 rows each) ...
+    constexpr int NWI = (NT + WR - 1) / WR;               // weight DMA instructions per wave and chunk (8 rows each) ...
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* const s_arow = reinterpret_cast<int*>(smem);            // [256] source row or -1
     int* const s_orow = s_arow + D_ROWS;                         // [256] destination row | D_ROW_RELU, or -1
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         if (T9) s_cls[tid] = cls;
     }
     if (T9)
-        for (int i = tid; i < D_ROWS * 9; i += 512) {
+        for (int i = tid; i < D_ROWS * 9; i += NTHR) {
             const int r = i / 9;
             s_atap[i] = r < rows ? p.a_rows[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
         }
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
     const int nchunks = (T9 ? 9 : 1) * cpt;
     const unsigned lds_ring = d_lds_off(s_ring);
     // ... of which this wave issues nwi: with NT = 160 (NSUB 5) the last instruction only exists for the waves whose 8 rows are inside the tile
-    const int nwi = (NT % 64 == 0 || (NWI - 1) * 64 + wave * 8 < NT) ? NWI : NWI - 1;
+    const int nwi = (NT % WR == 0 || (NWI - 1) * WR + wave * 8 < NT) ? NWI : NWI - 1;
     const int per_chunk = (active ? 4 : 0) + nwi;
     long asrc[4];                                                // this lane's four source rows (element offsets), -1 = zero row
 #pragma unroll
@@ -175,13 +178,13 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
             if (i >= nwi) break;
-            const int r = i * 64 + wave * 8 + (lane >> 3);
+            const int r = i * WR + wave * 8 + (lane >> 3);
             const int ls = (lane & 7) ^ ((r >> 1) & 7);
             const int n = n0 + r;
             const unsigned char* src = (r < NT && n < p.cout && ck * 8 + ls < p.cin / 4)
                                            ? p.ws + ((long)n * wrow + tap * (p.cin / 8) + ck * 4) * 32 + ls * 16
                                                                : reinterpret_cast<const unsigned char*>(g_dense_zero);
-            d_dma16(src, slot + (D_ROWS + i * 64 + wave * 8) * 128);      // (i < nwi: the wave's 8 rows are inside the tile)
+            d_dma16(src, slot + (D_ROWS + i * WR + wave * 8) * 128);      // (i < nwi: the wave's 8 rows are inside the tile)
         }
     };
     auto dma_dummy = [&](int c) {
@@ -208,11 +211,11 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
             if (real) dst = slot + (wave * 32 + k * 8) * 128;
         } else {
             const int i = k - 4;
-            const int r = i * 64 + wave * 8 + (lane >> 3);
+            const int r = i * WR + wave * 8 + (lane >> 3);
             const int ls = (lane & 7) ^ ((r >> 1) & 7);
             const int n = n0 + r;
             if (real && r < NT && n < p.cout && ck * 8 + ls < p.cin / 4) src = p.ws + ((long)n * wrow + tap * (p.cin / 8) + ck * 4) * 32 + ls * 16;
-            if (real && i * 64 + wave * 8 < NT) dst = slot + (D_ROWS + i * 64 + wave * 8) * 128;
+            if (real && i * WR + wave * 8 < NT) dst = slot + (D_ROWS + i * WR + wave * 8) * 128;
         }
         d_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
     };
@@ -434,28 +437,38 @@ __global__ __launch_bounds__(512, 2) void k_dense(const DenseArgs p) {
         }
         if constexpr (!T9 && FULL) {
             if (p.pool) {   // (wave-uniform) fixed-order sums over the rows of each patch: a register tree across the lanes that hold the patch
+                // cross-lane steps on the VALU (gfx950: v_permlane32_swap / v_permlane16_swap exchange half-waves / 16-lane rows of
+                // two registers, DPP row_ror:8 reaches lane ^ 8) -- no trip through the LDS crossbar; swap(a, b) leaves {a.lo, b.lo} and
+                // {a.hi, b.hi}: their sum is a's pair sum in the lower lanes and b's in the upper ones
+                // (inline asm: hipcc 7.2 folds the builtin's two results into one register when they are only added -- `v_add v0, v0, v0`
+                // behind the swap; the s_nop covers the VALU-write -> permlane-read wait states the compiler would insert)
+                auto swap32_sum = [](float a, float b) {
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+                    return a + b;
+                };
+                auto swap16_sum = [](float a, float b) {
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+                    return a + b;
+                };
+                auto ror8 = [](float a) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false)); };
                 f32x4 m;
                 if (p.pool_gy * p.pool_gx == 16) {
-                    const bool up = lane >= 32;
                     const f32x4 sa = xs4[0] + xs4[1], sb = xs4[2] + xs4[3];
-                    m = up ? sb : sa;
-                    const f32x4 give = up ? sa : sb;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) m[e] += __shfl_xor(give[e], 32, 64);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) m[e] += __shfl_xor(m[e], 16, 64);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) m[e] += __shfl_xor(m[e], 8, 64);
+                    for (int e = 0; e < 4; ++e) {
+                        float v = swap32_sum(sa[e], sb[e]);      // lanes 0-31: rows 0-15 (sa), lanes 32-63: rows 16-31 (sb)
+                        v = swap16_sum(v, v);                    // (by value: two registers -- the instruction exchanges rows BETWEEN its operands)
+                        m[e] = v + ror8(v);
+                    }
                     m *= 0.0625f;
                 } else {
-                    f32x4 k01 = pb3 ? xs4[1] : xs4[0], k23 = pb3 ? xs4[3] : xs4[2];
-                    const f32x4 g01 = pb3 ? xs4[0] : xs4[1], g23 = pb3 ? xs4[2] : xs4[3];
+                    const f32x4 k0 = pb3 ? xs4[1] : xs4[0], g0 = pb3 ? xs4[0] : xs4[1];
+                    const f32x4 k2 = pb3 ? xs4[3] : xs4[2], g2 = pb3 ? xs4[2] : xs4[3];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { k01[e] += __shfl_xor(g01[e], 8, 64); k23[e] += __shfl_xor(g23[e], 8, 64); }
-                    m = pb4 ? k23 : k01;
-                    const f32x4 gg = pb4 ? k01 : k23;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) m[e] += __shfl_xor(gg[e], 16, 64);
+                    for (int e = 0; e < 4; ++e) {
+                        const float k01 = k0[e] + ror8(g0[e]), k23 = k2[e] + ror8(g2[e]);
+                        m[e] = swap16_sum(k01, k23);             // even 16-lane rows: k01's pair sum, odd rows: k23's
+                    }
                     m *= 0.25f;
                 }
                 if (poff >= 0) *reinterpret_cast<f32x4*>(p.pool + poff + n0 + 32 * j + tc * 4) = m;
@@ -508,16 +521,16 @@ __global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, 
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_dense)
 
-template <int NSUB, bool T9, bool FULL, bool F32 = false>
+template <int NSUB, bool T9, bool FULL, bool F32 = false, int R = 256>
 static int launch_dense_f(DenseArgs& a, hipStream_t st) {
     constexpr int NT = NSUB * 32;
-    constexpr int D = NSUB == 8 ? 2 : 3;
-    const size_t lds = (size_t)(T9 ? 12 : 2) * D_ROWS * 4 + (size_t)D * (D_ROWS + NT) * 128;
+    constexpr int D = (NSUB == 8 || R == 128) ? 2 : 3;
+    const size_t lds = (size_t)(T9 ? 12 : 2) * R * 4 + (size_t)D * (R + NT) * 128;
     a.ntn = ceil_div(a.cout, NT);
-    a.mtn = ceil_div(a.m_cap, D_ROWS);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB, T9, FULL, F32>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
+    a.mtn = ceil_div(a.m_cap, R);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB, T9, FULL, F32, R>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
     const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
-    hipLaunchKernelGGL((k_dense<NSUB, T9, FULL, F32>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_dense<NSUB, T9, FULL, F32, R>), dim3(grid), dim3(2 * R), lds, st, a);
     LDN_CHECK_LAUNCH("k_dense");
     return LDN_OK;
 }
@@ -616,7 +629,7 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
                 stride, post_sub, chan_mask, rows_per_image > 0 ? rows_per_image : 1, 0, 0, ln_stats, ln_c1, pool, pool_gy, pool_gx, pool_Sx};
     hipStream_t st = static_cast<hipStream_t>(stream);
     // columns per workgroup: as wide as the layer allows (fewer passes over the activation rows) while the grid still fills the chip
-    const int mt = ceil_div(m_cap, D_ROWS);
+    const int mt = ceil_div(m_cap, D_ROWS_MAX);
     if (f32) {   // true-fp32 MFMA: the same tile rules (the matrix time per tile is 5.3x longer, the staging the same)
         if (taps == 9) return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true, true>(d, st) : launch_dense<2, true, true>(d, st);
         if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8, false, true>(d, st);
@@ -625,8 +638,18 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
         if (cout % 160 == 0 || (cout % 32 != 0 && cout > 128)) return launch_dense<5, false, true>(d, st);
         return launch_dense<4, false, true>(d, st);
     }
-    if (taps == 9) return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true>(d, st) : launch_dense<2, true>(d, st);
+    // 128-row tiles (four waves, two workgroups per CU) where the grid of 256-row tiles is at most one round of the chip's 512
+    // workgroup slots (the workgroups that survive the device-side row count sit alone on their CUs).  MEASURED SLOWER
+    // (round 4: channel 12.07 -> 12.30 ms, layer 12.92 -> 13.11, spatial 13.98 -> 14.28: a third more L2 -> LDS bytes per product
+    // outweighs the second resident workgroup), so it is off; LDN_DENSE_R128=1 (or a workgroup-count threshold) switches it on for A/B
+    static const int r128 = getenv("LDN_DENSE_R128") ? atoi(getenv("LDN_DENSE_R128")) : 0;
+    const bool small_grid = r128 && cout % 128 == 0 && (long)mt * (cout / 128) <= (r128 > 1 ? r128 : 512);
+    if (taps == 9) {
+        if (small_grid) return launch_dense_f<4, true, true, false, 128>(d, st);
+        return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true>(d, st) : launch_dense<2, true>(d, st);
+    }
     if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8, false>(d, st);
+    if (small_grid) return launch_dense_f<4, false, true, false, 128>(d, st);
     if (cout % 128 == 0) return launch_dense<4, false>(d, st);
     if (cout <= 64) return launch_dense<2, false>(d, st);
     // 160-column tiles: layers whose width is a multiple of 160 (320: two whole tiles instead of 128 + 128 + 64), and ragged widths

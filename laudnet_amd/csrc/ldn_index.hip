@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void k_layer_index(const float* __restrict__ p
                                                       int32_t* __restrict__ pos3, int32_t* __restrict__ idx1,
                                                       int32_t* __restrict__ pos1, int32_t* __restrict__ nbr,
                                                       int32_t* __restrict__ cnt, int32_t* __restrict__ pre3,
-                                                      int32_t* __restrict__ pre1, float* __restrict__ stats) {
+                                                      int32_t* __restrict__ pre1, float* __restrict__ stats, int tgy, int tgx) {
     __shared__ int s_cnt[2];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int HWo = g.Ho * g.Wo, HWi = g.Hi * g.Wi;
@@ -569,9 +569,19 @@ __global__ __launch_bounds__(256) void k_layer_index(const float* __restrict__ p
         }
     }
     const int step = gridDim.x * 256, first = blockIdx.x * 256 + tid;
+    // tgy > 0: the image's pixels tile by tile (tgy x tgx pixels, row-major inside a tile, tiles row-major) instead of row-major --
+    // tgy * tgx consecutive packed rows are then one tile (ldn_conv_rows_pool leaves the tiles' means: the fused layer masker)
+    const int PP = tgy * tgx, Tx = tgy ? g.Wo / tgx : 1;
+    auto pixel_of = [&](int i) {
+        if (!tgy) return i;
+        const int q = i / PP, l = i - q * PP;
+        const int ty = q / Tx, tx = q - ty * Tx, ly = l / tgx, lx = l - ly * tgx;
+        return (ty * tgy + ly) * g.Wo + tx * tgx + lx;
+    };
     for (int i = first; i < HWo; i += step) {
-        pos3[(size_t)b * HWo + i] = kept ? base3 + i : -1;
-        if (kept) idx3[base3 + i] = b * HWo + i;
+        const int pix = pixel_of(i);
+        pos3[(size_t)b * HWo + pix] = kept ? base3 + i : -1;
+        if (kept) idx3[base3 + i] = b * HWo + pix;
     }
     for (int i = first; i < HWi; i += step) {
         pos1[(size_t)b * HWi + i] = kept ? base1 + i : -1;
@@ -580,7 +590,8 @@ __global__ __launch_bounds__(256) void k_layer_index(const float* __restrict__ p
     if (!kept) return;
     for (int e = first; e < HWo * 9; e += step) {
         const int i = e / 9, t = e - 9 * i;
-        const int oy = i / g.Wo, ox = i - oy * g.Wo;
+        const int pix = pixel_of(i);
+        const int oy = pix / g.Wo, ox = pix - oy * g.Wo;
         const int iy = oy * g.stride - 1 + t / 3, ix = ox * g.stride - 1 + t % 3;
         const bool inb = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
         nbr[(size_t)base3 * 9 + e] = inb ? base1 + iy * g.Wi + ix : -1;
@@ -926,6 +937,70 @@ __global__ __launch_bounds__(256) void k_spatial_head(const float* __restrict__ 
     }
 }
 
+// The layer-skip decision from many equal tile means per image (ldn_layer_head): pool [B][nparts][C] -> mean over the parts -> 1x1 conv.
+// One workgroup per image; 16 bytes per lane, row lanes over the parts with eight loads in flight, fixed-order reductions.
+__global__ __launch_bounds__(256) void k_layer_head(const float* __restrict__ pool, int nparts, int C, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int g, float* __restrict__ mask,
+                                                     float* __restrict__ logits) {
+    __shared__ f32x4 s_part[256];
+    __shared__ float s_acc[4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int Q = C >> 2, G2 = 2 * g;
+    const int RL = Q >= 256 ? 1 : 256 / Q, rl = Q >= 256 ? 0 : tid / Q;
+    const float inv = 1.f / (float)nparts;
+    const float* pb = pool + (size_t)b * nparts * C;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    for (int q0 = 0; q0 < Q; q0 += 256) {
+        const int q = q0 + (Q >= 256 ? tid : tid % Q);
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        if (q < Q && rl < RL) {
+            const float* src = pb + q * 4;
+            int r = rl;
+            for (; r + 7 * RL < nparts; r += 8 * RL) {
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)(r + k * RL) * C);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += v[k];
+            }
+            for (; r < nparts; r += RL) sum += *reinterpret_cast<const f32x4*>(src + (size_t)r * C);
+        }
+        if (RL > 1) {
+            __syncthreads();
+            s_part[tid] = sum;
+            __syncthreads();
+            if (rl == 0)
+                for (int k = 1; k < RL; ++k) sum += s_part[k * Q + tid];
+        }
+        if (q < Q && rl == 0) {
+            sum *= inv;
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < G2) acc[o] += dot4(*reinterpret_cast<const f32x4*>(w + (size_t)o * C + q * 4), sum);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = wave_sum(acc[o]);
+    if (lane == 0) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) s_acc[wave][o] = acc[o];
+    }
+    __syncthreads();
+    if (tid < g) {
+        float sk = 0.f, sd = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) { sk += s_acc[wv][tid]; sd += s_acc[wv][tid + g]; }
+        const float lk = bias[tid] + sk, ld = bias[tid + g] + sd;
+        mask[(size_t)b * g + tid] = lk >= ld ? 1.f : 0.f;
+        if (logits) {
+            logits[(size_t)b * G2 + tid] = lk;
+            logits[(size_t)b * G2 + g + tid] = ld;
+        }
+    }
+}
+
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_index)
 
 }  // namespace ldn
@@ -1079,6 +1154,42 @@ extern "C" int ldn_mask_plan(const float* patch_mask, const float* pool, int C, 
     return launch_plan(a, work, static_cast<hipStream_t>(stream));
 }
 
+// layer skip (one decision per image) with the kept images' pixels listed TILE BY TILE (tile_gy x tile_gx pixels; 0, 0 = row-major,
+// i.e. ldn_mask_to_index with S = 1) -- the lists of the fused layer masker
+extern "C" int ldn_layer_index(const float* image_mask, int B, int Ho, int Wo, int stride, int tile_gy, int tile_gx, int32_t* idx3,
+                               int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt, int32_t* img_prefix3,
+                               int32_t* img_prefix1, float* stats, void* stream) {
+    LDN_REQUIRE(image_mask && idx3 && pos3 && idx1 && pos1 && nbr && cnt && img_prefix3 && img_prefix1 && stats, "ldn_layer_index: null pointer");
+    LDN_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && stride >= 1, "ldn_layer_index: bad shape");
+    LDN_REQUIRE((long)B * Ho * stride * Wo * stride < (1l << 31), "ldn_layer_index: index space exceeds int32");
+    LDN_REQUIRE((tile_gy == 0 && tile_gx == 0) || (tile_gy > 0 && tile_gx > 0 && Ho % tile_gy == 0 && Wo % tile_gx == 0),
+                "ldn_layer_index: the %dx%d map must split evenly into %dx%d tiles", Ho, Wo, tile_gy, tile_gx);
+    IdxGeom g{B, 1, 1, Ho, Wo, stride, Ho * stride, Wo * stride};
+    const long items = (long)Ho * Wo * 9 > (long)g.Hi * g.Wi ? (long)Ho * Wo * 9 : (long)g.Hi * g.Wi;
+    const unsigned chunks = (unsigned)(items / 2048 < 1 ? 1 : (items / 2048 > 32 ? 32 : items / 2048));
+    hipLaunchKernelGGL(k_layer_index, dim3(chunks, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), image_mask, g, idx3, pos3,
+                       idx1, pos1, nbr, cnt, img_prefix3, img_prefix1, stats, tile_gy, tile_gx);
+    LDN_CHECK_LAUNCH("k_layer_index");
+    return LDN_OK;
+}
+
+// the layer-skip decision from pooled TILE MEANS (models/utils.py:47-65 with mask_size 1): pool [B][nparts][C] holds the channel means
+// of nparts equal tiles of every image (ldn_spatial_masker's patch means with S*S = nparts, refreshed by ldn_conv_rows_pool), the global
+// average is their mean; mask [B][g], logits [B][2g] optional.  x is not read.
+extern "C" int ldn_layer_head(const float* pool, int B, int nparts, int C, const float* w, const float* bias, int g, float* mask,
+                              float* logits, void* stream) {
+    LDN_REQUIRE(pool && w && bias && mask, "ldn_layer_head: null pointer");
+    LDN_REQUIRE(B > 0 && nparts > 0 && C > 0 && g >= 1 && g <= 4, "ldn_layer_head: bad shape");
+    if (C % 4 == 0 && (C / 4 >= 256 || 256 % (C / 4) == 0) && (uintptr_t)pool % 16 == 0 && (uintptr_t)w % 16 == 0) {
+        hipLaunchKernelGGL(k_layer_head, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), pool, nparts, C, w, bias, g, mask, logits);
+        LDN_CHECK_LAUNCH("k_layer_head");
+        return LDN_OK;
+    }
+    hipLaunchKernelGGL(k_spatial_head, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), pool, B, nparts, C, nparts, w, bias, g, mask, logits);
+    LDN_CHECK_LAUNCH("k_spatial_head");
+    return LDN_OK;
+}
+
 extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, int Ho, int Wo, int stride, int32_t* idx3,
                                  int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
                                  int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work,
@@ -1093,7 +1204,7 @@ extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, 
         const long items = (long)Ho * Wo * 9 > (long)g.Hi * g.Wi ? (long)Ho * Wo * 9 : (long)g.Hi * g.Wi;
         const unsigned chunks = (unsigned)(items / 2048 < 1 ? 1 : (items / 2048 > 32 ? 32 : items / 2048));
         hipLaunchKernelGGL(k_layer_index, dim3(chunks, (unsigned)B), dim3(256), 0, st, patch_mask, g, idx3, pos3, idx1, pos1, nbr, cnt,
-                           img_prefix3, img_prefix1, stats);
+                           img_prefix3, img_prefix1, stats, 0, 0);
         LDN_CHECK_LAUNCH("k_layer_index");
         return LDN_OK;
     }

@@ -179,6 +179,19 @@ class Masker_spatial(_PrepCache):
         self.last_work = work
         return mask, ix
 
+    def decide_layer_pooled(self, x, S):
+        """Layer skip at the start of a fused run: the channel means of the S x S tiles of every image (one pass over x, as the
+        global pool is) stay in last_work for the blocks behind; the decision is taken from them (ldn_layer_head)."""
+        w, b = self._wb()
+        _, _, self.last_work = ops.spatial_masker(ops.as_nhwc(x), w, b, self.mask_channel_group, S, False, return_work=True)
+        B, C = x.shape[0], x.shape[1]
+        return ops.layer_head(self.last_work.view(B, S * S, C), w, b, self.mask_channel_group)[0]
+
+    def decide_layer_from_means(self, work, B, S, C):
+        w, b = self._wb()
+        self.last_work = work
+        return ops.layer_head(work.view(B, S * S, C), w, b, self.mask_channel_group)[0]
+
     def decide(self, x, carry=None):
         """The mask alone (what the blocks of the HIP path consume; their sparsities come from ldn_mask_to_index): forward()
         without the mean over the mask, a reduction launch per block."""
@@ -675,15 +688,24 @@ class Bottleneck(_PrepCache):
 
     use_fused_spatial_masker = os.environ.get("LDN_FUSED_SPATIAL_MASKER", "1") != "0"   # class-level switch (A/B, tests)
 
-    def _pool_eligible(self, Hi, Wi, Ho, Wo, cout):
-        """An identity spatial block of ONE mask group on an even patch grid of 4- or 16-pixel patches, on the k_dense path, with
-        in-place residual (the pixels it does not touch keep their values: their patches' means stay valid)."""
+    def _pool_grid(self, Hi, Wi, Ho, Wo, cout):
+        """S of the S x S grid of cells whose means conv3's epilogue can leave for the next masker (None: not on the fused path): an
+        identity block of ONE mask group, on the k_dense path, with in-place residual (the pixels it does not touch keep their values:
+        their cells' means stay valid); spatial: the masker's own even patch grid of 4- or 16-pixel patches; layer skip (mask_size 1):
+        a tiling of the square map by 4x4 or 2x2 pixel tiles (the global average pool = the mean of the tile means)."""
         ms = self.masker_spatial
+        if not (self.use_fused_spatial_masker and ms.mask_channel_group == 1 and self.forced_spatial_mask is None
+                and self.downsample is None and self.stride == 1 and self._inplace and cout % 128 == 0 and self.width % 8 == 0
+                and ops.dense_kernel_ok()):
+            return None
         S = ms.mask_size
-        return (self.use_fused_spatial_masker and ms.mask_channel_group == 1 and self.forced_spatial_mask is None
-                and self.downsample is None and self.stride == 1 and self._inplace and 1 < S < Hi and Hi % S == 0 and Wi % S == 0
-                and (Hi // S) * (Wi // S) in (4, 16) and cout % 128 == 0 and ops.dense_kernel_ok()
-                and ops.mask_plan_fits(S, S, Ho, Wo, 1))
+        if S == 1:
+            if Hi != Wi:
+                return None
+            return Hi // 4 if Hi % 4 == 0 else (Hi // 2 if Hi % 2 == 0 else None)
+        if 1 < S < Hi and Hi % S == 0 and Wi % S == 0 and (Hi // S) * (Wi // S) in (4, 16) and ops.mask_plan_fits(S, S, Ho, Wo, 1):
+            return S
+        return None
 
     def _run_spatial(self, x, p):
         B, Cin, Hi, Wi = x.shape
@@ -696,32 +718,44 @@ class Bottleneck(_PrepCache):
         # the fused spatial masker: an identity block whose successor decides on the same patch grid leaves the pooled
         # means of the patches it rewrites in conv3's epilogue (pool_out: its lists are then patch-major); the successor decides and
         # builds its lists from those means in ONE launch (ldn_mask_plan) -- no pass over x, no count launch
-        pool_out = bool(getattr(self, "_pool_next", False)) and self._pool_eligible(Hi, Wi, Ho, Wo, p["w3"].shape[0])
+        layer = ms.mask_size == 1
+        pS = self._pool_grid(Hi, Wi, Ho, Wo, p["w3"].shape[0])
+        pool_out = bool(getattr(self, "_pool_next", False)) and pS is not None
         self._pool_next = False
         ix = None
+        fresh = (pS is not None and carry_in is not None and len(carry_in) > 4 and carry_in[4] and carry_in[0] is not None
+                 and tuple(carry_in[2] or ()) == (B, Hi, Wi, Cin, pS))
         if self.forced_spatial_mask is not None:
             patch = self.forced_spatial_mask.to(device=x.device, dtype=torch.float32).contiguous()
-        elif (carry_in is not None and len(carry_in) > 4 and carry_in[4] and carry_in[0] is not None
-              and tuple(carry_in[2] or ()) == (B, Hi, Wi, Cin, ms.mask_size) and self._pool_eligible(Hi, Wi, Ho, Wo, p["w3"].shape[0])):
+        elif fresh and layer:
+            patch = ms.decide_layer_from_means(carry_in[0], B, pS, Cin)
+        elif fresh:
             patch, ix = ms.decide_from_means(carry_in[0], x.shape, (Ho, Wo), pool_out)
+        elif layer and pool_out:
+            patch = ms.decide_layer_pooled(x, pS)
         else:
-            patch = ms.decide(x, carry=carry_in)
+            patch = ms.decide(x, carry=carry_in if not (carry_in is not None and len(carry_in) > 4 and layer) else None)
         dev = x.device
         # spatial_mask_channel_group > 1 (models/utils.py:27-33,74-89): group g of the OUTPUT channels has its own pixel mask.
         # ExpandMask ORs the groups (its dilation kernel is [g,g,k,k] ones), so conv1 / conv2 -- and the sparsities the
         # reference reports for them -- live on the UNION of the groups; only conv3's scatter is per group.
         union = patch[:, 0] if G == 1 else patch.amax(dim=1)
         if ix is None:
-            ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride, patch_major=pool_out)
+            if layer and pool_out:     # the kept images' pixels tile by tile: conv3's epilogue owns whole tiles
+                ix = ops.layer_index(union.reshape(B), Ho, Wo, self.stride, tile=(Hi // pS, Wi // pS))
+            else:
+                ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride, patch_major=pool_out)
         pool = None
         if self.forced_spatial_mask is None and getattr(ms, "last_work", None) is not None:
             key = getattr(ms.last_work, "ldn_shape_key", None)
-            if ms.mask_size == 1 and G == 1:
+            if pool_out and ix.patch_major and key is not None and tuple(key) == (B, Hi, Wi, Cin, pS):
+                # [4]: conv3 below refreshes the means of the cells it rewrites -> the next block decides without reading x
+                pool = ms.last_work.view(B, pS, pS, Cin)
+                self.last_carry = (ms.last_work, ix.pre3 if layer else None, key, None if layer else union.contiguous(), True)
+            elif ms.mask_size == 1 and G == 1:
                 self.last_carry = (ms.last_work, ix.pre3, key)      # layer skip: which images this block leaves unchanged, and their channel sums
             elif ms.mask_size > 1:
-                # patch masks: the patches this block touches, and every patch's pooled means; [4]: conv3 below refreshes the touched ones
-                pool = ms.last_work.view(B, ms.mask_size, ms.mask_size, Cin) if (pool_out and ix.patch_major) else None
-                self.last_carry = (ms.last_work, None, key, union.contiguous(), pool is not None)
+                self.last_carry = (ms.last_work, None, key, union.contiguous(), False)   # patch masks: the patches this block touches, every patch's pooled means
         x2d = xn.reshape(B * Hi * Wi, Cin)
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
         ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
@@ -754,7 +788,7 @@ class Bottleneck(_PrepCache):
         for ig, rows, cs in groups:
             ops.conv_rows(h2, p["w3"][cs], None, p["t3"][cs], out2d[:, cs], a_rows=rows, taps=1, m_count=ig.cnt[0:1],
                           m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs], pool=pool,
-                          pool_grid=(ms.mask_size, ms.mask_size, Ho, Wo) if pool is not None else None)
+                          pool_grid=(pS, pS, Ho, Wo) if pool is not None else None)
         self.last_spatial_mask = patch
         if G > 1:   # sparsity of conv3 = mean over ALL group masks (Masker_spatial, utils.py:61); conv2 / conv1 = the union's
             ix.stats = torch.cat((patch.mean().reshape(1), ix.stats[1:]))
@@ -1068,7 +1102,7 @@ class ResNet(nn.Module):
                                                  # shortcut / stride 2 turns them into relu(downsample(x))
                                                  and prev.stride == 1 and prev.downsample is None
                                                  and getattr(prev, "_carry_step", -1) == step_id) else None)
-            blk._pool_next = (self.use_layer_carry and nxt is not None and blk.dyn_mode == "spatial" and nxt.dyn_mode == "spatial"
+            blk._pool_next = (self.use_layer_carry and nxt is not None and blk.dyn_mode in ("spatial", "layer") and nxt.dyn_mode == blk.dyn_mode
                               and nxt.stride == 1 and nxt.downsample is None and nxt.forced_spatial_mask is None
                               and nxt.masker_spatial.mask_size == blk.masker_spatial.mask_size
                               and nxt.masker_spatial.mask_channel_group == 1)

@@ -178,6 +178,33 @@ def mask_to_index(patch_mask, out_h, out_w, stride, patch_major=False):
     return ix
 
 
+def layer_index(image_mask, out_h, out_w, stride=1, tile=None):
+    """Layer skip: image_mask [B] float {0,1} -> packed lists (ldn_layer_index); tile = (gy, gx): the kept images' pixels tile by tile
+    (IndexSet.patch_major), None: row-major (= mask_to_index of a [B,1,1] mask)."""
+    L.require_device(image_mask)
+    lib = L.load()
+    B = image_mask.numel()
+    ix, _ = _empty_index(B, out_h, out_w, stride, image_mask.device)
+    gy, gx = tile if tile is not None else (0, 0)
+    ix.patch_major = tile is not None
+    L.check(lib.ldn_layer_index(L.ptr(_f32c(image_mask.reshape(B), "image_mask")), B, out_h, out_w, stride, gy, gx, L.ptr(ix.idx3),
+                                L.ptr(ix.pos3), L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr), L.ptr(ix.cnt), L.ptr(ix.pre3),
+                                L.ptr(ix.pre1), L.ptr(ix.stats), L.stream_ptr()), "ldn_layer_index")
+    return ix
+
+
+def layer_head(pool, weight, bias, groups, want_logits=False):
+    """The layer-skip decision from pooled tile means (ldn_layer_head): pool [B,nparts,C] -> (mask [B,g,1,1], logits [B,2g,1,1] or None)."""
+    L.require_device(pool, weight, bias)
+    lib = L.load()
+    B, nparts, C = pool.shape
+    mask = torch.empty(B, groups, 1, 1, device=pool.device, dtype=torch.float32)
+    logits = torch.empty(B, 2 * groups, 1, 1, device=pool.device, dtype=torch.float32) if want_logits else None
+    L.check(lib.ldn_layer_head(L.ptr(_f32c(pool, "pool")), B, nparts, C, L.ptr(_f32c(weight, "w")), L.ptr(_f32c(bias, "bias")), groups,
+                               L.ptr(mask), L.ptr(logits), L.stream_ptr()), "ldn_layer_head")
+    return mask, logits
+
+
 def mask_plan(pool, weight, bias, out_h, out_w, stride=1, patch_major=True, want_logits=False):
     """The fused spatial masker + list build of a block whose input's pooled patch means are already known (ldn_mask_plan, decide
     mode): pool [B,S,Sx,C] (the `work` of spatial_masker, refreshed by the previous block's conv_rows(..., pool=...)), weight [2,C],

@@ -229,3 +229,89 @@ def test_fused_spatial_masker_graph_replay(ops):
         got = g(x)[0]
         torch.cuda.synchronize()
         assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("B,Ho,stride,tile,p", [(9, 14, 1, (2, 2), 0.5), (256, 14, 1, (2, 2), 0.5), (5, 56, 1, (4, 4), 0.6), (7, 28, 2, (4, 4), 0.4),
+                                                (4, 28, 1, (2, 2), 1.0), (4, 28, 1, (4, 4), 0.0), (3, 12, 1, (4, 2), 0.5)])
+def test_layer_index_tile_order(ops, B, Ho, stride, tile, p):
+    """ldn_layer_index: one decision per image, the kept images' pixels tile by tile -- bit-exact lists (the oracle's pixels in the
+    documented order), and with tile = None the lists of ldn_mask_to_index."""
+    patch = seeded_bernoulli((B, 1, 1), p, 13 + B + Ho)
+    ix = ops.layer_index(patch.to(DEV).reshape(B), Ho, Ho, stride, tile=tile)
+    torch.cuda.synchronize()
+    # the oracle sees a patch grid of Ho/gy x Ho/gx cells that all carry the image's decision
+    S, Sx = Ho // tile[0], Ho // tile[1]
+    cells = patch.expand(B, S, Sx).contiguous()
+    m3 = IR.upsample_patch_mask(cells.numpy() > 0.5, Ho, Ho)
+    m1 = IR.dilate_mask(m3, stride, 1)
+    want3, pre3 = _patch_major_order(m3, S, Sx)
+    cnt = ix.cnt.cpu().numpy()
+    assert cnt[0] == len(want3) and np.array_equal(ix.idx3.cpu().numpy()[:cnt[0]], want3)
+    assert np.array_equal(ix.pre3.cpu().numpy(), pre3)
+    pos3 = np.full(B * Ho * Ho, -1, dtype=np.int64)
+    pos3[want3] = np.arange(len(want3))
+    assert np.array_equal(ix.pos3.cpu().numpy(), pos3)
+    idx1, pre1 = IR.nonzero_rows(m1)
+    assert cnt[1] == len(idx1) and np.array_equal(ix.idx1.cpu().numpy()[:cnt[1]], idx1) and np.array_equal(ix.pre1.cpu().numpy(), pre1)
+    raster = IR.nonzero_rows(m3)[0]
+    where = {int(r): i for i, r in enumerate(raster)}
+    nbr_raster = IR.neighbour_table(m3, m1, stride)
+    want_nbr = nbr_raster[[where[int(r)] for r in want3]] if len(want3) else nbr_raster
+    assert np.array_equal(ix.nbr.cpu().numpy().reshape(-1, 9)[:cnt[0]], want_nbr)
+    assert np.allclose(ix.stats.cpu().numpy(), np.array([patch.mean().item(), m3.mean(), m1.mean()], dtype=np.float32), atol=1e-6)
+    plain = ops.layer_index(patch.to(DEV).reshape(B), Ho, Ho, stride)
+    ref = ops.mask_to_index(patch.to(DEV), Ho, Ho, stride)
+    n3 = int(ref.cnt[0])
+    assert torch.equal(plain.cnt, ref.cnt) and torch.equal(plain.idx3[:n3], ref.idx3[:n3]) and torch.equal(plain.pos3, ref.pos3)
+    assert torch.equal(plain.nbr[:9 * n3], ref.nbr[:9 * n3])
+
+
+def test_layer_head_from_tile_means(ops):
+    """The layer-skip decision from tile means: the mean of the means of equal tiles is the global average pool -- logits within fp32
+    reduction-order noise of the stand-alone layer masker's, decisions equal away from ties."""
+    B, C, H = 6, 256, 28
+    w = seeded_randn((2, C), 5).to(DEV) * 0.1
+    b = torch.tensor([0.0, 0.0], device=DEV)
+    x = F.relu(seeded_randn((B, H, H, C), 9)).to(DEV).contiguous()
+    mask0, lg0 = ops.spatial_masker(x, w, b, 1, 1, want_logits=True)
+    _, _, work = ops.spatial_masker(x, w, b, 1, 7, return_work=True)
+    mask1, lg1 = ops.layer_head(work.view(B, 49, C), w, b, 1, want_logits=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(lg1.reshape(-1), lg0.reshape(-1), atol=1e-5, rtol=1e-5)
+    margin = (lg0.reshape(B, 2)[:, 0] - lg0.reshape(B, 2)[:, 1]).abs()
+    differs = mask1.reshape(B) != mask0.reshape(B)
+    assert not bool((differs & (margin > 1e-4)).any())
+
+
+def test_fused_layer_masker_whole_model(ops):
+    """LAUD-ResNet50 layer skip: with the fused masker (tile means from conv3's epilogue, the decision from them) every block takes the
+    decisions of the stand-alone path and the logits agree bit for bit (a decision on a tie of the two summation orders would be named)."""
+    import laudnet_amd
+    from laudnet_amd import laud_resnet as LR
+    from fill import fill_state_dict
+    m = laudnet_amd.uni_resnet50(dyn_mode=["layer"] * 4, width_mult=0.5, input_size=224, num_classes=10).eval()
+    sd = fill_state_dict(m.state_dict(), 3)
+    for k in sd:
+        if k.endswith("masker_spatial.conv.bias"):
+            sd[k] = torch.zeros_like(sd[k])
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x = seeded_randn((12, 3, 224, 224), 21).to(DEV)
+    blocks = [b for i in range(4) for b in getattr(m, f"layer{i + 1}")]
+    outs = {}
+    for fused in (False, True):
+        LR.Bottleneck.use_fused_spatial_masker = fused
+        try:
+            with torch.no_grad():
+                logits = m(x, 1.0)[0]
+            outs[fused] = (logits.clone(), [b.last_spatial_mask.clone() for b in blocks],
+                           [bool(getattr(b, "last_carry", None) and len(b.last_carry) > 4 and b.last_carry[4]) for b in blocks])
+        finally:
+            LR.Bottleneck.use_fused_spatial_masker = True
+    torch.cuda.synchronize()
+    assert sum(outs[True][2]) >= 6 and not any(outs[False][2])
+    kept = torch.cat([a.reshape(-1) for a in outs[False][1]])
+    assert 0.05 < float(kept.mean()) < 0.95
+    flips = [i for i, (a, b) in enumerate(zip(outs[False][1], outs[True][1])) if not torch.equal(a, b)]
+    assert not flips, f"decisions differ at blocks {flips} (a tie between the two summation orders of the pooled means?)"
+    assert torch.equal(outs[True][0], outs[False][0])

@@ -63,6 +63,8 @@ class TokenSkipBlock(nn.Module):
                 self._w = (key, after_ln(self.qkv, self.norm1), plain(self.proj), after_ln(self.fc1, self.norm2), plain(self.fc2))
         return self._w[1:]
 
+    qkv_kept_only = True      # class-level switch (A/B, tests): False = q / k / v for the rows of `qkv_rows` (every token of the running images)
+
     def run_packed(self, x2d, tok_rows, prefix, count, B, max_tokens, head_keep=None, mlp_lists=None, qkv_rows=None):
         """x2d [B*L, dim] fp32, updated IN PLACE on the kept tokens; tok_rows / prefix / count from ops.token_lists (the attention
         sub-block's token list).  Head and layer skipping (simulate_adavit.py:81-88,140-182), all optional:
@@ -70,8 +72,8 @@ class TokenSkipBlock(nn.Module):
                                       its attention workgroup computes nothing and contributes zeros to the projection;
           mlp_lists (rows, prefix, count)  the MLP sub-block's own token list (layer skipping decides the two sub-blocks separately:
                                       an image whose attention / MLP is skipped simply has no tokens in that list);
-          qkv_rows (rows, count)      token rows q / k / v are computed for (default: every token; with layer skipping: the tokens
-                                      of the images whose attention sub-block runs)."""
+          qkv_rows (rows, count)      (only with qkv_kept_only = False) token rows q / k / v are computed for; by default they are
+                                      computed for the attention list itself."""
         if self.training:
             raise LdnError("laudnet_amd implements the eval-mode (inference) hot path only")
         if ops.get_math_mode() != "bf16x3":
@@ -85,12 +87,11 @@ class TokenSkipBlock(nn.Module):
         if head_keep is not None:     # [B, 3 * dim]: the head's decision over its 64 channels of q, k and v
             hk = head_keep.float().reshape(B, self.heads)
             hk3 = hk.repeat_interleave(self.dim // self.heads, dim=1).repeat(1, 3).contiguous()
-        if qkv_rows is None:
-            ops.conv_rows(x2d, wq, None, bq, qkv, taps=1, m_cap=rows, relu=0, ln_stats=st, ln_c1=cq, chan_mask=hk3,
-                          rows_per_image=Lt if hk3 is not None else 0)                           # norm1 + q / k / v for every token
-        else:
-            ops.conv_rows(x2d, wq, None, bq, qkv, a_rows=qkv_rows[0], out_rows=qkv_rows[0], taps=1, m_count=qkv_rows[1], m_cap=rows, relu=0,
-                          ln_stats=st, ln_c1=cq, chan_mask=hk3, rows_per_image=Lt if hk3 is not None else 0)
+        # norm1 + q / k / v of the tokens that attend (the attention list: a dropped token is neither query nor key,
+        # simulate_adavit.py:96-109) -- not of every token: at keep 0.5 that is half of the widest linear of the block
+        q_rows, q_count = qkv_rows if qkv_rows is not None and not self.qkv_kept_only else (tok_rows, count)
+        ops.conv_rows(x2d, wq, None, bq, qkv, a_rows=q_rows, out_rows=q_rows, taps=1, m_count=q_count, m_cap=rows, relu=0,
+                      ln_stats=st, ln_c1=cq, chan_mask=hk3, rows_per_image=Lt if hk3 is not None else 0)
         att = ops.packed_mha(qkv, tok_rows, prefix, B, self.heads, max_tokens,
                              head_keep=None if head_keep is None else head_keep.float().reshape(B, self.heads).contiguous())   # [capacity, dim], packed
         ops.conv_rows(att, wp, None, bp, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d)

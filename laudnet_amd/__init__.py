@@ -4,7 +4,14 @@ The package holds only what that path needs: `csrc/` (HIP kernels + the C ABI of
 `_lib.py`/`ops.py` (ctypes binding) and `laud_resnet.py` (host-side mirror of the reference's
 nn.Module surface).  There is no CPU or PyTorch fallback for the hot path.
 """
-from ._lib import LdnError, load as load_library  # noqa: F401
+import os as _os
+
+# Kernel arguments in device memory (ROCm runtime switch, read when HIP initialises -- i.e. it takes effect if laudnet_amd is imported
+# before the first HIP call of the process): the ~150-250 launches of a forward each start without an argument fetch over PCIe.
+# An explicit HIP_FORCE_DEV_KERNARG in the environment wins.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+from ._lib import LdnError, load as load_library  # noqa: F401,E402
 from .laud_resnet import (Bottleneck, ExpandMask, Masker_channel_conv_linear, Masker_channel_MLP,  # noqa: F401
                           Masker_spatial, ResNet, uni_resnet50, uni_resnet101)
 

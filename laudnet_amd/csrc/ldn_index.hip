@@ -2,6 +2,9 @@
 // (wave64 ballot + popcount prefix sums), stand-alone row gather and masked scatter-add.
 #include <stdarg.h>
 
+#include <map>
+#include <mutex>
+
 #include "ldn_common.h"
 #include "ldn_mlp.h"
 
@@ -18,10 +21,20 @@ void set_error(const char* fmt, ...) {
 // Raise a kernel's dynamic-LDS ceiling above the 64 KiB default when a launch needs it (gfx950: 160 KiB/CU).
 bool allow_dynamic_lds(const void* kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return true;
+    // the attribute is set once per (kernel, device) and raised when a launch needs more -- not on every launch
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> granted;
+    static const bool always = getenv("LDN_LDS_ATTR_ALWAYS") != nullptr;      // A/B: the attribute call in front of every launch
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = granted[{kernel, dev}];
+    if (have >= bytes && !always) return true;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
+    have = bytes;
     return true;
 }
 

@@ -179,6 +179,12 @@ int ldn_conv_rows_f32(const float* a, int lda, const int32_t* a_rows, int taps, 
                         const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride, const float* ln_stats,
                         const float* ln_c1, void* stream);
 
+/* Advisory, per thread, consumed by the next ldn_conv_rows_split / ldn_conv_rows_pool call: about how many rows that call will find in
+ * its device-side count *m_count (the host cannot read it without a synchronisation; a caller passes e.g. the previous forward's
+ * count, copied to pinned memory asynchronously).  It only selects the tile width (a launch takes rounds-of-workgroups x tile time,
+ * DESIGN.md 4n / 4t); results are bit-identical with any hint or none.  Calls without a device-side count know their rows exactly. */
+int ldn_hint_rows(int rows);   /* returns 0 */
+
 /* ldn_conv_rows_split / ldn_conv_rows_f32 with taps == 1, plus a by-product: pool [B][S*Sx][cout] receives, for every patch
  * this launch writes, the MEAN of the final output (after residual and ReLU) over the patch's Ho/S x Wo/Sx pixels (4 or 16) --
  * the pooled means the next block's spatial masker needs (adaptive_avg_pool2d of models/utils.py:48-52 on an even grid), so

@@ -25,6 +25,7 @@ SIGNATURES = {
     "ldn_mask_to_index": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "ldn_mask_to_index_workspace_bytes": ([_I, _I, _I, _I], C.c_size_t),
     "ldn_mask_plan_fits": ([_I, _I, _I, _I, _I], _I),
+    "ldn_hint_rows": ([_I], _I),
     "ldn_layer_index": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "ldn_layer_head": ([_P, _I, _I, _I, _P, _P, _I, _P, _P, _P], _I),
     "ldn_mask_plan": ([_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),

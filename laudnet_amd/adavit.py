@@ -90,16 +90,22 @@ class TokenSkipBlock(nn.Module):
         # norm1 + q / k / v of the tokens that attend (the attention list: a dropped token is neither query nor key,
         # simulate_adavit.py:96-109) -- not of every token: at keep 0.5 that is half of the widest linear of the block
         q_rows, q_count = qkv_rows if qkv_rows is not None and not self.qkv_kept_only else (tok_rows, count)
+        m_rows, _, m_count = mlp_lists if mlp_lists is not None else (tok_rows, prefix, count)
+        # list lengths of this block's previous forward (pinned memory, no synchronisation): the tile-width hint of the row kernels
+        hint = getattr(self, "_rows_hint", None)
+        if hint is None:
+            hint = self._rows_hint = ops.RowsHint(3)
+        nq, na, nm = hint.get(0), hint.get(1), hint.get(2)
+        hint.update(q_count, count, m_count)
         ops.conv_rows(x2d, wq, None, bq, qkv, a_rows=q_rows, out_rows=q_rows, taps=1, m_count=q_count, m_cap=rows, relu=0,
-                      ln_stats=st, ln_c1=cq, chan_mask=hk3, rows_per_image=Lt if hk3 is not None else 0)
+                      ln_stats=st, ln_c1=cq, chan_mask=hk3, rows_per_image=Lt if hk3 is not None else 0, rows_hint=nq)
         att = ops.packed_mha(qkv, tok_rows, prefix, B, self.heads, max_tokens,
                              head_keep=None if head_keep is None else head_keep.float().reshape(B, self.heads).contiguous())   # [capacity, dim], packed
-        ops.conv_rows(att, wp, None, bp, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d)
-        m_rows, _, m_count = mlp_lists if mlp_lists is not None else (tok_rows, prefix, count)
+        ops.conv_rows(att, wp, None, bp, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d, rows_hint=na)
         st = ops.row_stats(x2d, self.norm2.eps)                                                 # norm2 (after the attention update)
         hid = torch.empty(rows, w1.shape[0], device=x2d.device, dtype=torch.float32)
-        ops.conv_rows(x2d, w1, None, b1, hid, a_rows=m_rows, taps=1, m_count=m_count, m_cap=rows, relu=3, ln_stats=st, ln_c1=c1)   # norm2 + fc1 + GELU
-        ops.conv_rows(hid, w2, None, b2, x2d, taps=1, m_count=m_count, m_cap=rows, relu=0, out_rows=m_rows, residual2d=x2d)
+        ops.conv_rows(x2d, w1, None, b1, hid, a_rows=m_rows, taps=1, m_count=m_count, m_cap=rows, relu=3, ln_stats=st, ln_c1=c1, rows_hint=nm)   # norm2 + fc1 + GELU
+        ops.conv_rows(hid, w2, None, b2, x2d, taps=1, m_count=m_count, m_cap=rows, relu=0, out_rows=m_rows, residual2d=x2d, rows_hint=nm)
         return x2d
 
     @staticmethod

@@ -79,7 +79,7 @@ __device__ __forceinline__ unsigned d_lds_off(const void* ptr) {
 constexpr int D_ROWS_MAX = 256;
 constexpr int D_ROW_RELU = 1 << 30;
 
-// NSUB = n-subtiles of 32 columns per workgroup (2, 4, 8); D = ring depth (2 for NSUB 8, 3 otherwise)
+// NSUB = n-subtiles of 32 columns per workgroup (2, 4, 5, 6, 8); D = ring depth (2 for NSUB >= 6, 3 otherwise)
 // T9: 3x3 over a neighbour table (compiled apart: the 1x1 form carries none of its tables or branches); FULL: cout is a multiple of
 // the tile width, so every workgroup owns NSUB whole n-subtiles (compiled apart: no per-subtile branch in the K loop)
 // F32: true-fp32 arithmetic (v_mfma_f32_32x32x2_f32, fp32 multiply and accumulate -- the `fp32` math mode of the library).  The byte
@@ -91,7 +91,7 @@ constexpr int D_ROW_RELU = 1 << 30;
 template <int NSUB, bool T9, bool FULL, bool F32 = false, int R = 256>
 __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
     constexpr int NT = NSUB * 32;
-    constexpr int D = (NSUB == 8 || R == 128) ? 2 : 3;
+    constexpr int D = (NSUB >= 6 || R == 128) ? 2 : 3;
     constexpr int D_ROWS = R, NTHR = 2 * R, WR = R / 4;     // WR: weight rows one DMA round of all waves covers (8 per wave)
     constexpr int SLOT = (D_ROWS + NT) * 128;
     constexpr int NWI = (NT + WR - 1) / WR;               // weight DMA instructions per wave and chunk (8 rows each) ...
@@ -524,7 +524,7 @@ LDN_DEFINE_TU_VIOLATIONS(tu_violations_dense)
 template <int NSUB, bool T9, bool FULL, bool F32 = false, int R = 256>
 static int launch_dense_f(DenseArgs& a, hipStream_t st) {
     constexpr int NT = NSUB * 32;
-    constexpr int D = (NSUB == 8 || R == 128) ? 2 : 3;
+    constexpr int D = (NSUB >= 6 || R == 128) ? 2 : 3;
     const size_t lds = (size_t)(T9 ? 12 : 2) * R * 4 + (size_t)D * (R + NT) * 128;
     a.ntn = ceil_div(a.cout, NT);
     a.mtn = ceil_div(a.m_cap, R);
@@ -558,6 +558,11 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
                                 int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
                                 const float* ln_stats, const float* ln_c1, bool f32, void* stream, float* pool = nullptr, int pool_S = 0,
                                 int pool_Sx = 0);
+
+// Advisory: about how many rows the NEXT ldn_conv_rows_split / _pool call of this thread will find in its device-side count (which the
+// host cannot read without a synchronisation) -- e.g. the count of the previous forward.  Used to choose the tile width only.
+static thread_local long g_rows_hint = -1;
+extern "C" int ldn_hint_rows(int rows) { g_rows_hint = rows; return LDN_OK; }
 
 extern "C" int ldn_conv_rows_split(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                                    const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
@@ -600,6 +605,8 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
                                 float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
                                 int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
                                 const float* ln_stats, const float* ln_c1, bool f32, void* stream, float* pool, int pool_S, int pool_Sx) {
+    const long hint = g_rows_hint;      // (consumed by this call whatever path it takes)
+    g_rows_hint = -1;
     LDN_REQUIRE(a && w_split && shift && out, "ldn_conv_rows_split: null pointer");
     int pool_gy = 0, pool_gx = 0;
     if (pool) {
@@ -644,9 +651,39 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
     // outweighs the second resident workgroup), so it is off; LDN_DENSE_R128=1 (or a workgroup-count threshold) switches it on for A/B
     static const int r128 = getenv("LDN_DENSE_R128") ? atoi(getenv("LDN_DENSE_R128")) : 0;
     const bool small_grid = r128 && cout % 128 == 0 && (long)mt * (cout / 128) <= (r128 > 1 ? r128 : 512);
+    // Tile width by a cost model when the number of rows is KNOWN (no device-side count) or HINTED (ldn_hint_rows: the host cannot see
+    // a device-side count, the caller passes what the previous forward's count was): the time of a launch is rounds x tile time
+    // (DESIGN.md 4n), rounds = ceil(live workgroups / 256) (one workgroup per CU: 115-159 KB of LDS), tile time = chunks x (1700 + 500
+    // NSUB) + 6000 NSUB cycles (the per-chunk law of 4r, the epilogue per 32-column subtile).  Results do not depend on the choice.
+    static const bool use_model = !(getenv("LDN_DENSE_MODEL") && atoi(getenv("LDN_DENSE_MODEL")) == 0);
+    const long rows_known = !m_count ? (long)m_cap : (hint >= 0 ? (hint < m_cap ? hint : (long)m_cap) : -1);
+    auto tile_cost = [&](int ns) {
+        const long mtl = (rows_known + D_ROWS_MAX - 1) / D_ROWS_MAX;
+        const long chunks = (long)taps * ((cin + 31) / 32);
+        const long wgs = mtl * (cout / (ns * 32));
+        return (double)((wgs + 255) / 256) * (double)(chunks * (1700 + 500 * ns) + 6000 * ns);
+    };
     if (taps == 9) {
         if (small_grid) return launch_dense_f<4, true, true, false, 128>(d, st);
+        if (use_model && rows_known > 0 && cout % 128 == 0 && tile_cost(2) < tile_cost(4)) return launch_dense_f<2, true, true>(d, st);
         return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true>(d, st) : launch_dense<2, true>(d, st);
+    }
+    if (use_model && rows_known > 0 && !small_grid) {
+        int best = 0;
+        double best_cost = 0.0;
+        for (int ns : {8, 6, 5, 4, 2}) {
+            if (cout % (ns * 32) != 0) continue;
+            const double cost = tile_cost(ns);
+            if (!best || cost < best_cost) { best = ns; best_cost = cost; }
+        }
+        switch (best) {
+            case 8: return launch_dense_f<8, false, true>(d, st);
+            case 6: return launch_dense_f<6, false, true>(d, st);
+            case 5: return launch_dense_f<5, false, true>(d, st);
+            case 4: return launch_dense_f<4, false, true>(d, st);
+            case 2: return launch_dense_f<2, false, true>(d, st);
+            default: break;
+        }
     }
     if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8, false>(d, st);
     if (small_grid) return launch_dense_f<4, false, true, false, 128>(d, st);

@@ -248,8 +248,13 @@ class ResBottleneckBlock(_PrepCache):
             f.last_carry = (f.masker_spatial.last_work, ix.pre3, getattr(f.masker_spatial.last_work, "ldn_shape_key", None))   # which images this block leaves unchanged, and their channel sums
         x2d = xn.reshape(B * Hi * Wi, Cin)
         w_b = f.w_b
+        hint = getattr(f, "_rows_hint", None)     # row counts of this block's previous forward: tile-width hint of the row kernels
+        if hint is None:
+            hint = f._rows_hint = ops.RowsHint(2)
+        n3, n1 = hint.get(0), hint.get(1)
+        hint.update(ix.cnt)
         h_a = torch.empty(ix.cap1, w_b, device=dev, dtype=torch.float32)
-        ops.conv_rows(x2d, p["wa"], p["sa"], p["ta"], h_a, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
+        ops.conv_rows(x2d, p["wa"], p["sa"], p["ta"], h_a, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1, rows_hint=n1)
         h_b = torch.empty(ix.cap3, w_b, device=dev, dtype=torch.float32)
         _conv_b_rows(p, f, h_a, ix.nbr, h_b, ix.cnt[0:1], ix.cap3, images=(B, Hi, Wi, Ho, Wo, self.stride))
         ops.se_packed(h_b, ix.pre3, p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo)
@@ -265,7 +270,7 @@ class ResBottleneckBlock(_PrepCache):
         else:
             resid, out2d = x2d, torch.relu(x2d)
         ops.conv_rows(h_b, p["wc"], p["sc"], p["tc"], out2d, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
-                      out_rows=ix.idx3, residual2d=resid)
+                      out_rows=ix.idx3, residual2d=resid, rows_hint=n3)
         f.last_spatial_mask = patch
         # (defer_stats: the caller appends the channel sparsity 1 to all blocks at once -- a fill and a cat per block otherwise)
         stats = ix.stats if defer_stats else torch.cat((ix.stats, torch.ones(1, device=dev)))

@@ -757,10 +757,16 @@ class Bottleneck(_PrepCache):
             elif ms.mask_size > 1:
                 self.last_carry = (ms.last_work, None, key, union.contiguous(), False)   # patch masks: the patches this block touches, every patch's pooled means
         x2d = xn.reshape(B * Hi * Wi, Cin)
+        # row counts of the previous forward of THIS block (pinned memory, no synchronisation): the tile-width hint of the row kernels
+        hint = getattr(self, "_rows_hint", None)
+        if hint is None:
+            hint = self._rows_hint = ops.RowsHint(2)
+        n3, n1 = hint.get(0), hint.get(1)
+        hint.update(ix.cnt)
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
-        ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1)
+        ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1, rows_hint=n1)
         h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
-        ops.conv_rows(h1, p["w2"], p["s2"], p["t2"], h2, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3)
+        ops.conv_rows(h1, p["w2"], p["s2"], p["t2"], h2, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3, rows_hint=n3)
         cout = p["w3"].shape[0]
         if G == 1:
             groups = [(ix, None, slice(0, cout))]
@@ -787,7 +793,7 @@ class Bottleneck(_PrepCache):
             resid, out2d = x2d, torch.relu(x2d)
         for ig, rows, cs in groups:
             ops.conv_rows(h2, p["w3"][cs], None, p["t3"][cs], out2d[:, cs], a_rows=rows, taps=1, m_count=ig.cnt[0:1],
-                          m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs], pool=pool,
+                          m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs], rows_hint=n3 if G == 1 else None, pool=pool,
                           pool_grid=(pS, pS, Ho, Wo) if pool is not None else None)
         self.last_spatial_mask = patch
         if G > 1:   # sparsity of conv3 = mean over ALL group masks (Masker_spatial, utils.py:61); conv2 / conv1 = the union's

@@ -333,7 +333,41 @@ def row_stats(x2d, eps=1e-5):
     return st
 
 
-def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None, m_cap=None, relu=1,
+class RowsHint:
+    """Row counts of the PREVIOUS forward for the tile-width choice of k_dense (ldn_hint_rows): the device-side counts of a block are
+    copied to pinned memory without a synchronisation (update), the next forward reads what has arrived (get).  A stale or missing
+    value only changes tile shapes, never results."""
+
+    EVERY = 32      # after the first two forwards the counts are refreshed on every 32nd call only (a copy is a launch on the stream)
+
+    def __init__(self, n):
+        self.n, self.host, self.seen, self.calls = n, None, False, 0
+
+    def get(self, i):
+        if not self.seen or self.host is None:
+            return None
+        v = int(self.host[i])
+        return v if v >= 0 else None
+
+    def update(self, *dev_counts):
+        """dev_counts: int32 device tensors whose elements fill the slots in order."""
+        self.calls += 1
+        if (self.calls > 2 and self.calls % self.EVERY) or torch.cuda.is_current_stream_capturing():
+            return
+        if self.host is None:
+            self.host = torch.full((self.n,), -1, dtype=torch.int32).pin_memory()
+        o = 0
+        for t in dev_counts:
+            k = t.numel()
+            self.host[o:o + k].copy_(t.reshape(-1), non_blocking=True)
+            o += k
+        self.seen = True
+
+
+USE_ROWS_HINT = os.environ.get("LDN_ROWS_HINT", "1") != "0"
+
+
+def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None, m_cap=None, relu=1, rows_hint=None,
               relu_if_neg=None, out_rows=None, residual2d=None, math=None, post_sub=None, chan_mask=None, rows_per_image=0,
               pix_map=None, geom=None, ln_stats=None, ln_c1=None, pool=None, pool_grid=None):
     """Packed-row convolution (see ldn_conv_rows).  a2d [rows,lda>=cin]; w [cout,taps,cin]; out2d [rows,ldo].
@@ -358,6 +392,8 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
     classes = 1 if shift.dim() == 1 else shift.shape[0]
     if (post_sub is not None or chan_mask is not None or classes != 1 or relu == 3 or ln_stats is not None) and not dense_ok:
         raise L.LdnError("conv_rows: post_sub / chan_mask / a shift table / the GELU and LayerNorm epilogues need the k_dense path (cin % 8 == 0, cout % 4 == 0)")
+    if rows_hint is not None and m_count is not None and USE_ROWS_HINT and dense_ok:
+        lib.ldn_hint_rows(int(rows_hint))
     if pool is not None:
         # the pooled patch means of the output as a by-product (ldn_conv_rows_pool): pool [B,S,Sx,cout], pool_grid = (S, Sx, Ho, Wo);
         # the packed rows list whole patches (IndexSet.patch_major)

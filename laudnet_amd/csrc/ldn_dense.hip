@@ -653,15 +653,18 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
     const bool small_grid = r128 && cout % 128 == 0 && (long)mt * (cout / 128) <= (r128 > 1 ? r128 : 512);
     // Tile width by a cost model when the number of rows is KNOWN (no device-side count) or HINTED (ldn_hint_rows: the host cannot see
     // a device-side count, the caller passes what the previous forward's count was): the time of a launch is rounds x tile time
-    // (DESIGN.md 4n), rounds = ceil(live workgroups / 256) (one workgroup per CU: 115-159 KB of LDS), tile time = chunks x (1700 + 500
-    // NSUB) + 6000 NSUB cycles (the per-chunk law of 4r, the epilogue per 32-column subtile).  Results do not depend on the choice.
+    // (DESIGN.md 4n / 4t), rounds = ceil(live workgroups / 256) (one workgroup per CU: 115-159 KB of LDS), tile time = chunks x (1700 + 500
+    // NSUB) + 12000 NSUB cycles (the per-chunk law of 4r; the second constant, fitted: epilogue + pipeline fill per 32-column subtile).  Results do not depend on the choice.
     static const bool use_model = !(getenv("LDN_DENSE_MODEL") && atoi(getenv("LDN_DENSE_MODEL")) == 0);
     const long rows_known = !m_count ? (long)m_cap : (hint >= 0 ? (hint < m_cap ? hint : (long)m_cap) : -1);
+    static long mc[3] = {1700, 500, 12000};   // LDN_DENSE_MODEL_C="a,b,c" overrides (tuning)
+    static const bool mc_env = [] { const char* e = getenv("LDN_DENSE_MODEL_C"); if (e) sscanf(e, "%ld,%ld,%ld", &mc[0], &mc[1], &mc[2]); return e != nullptr; }();
+    (void)mc_env;
     auto tile_cost = [&](int ns) {
         const long mtl = (rows_known + D_ROWS_MAX - 1) / D_ROWS_MAX;
         const long chunks = (long)taps * ((cin + 31) / 32);
         const long wgs = mtl * (cout / (ns * 32));
-        return (double)((wgs + 255) / 256) * (double)(chunks * (1700 + 500 * ns) + 6000 * ns);
+        return (double)((wgs + 255) / 256) * (double)(chunks * (mc[0] + mc[1] * ns) + mc[2] * ns);
     };
     if (taps == 9) {
         if (small_grid) return launch_dense_f<4, true, true, false, 128>(d, st);

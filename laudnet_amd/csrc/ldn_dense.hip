@@ -63,7 +63,10 @@ __device__ __forceinline__ void d_wait_vm_rt(int n) {
     switch (n) {
         case 1: d_wait_vm<1>(); break;   case 2: d_wait_vm<2>(); break;   case 3: d_wait_vm<3>(); break;
         case 4: d_wait_vm<4>(); break;   case 5: d_wait_vm<5>(); break;   case 6: d_wait_vm<6>(); break;
-        case 7: d_wait_vm<7>(); break;   case 8: d_wait_vm<8>(); break;
+        case 7: d_wait_vm<7>(); break;   case 8: d_wait_vm<8>(); break;   case 9: d_wait_vm<9>(); break;
+        case 10: d_wait_vm<10>(); break; case 11: d_wait_vm<11>(); break; case 12: d_wait_vm<12>(); break;
+        case 13: d_wait_vm<13>(); break; case 14: d_wait_vm<14>(); break; case 15: d_wait_vm<15>(); break;
+        case 16: d_wait_vm<16>(); break;
         default: d_wait_vm<0>(); break;   // 0, and anything unexpected: wait for everything (always safe)
     }
 }
@@ -233,6 +236,42 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
     unsigned long long d0, d1, d2, d3, d4, d5, a_wait = 0, a_bar = 0, a_issue = 0, a_prep = 0, a_mfma = 0, d_start, d_loop;
     DT(d_start)
 #endif
+    // B operands of both K16 steps of a chunk: the wave's 32 rows, split into bf16 hi / lo once for all n-subtiles.  The rows are staged
+    // by THIS wave's own DMA, so they need its vmcnt only, not the workgroup barrier (that one is for the weights, staged by all waves):
+    // full tiles read and split the NEXT chunk's rows behind the current chunk's MFMA steps (PRE), off the barrier-to-MFMA path.
+    bf16x8 bh[2], bl[2];       // F32: bh = the lane's k-slots 0-3, bl = k-slots 4-7 as raw floats (bit patterns)
+    auto load_b = [&](int c) {
+        const unsigned char* xs = s_ring + (c % D) * SLOT;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned sl = 4u * half + 2u * h;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
+            if constexpr (F32) {
+                bh[half] = __builtin_bit_cast(bf16x8, x0);
+                bl[half] = __builtin_bit_cast(bf16x8, x1);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = e < 4 ? x0[e] : x1[e - 4];
+                    const __bf16 hb = (__bf16)v;
+                    bh[half][e] = hb;
+                    bl[half][e] = (__bf16)(v - (float)hb);
+                }
+            }
+        }
+    };
+#ifndef LDN_DENSE_NO_PRE
+    constexpr bool PRE = FULL;
+#else
+    constexpr bool PRE = false;
+#endif
+    // own rows of a chunk = the first four DMA instructions of that chunk: landed once at most (chunks in flight) x per_chunk - 4 are outstanding
+    const int own_landed = per_chunk * (D - 1) - 4;
+    if (PRE && active && nchunks > 0) {
+        d_wait_vm_rt(own_landed <= 16 ? own_landed : 0);
+        load_b(0);
+    }
     for (int c = 0; c < nchunks; ++c) {
         DT(d0)
         d_wait_vm_rt(per_chunk * (D - 2));
@@ -245,28 +284,8 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
         if (!(FULL && active)) { if (c + D - 1 < nchunks) dma_chunk(c + D - 1); else dma_dummy(c + D - 1); }
         DT(d3)
         if (!active) continue;
-        const unsigned char* xs = s_ring + (c % D) * SLOT;
-        const unsigned char* ws = xs + D_ROWS * 128;
-        // B operands of both K16 steps of the chunk: the wave's 32 rows, split into bf16 hi / lo once for all n-subtiles
-        bf16x8 bh[2], bl[2];       // F32: bh = the lane's k-slots 0-3, bl = k-slots 4-7 as raw floats (bit patterns)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const unsigned sl = 4u * half + 2u * h;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
-            if constexpr (F32) {
-                bh[half] = __builtin_bit_cast(bf16x8, x0);
-                bl[half] = __builtin_bit_cast(bf16x8, x1);
-            } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = e < 4 ? x0[e] : x1[e - 4];
-                const __bf16 hb = (__bf16)v;
-                bh[half][e] = hb;
-                bl[half][e] = (__bf16)(v - (float)hb);
-            }
-            }
-        }
+        const unsigned char* ws = s_ring + (c % D) * SLOT + D_ROWS * 128;
+        if (!PRE) load_b(c);
         // one K16 step of n-subtile j_: bf16x3 = three 32x32x16 products of the hi / lo halves; F32 = eight 32x32x2 products of raw floats
 #define LDN_DENSE_STEP(ACC_, AH_, AL_, BH_, BL_) \
         if constexpr (F32) { \
@@ -318,6 +337,10 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
 #pragma unroll
             for (int k = 2 * NSUB; k < 4 + NWI; ++k)
                 if (k < 4 + nwi) dma_one(c + D - 1, k);   // (64-column tiles: five instructions, four steps)
+            if (PRE && c + 1 < nchunks) {              // the next chunk's rows: landed (own DMA), read and split behind this chunk's MFMAs
+                d_wait_vm_rt(own_landed <= 16 ? own_landed : 0);
+                load_b(c + 1);
+            }
         } else {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {

@@ -198,6 +198,10 @@ int ldn_conv_rows_pool(const float* a, int lda, const int32_t* a_rows, const int
                        int Sx, int Ho, int Wo, int math_mode, void* stream);
 /* stats[r] = {mean, 1 / sqrt(biased variance + eps)} of row r of x [rows][ld >= C] (nn.LayerNorm's statistics), C % 4 == 0, C <= 2048 */
 int ldn_row_stats(const float* x, int ld, int rows, int C, float eps, float* stats, void* stream);
+/* the same for the rows list[0 .. *count) only (stats of the other rows are left untouched): the LayerNorm statistics of the tokens a
+ * token-skip block works on -- the rows of the others are never read */
+int ldn_row_stats_list(const float* x, int ld, int rows, int C, float eps, const int32_t* list, const int32_t* count, float* stats,
+                       void* stream);
 
 /* ---- a2: Masker_channel_MLP.forward, eval branch (models/utils.py:113-131) + index build ----
  * x [B,HW,C] NHWC -> global average pool -> Linear(C,hidden)+ReLU+Linear(hidden,2G) (hidden>0)

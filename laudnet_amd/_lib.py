@@ -38,6 +38,7 @@ SIGNATURES = {
     "ldn_conv_rows_f32": ([_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I,
                              _I, _I, _P, _P, _P], _I),
     "ldn_row_stats": ([_P, _I, _I, _I, C.c_float, _P, _P], _I),
+    "ldn_row_stats_list": ([_P, _I, _I, _I, C.c_float, _P, _P, _P, _P], _I),
     "ldn_channel_masker_splits": ([_I], _I),
     "ldn_channel_masker": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P], _I),
     "ldn_channel_masker_workspace_bytes": ([_I, _I, _I], C.c_size_t),

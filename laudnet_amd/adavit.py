@@ -81,7 +81,8 @@ class TokenSkipBlock(nn.Module):
         (wq, bq, cq), (wp, bp), (w1, b1, c1), (w2, b2) = self._weights(x2d.device)
         rows = x2d.shape[0]
         Lt = rows // B
-        st = ops.row_stats(x2d, self.norm1.eps)                                                 # {mean, rstd} of every token (norm1)
+        q_rows, q_count = qkv_rows if qkv_rows is not None and not self.qkv_kept_only else (tok_rows, count)
+        st = ops.row_stats(x2d, self.norm1.eps, rows=q_rows, count=q_count)                     # {mean, rstd} of the attending tokens (norm1)
         qkv = torch.empty(rows, 3 * self.dim, device=x2d.device, dtype=torch.float32)
         hk3 = None
         if head_keep is not None:     # [B, 3 * dim]: the head's decision over its 64 channels of q, k and v
@@ -89,7 +90,6 @@ class TokenSkipBlock(nn.Module):
             hk3 = hk.repeat_interleave(self.dim // self.heads, dim=1).repeat(1, 3).contiguous()
         # norm1 + q / k / v of the tokens that attend (the attention list: a dropped token is neither query nor key,
         # simulate_adavit.py:96-109) -- not of every token: at keep 0.5 that is half of the widest linear of the block
-        q_rows, q_count = qkv_rows if qkv_rows is not None and not self.qkv_kept_only else (tok_rows, count)
         m_rows, _, m_count = mlp_lists if mlp_lists is not None else (tok_rows, prefix, count)
         # list lengths of this block's previous forward (pinned memory, no synchronisation): the tile-width hint of the row kernels
         hint = getattr(self, "_rows_hint", None)
@@ -102,7 +102,7 @@ class TokenSkipBlock(nn.Module):
         att = ops.packed_mha(qkv, tok_rows, prefix, B, self.heads, max_tokens,
                              head_keep=None if head_keep is None else head_keep.float().reshape(B, self.heads).contiguous())   # [capacity, dim], packed
         ops.conv_rows(att, wp, None, bp, x2d, taps=1, m_count=count, m_cap=rows, relu=0, out_rows=tok_rows, residual2d=x2d, rows_hint=na)
-        st = ops.row_stats(x2d, self.norm2.eps)                                                 # norm2 (after the attention update)
+        st = ops.row_stats(x2d, self.norm2.eps, rows=m_rows, count=m_count)                     # norm2 (after the attention update)
         hid = torch.empty(rows, w1.shape[0], device=x2d.device, dtype=torch.float32)
         ops.conv_rows(x2d, w1, None, b1, hid, a_rows=m_rows, taps=1, m_count=m_count, m_cap=rows, relu=3, ln_stats=st, ln_c1=c1, rows_hint=nm)   # norm2 + fc1 + GELU
         ops.conv_rows(hid, w2, None, b2, x2d, taps=1, m_count=m_count, m_cap=rows, relu=0, out_rows=m_rows, residual2d=x2d, rows_hint=nm)

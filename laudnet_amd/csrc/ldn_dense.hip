@@ -512,9 +512,14 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
 
 // LayerNorm statistics of the rows of a [rows, C] matrix: stats[r] = {mean, 1 / sqrt(var + eps)} (biased variance, as nn.LayerNorm),
 // one wave per row, the row held in registers (two passes over registers, one over memory).
-__global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, int ld, int rows, int C, float eps, float* __restrict__ stats) {
+__global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, int ld, int rows, int C, float eps, float* __restrict__ stats,
+                                                    const int32_t* __restrict__ list, const int32_t* __restrict__ count) {
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (list) {      // only the listed rows (first *count entries): the tokens a token-skip block works on
+        if (r >= min(*count, rows)) return;
+        r = list[r];
+    }
     if (r >= rows) return;
     const float* xr = x + (size_t)r * ld;
     f32x4 v[8];     // C <= 2048 (ViT-H: 1280)
@@ -728,7 +733,20 @@ extern "C" int ldn_row_stats(const float* x, int ld, int rows, int C, float eps,
     LDN_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 2048 && ld >= C && ld % 4 == 0, "ldn_row_stats: C must be a multiple of 4, at most 2048 (got %d), ld >= C", C);
     LDN_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)stats % 8 == 0, "ldn_row_stats: pointers must be 16 / 8-byte aligned");
     if (rows == 0) return LDN_OK;
-    hipLaunchKernelGGL(ldn::k_row_stats, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, rows, C, eps, stats);
+    hipLaunchKernelGGL(ldn::k_row_stats, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, rows, C, eps, stats,
+                       nullptr, nullptr);
+    LDN_CHECK_LAUNCH("k_row_stats");
+    return LDN_OK;
+}
+
+extern "C" int ldn_row_stats_list(const float* x, int ld, int rows, int C, float eps, const int32_t* list, const int32_t* count, float* stats,
+                                  void* stream) {
+    LDN_REQUIRE(x && stats && list && count, "ldn_row_stats_list: null pointer");
+    LDN_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= 2048 && ld >= C && ld % 4 == 0, "ldn_row_stats_list: C must be a multiple of 4, at most 2048 (got %d), ld >= C", C);
+    LDN_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)stats % 8 == 0, "ldn_row_stats_list: pointers must be 16 / 8-byte aligned");
+    if (rows == 0) return LDN_OK;
+    hipLaunchKernelGGL(ldn::k_row_stats, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, rows, C, eps, stats,
+                       list, count);
     LDN_CHECK_LAUNCH("k_row_stats");
     return LDN_OK;
 }

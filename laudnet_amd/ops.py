@@ -324,10 +324,16 @@ def split_rows_weight(w):
     return hit[0]
 
 
-def row_stats(x2d, eps=1e-5):
-    """LayerNorm statistics of the rows of x2d [rows, C]: [rows, 2] = {mean, 1 / sqrt(biased var + eps)} (see ldn_row_stats)."""
+def row_stats(x2d, eps=1e-5, rows=None, count=None):
+    """LayerNorm statistics of the rows of x2d [rows, C]: [rows, 2] = {mean, 1 / sqrt(biased var + eps)} (see ldn_row_stats).
+    rows / count: only the listed rows (ldn_row_stats_list; the other entries of the result are uninitialised)."""
     L.require_device(x2d)
     st = torch.empty(x2d.shape[0], 2, device=x2d.device, dtype=torch.float32)
+    if rows is not None:
+        L.check(L.load().ldn_row_stats_list(L.ptr(_f32rows(x2d, "x")), x2d.stride(0), x2d.shape[0], x2d.shape[1], float(eps),
+                                            L.ptr(_i32c(rows, "rows")), L.ptr(_i32c(count, "count")), L.ptr(st), L.stream_ptr(x2d)),
+                "ldn_row_stats_list")
+        return st
     L.check(L.load().ldn_row_stats(L.ptr(_f32rows(x2d, "x")), x2d.stride(0), x2d.shape[0], x2d.shape[1], float(eps), L.ptr(st),
                                    L.stream_ptr(x2d)), "ldn_row_stats")
     return st

@@ -145,6 +145,11 @@ def test_layernorm_and_gelu_as_epilogue_terms(rows, cin, cout, gather):
         assert torch.allclose(st[:, 0].cpu().double(), mean, atol=1e-5) and torch.allclose(st[:, 1].cpu().double(), (var + 1e-5).rsqrt(), rtol=1e-5)
         wg = (w.double() * g.double().view(1, -1))
         src = torch.randperm(rows, generator=torch.Generator().manual_seed(3))[: rows // 2].to(torch.int32) if gather else None
+        if gather:     # ldn_row_stats_list: the listed rows only (the first `count` entries), same floats; the others untouched
+            lst = torch.cat((src, torch.zeros(7, dtype=torch.int32))).to(DEV)
+            st2 = ops.row_stats(x.to(DEV), 1e-5, rows=lst, count=torch.tensor([rows // 2], dtype=torch.int32, device=DEV))
+            assert torch.equal(st2[src.long().to(DEV)], st[src.long().to(DEV)])
+            st = st2
         n = rows // 2 if gather else rows
         out = torch.zeros(n, cout, device=DEV)
         ops.conv_rows(x.to(DEV), wg.float().reshape(cout, 1, cin).contiguous().to(DEV), None, (w.double() @ be.double() + b.double()).float().to(DEV),

@@ -1000,6 +1000,54 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
     unsigned long long h0, h1, h2, h3, h4, h5, hw = 0, hb = 0, hi_ = 0, hs = 0, hm = 0, hstart;
     TT(hstart)
 #endif
+    // B operands of both K16 steps of a chunk (this wave's 32 pixels), split once for all of the image's n-subtiles.  The rows are staged by
+    // THIS wave's own four DMA pieces (the first of its chunk), so they need its vmcnt only -- the workgroup barrier is for the weight
+    // rows.  PRE (-DLDN_HEAD_PRE, off): chunk c + 1's rows read and split right behind chunk c's MFMA steps, off the barrier -> first-MFMA path.
+    bf16x8 bh[2], bl[2];
+    auto load_b = [&](int c) {
+        const unsigned char* xs = s_ring + (c % D) * slot_bytes;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned sl = 4u * half + 2u * h;          // logical 16-byte slot of this lane's 8 k values (x: fp32 k .. k+3, k+4 .. k+7)
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
+            if constexpr (F32) {     // raw floats: k-slots 0-3 / 4-7
+                bh[half] = __builtin_bit_cast(bf16x8, x0);
+                bl[half] = __builtin_bit_cast(bf16x8, x1);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = e < 4 ? x0[e] : x1[e - 4];
+                    const __bf16 hb = (__bf16)v;
+                    bh[half][e] = hb;
+                    bl[half][e] = (__bf16)(v - (float)hb);
+                }
+            }
+        }
+        if (!F32 && p.xs && (int)xrow < npix) {
+            // the split x fragments ARE whole octets of the pre-split format: lane (pixel, h), K16 half `half` of chunk c = octet 4 c + 2 half + h.
+            // (Stores share vmcnt with the LDS-DMA: the counted waits then ask for MORE completions than they need -- safe.)
+            // TILED layout (tiles of 32 consecutive pixels of the flat batch): [tile][K16 step s][h][hi | lo][pixel % 32][16 B] -- the
+            // consumer's B-fragment load (lane = pixel, fixed s / h / plane) then covers two contiguous 512-byte runs
+            const long q = row0 + xrow;
+            unsigned char* xo_ = p.xs + (q >> 5) * ((long)p.cin * 128) + (q & 31) * 16 + h * 1024;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                *reinterpret_cast<bf16x8*>(xo_ + (2 * c + half) * 2048) = bh[half];
+                *reinterpret_cast<bf16x8*>(xo_ + (2 * c + half) * 2048 + 512) = bl[half];
+            }
+        }
+    };
+#ifdef LDN_HEAD_PRE      // measured on the headline (three interleaved pairs): 12.03 vs 11.92 ms WITHOUT it -- the chained kernel's register allocation
+    constexpr bool PRE = true;      // again (4r); off.  (The same move pays in k_dense, csrc/ldn_dense.hip.)
+#else
+    constexpr bool PRE = false;
+#endif
+    const int own_landed = per_chunk * (D - 1) - 4;      // own rows of the oldest chunk in flight = its first four pieces
+    if (PRE && active && nchunks > 0) {
+        wait_vm_rt(own_landed);
+        load_b(0);
+    }
     for (int c = 0; c < nchunks; ++c) {
         TT(h0)
         wait_vm_rt(per_chunk * (D - 2));     // chunk c has landed; the D - 2 chunks issued after it may still fly
@@ -1012,46 +1060,13 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
         TT(h3)
         TT_ADD(hw, h0, h1) TT_ADD(hb, h1, h2) TT_ADD(hi_, h2, h3)
         if (!active) continue;
-        const unsigned char* xs = s_ring + (c % D) * slot_bytes;
-        const unsigned char* ws = xs + xrows * 128;
-        // B operands of both K16 steps of the chunk (this wave's 32 pixels), split once for all of the image's n-subtiles
-        bf16x8 bh[2], bl[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const unsigned sl = 4u * half + 2u * h;          // logical 16-byte slot of this lane's 8 k values (x: fp32 k .. k+3, k+4 .. k+7)
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
-            if constexpr (F32) {     // raw floats: k-slots 0-3 / 4-7
-                bh[half] = __builtin_bit_cast(bf16x8, x0);
-                bl[half] = __builtin_bit_cast(bf16x8, x1);
-            } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = e < 4 ? x0[e] : x1[e - 4];
-                const __bf16 hb = (__bf16)v;
-                bh[half][e] = hb;
-                bl[half][e] = (__bf16)(v - (float)hb);
-            }
-            }
-        }
+        const unsigned char* ws = s_ring + (c % D) * slot_bytes + xrows * 128;
+        if (!PRE) load_b(c);
 #ifdef LDN_TRACE
         asm volatile("" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
         TT(h4)
         TT_ADD(hs, h3, h4)
 #endif
-        if (!F32 && p.xs && (int)xrow < npix) {
-            // the split x fragments ARE whole octets of the pre-split format: lane (pixel, h), K16 half `half` of chunk c = octet 4 c + 2 half + h.
-            // (Stores share vmcnt with the LDS-DMA: the counted waits above then ask for MORE completions than they need -- safe.)
-            // TILED layout (tiles of 32 consecutive pixels of the flat batch): [tile][K16 step s][h][hi | lo][pixel % 32][16 B] -- the
-            // consumer's B-fragment load (lane = pixel, fixed s / h / plane) then covers two contiguous 512-byte runs
-            const long q = row0 + xrow;
-            unsigned char* xo_ = p.xs + (q >> 5) * ((long)p.cin * 128) + (q & 31) * 16 + h * 1024;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                *reinterpret_cast<bf16x8*>(xo_ + (2 * c + half) * 2048) = bh[half];
-                *reinterpret_cast<bf16x8*>(xo_ + (2 * c + half) * 2048 + 512) = bl[half];
-            }
-        }
         // The image's n-subtiles in DESCENDING order as ONE linear, software-pipelined sequence with an entry point per subtile count
         // (a switch that falls through: no duplicated code, every accumulator keeps its registers).  Step j = the two K16 halves of
         // subtile j; a weight fragment is two ds_read_b128 (8 hi | 8 lo of row 32 j + l31, no VALU), double-buffered in a0 / a1: the
@@ -1108,6 +1123,10 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
             }
         }
 #undef LDN_HEAD_STEP
+        if (PRE && c + 1 < nchunks) {
+            wait_vm_rt(own_landed);
+            load_b(c + 1);
+        }
 #ifdef LDN_TRACE
         asm volatile("" : "+v"(acc[0]));
         TT(h5)

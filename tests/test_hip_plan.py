@@ -315,3 +315,26 @@ def test_fused_layer_masker_whole_model(ops):
     flips = [i for i, (a, b) in enumerate(zip(outs[False][1], outs[True][1])) if not torch.equal(a, b)]
     assert not flips, f"decisions differ at blocks {flips} (a tie between the two summation orders of the pooled means?)"
     assert torch.equal(outs[True][0], outs[False][0])
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(25000, 384, 384), (42000, 1024, 256), (6000, 512, 512)])
+def test_tile_width_hint_never_changes_results(ops, rows, cin, cout):
+    """ldn_hint_rows (ops.conv_rows(rows_hint=...)) selects the tile width of k_dense from a cost model -- 64 / 128 / 192 /
+    256-column tiles here; every output element's K loop is the same in every shape: bit-identical outputs whatever the hint says
+    (missing, exact, far too small, far too large)."""
+    cap = 2 * rows
+    a = seeded_randn((cap, cin), 3).to(DEV)
+    w = (seeded_randn((cout, 1, cin), 4) * 0.05).to(DEV)
+    t = seeded_randn((cout,), 5).to(DEV)
+    cnt = torch.tensor([rows], dtype=torch.int32, device=DEV)
+    outs = []
+    for hint in (None, rows, 100, cap, 3 * rows // 2):
+        out = torch.zeros(cap, cout, device=DEV)
+        ops.conv_rows(a, w, None, t, out, taps=1, m_count=cnt, m_cap=cap, relu=1, rows_hint=hint)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert float(outs[0][rows:].abs().max()) == 0.0 and float(outs[0][:rows].abs().max()) > 0.0
+    want = torch.relu(a[:64].double() @ w[:, 0].double().t() + t.double())
+    assert torch.allclose(outs[0][:64].double(), want, atol=2e-4, rtol=1e-4)

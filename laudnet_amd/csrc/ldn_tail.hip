@@ -913,7 +913,7 @@ __device__ __forceinline__ const void* uniform_cptr(const void* v) {
 
 constexpr int H_XROWS = 256;                          // rows of the x tile of a ring slot (pixels of the block, padded)
 
-template <int NS, bool F32 = false>
+template <int NS, bool F32 = false, bool PRE_ROWS = false>
 __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const int mb, unsigned char* const smem, const int lds_total, const int tid) {
     constexpr int W = NS * 32;
     int* const s_nidx = reinterpret_cast<int*>(smem);                    // [W + 32]
@@ -1002,7 +1002,7 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
 #endif
     // B operands of both K16 steps of a chunk (this wave's 32 pixels), split once for all of the image's n-subtiles.  The rows are staged by
     // THIS wave's own four DMA pieces (the first of its chunk), so they need its vmcnt only -- the workgroup barrier is for the weight
-    // rows.  PRE (-DLDN_HEAD_PRE, off): chunk c + 1's rows read and split right behind chunk c's MFMA steps, off the barrier -> first-MFMA path.
+    // rows.  PRE_ROWS: chunk c + 1's rows are read and split right behind chunk c's MFMA steps, off the barrier -> first-MFMA path.
     bf16x8 bh[2], bl[2];
     auto load_b = [&](int c) {
         const unsigned char* xs = s_ring + (c % D) * slot_bytes;
@@ -1038,11 +1038,9 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
             }
         }
     };
-#ifdef LDN_HEAD_PRE      // measured on the headline (three interleaved pairs): 12.03 vs 11.92 ms WITHOUT it -- the chained kernel's register allocation
-    constexpr bool PRE = true;      // again (4r); off.  (The same move pays in k_dense, csrc/ldn_dense.hip.)
-#else
-    constexpr bool PRE = false;
-#endif
+    // Inside the chained kernel it measured SLOWER on the headline (three interleaved pairs: 12.03 vs 11.92 ms -- the register allocation of
+    // the 14 k-instruction kernel again), so k_chain instantiates PRE_ROWS = false; the stand-alone k_head takes it.
+    constexpr bool PRE = PRE_ROWS;
     const int own_landed = per_chunk * (D - 1) - 4;      // own rows of the oldest chunk in flight = its first four pieces
     if (PRE && active && nchunks > 0) {
         wait_vm_rt(own_landed);
@@ -1192,7 +1190,11 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
 template <int NS, bool F32 = false>
 __global__ __launch_bounds__(512, 2) void k_head(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    head_body<NS, F32>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, 160 * 1024, threadIdx.x);
+#ifdef LDN_HEAD_NO_PRE
+    head_body<NS, F32, false>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, 160 * 1024, threadIdx.x);
+#else
+    head_body<NS, F32, true>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, 160 * 1024, threadIdx.x);
+#endif
 }
 
 template <int NS, bool F32 = false>

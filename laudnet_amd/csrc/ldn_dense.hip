@@ -402,10 +402,17 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
         sc = (p.scale && cok) ? *reinterpret_cast<const f32x4*>(p.scale + cb) : f32x4{1.f, 1.f, 1.f, 1.f};
         ps = (p.post_sub && cok) ? *reinterpret_cast<const f32x4*>(p.post_sub + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
+#ifdef LDN_TRACE_EPI
+    unsigned long long e0, e1, e2, e3, e4, ea = 0, eb = 0, ec = 0, ed = 0;
+#define ET(x) x = __builtin_amdgcn_s_memtime();
+#else
+#define ET(x)
+#endif
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
         if (j >= nsub) continue;
         f32x4 res[4], sc, sh, ps;
+        ET(e0)
         load_res(j, res, sc, sh, ps);
         f32x4 cm[4];
         const bool cok = FULL || n0 + 32 * j + tc * 4 < p.cout;
@@ -433,10 +440,12 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        ET(e1)
         // residual / scale / shift registers touched before the first store (gfx9: a load first used after a store waits vmcnt(0)
         // for that store's acknowledgement)
         asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sc), "+v"(sh), "+v"(ps));
         asm volatile("" : "+v"(cm[0]), "+v"(cm[1]), "+v"(cm[2]), "+v"(cm[3]));
+        ET(e2)
         f32x4 xs4[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -497,10 +506,20 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
                 if (poff >= 0) *reinterpret_cast<f32x4*>(p.pool + poff + n0 + 32 * j + tc * 4) = m;
             }
         }
+        ET(e3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+#ifdef LDN_TRACE_EPI
+        ET(e4)
+        ea += e1 - e0; eb += e2 - e1; ec += e3 - e2; ed += e4 - e3;
+#endif
     }
-#ifdef LDN_TRACE
+#ifdef LDN_TRACE_EPI
+    if (g_dense_trace && lane == 0) {
+        unsigned long long* r = g_dense_trace + ((size_t)blockIdx.x * 8 + wave) * 8;
+        r[0] = ea; r[1] = eb; r[2] = ec; r[3] = ed; r[4] = 0; r[5] = 1; r[6] = ea + eb + ec + ed; r[7] = nchunks;
+    }
+#elif defined(LDN_TRACE)
     if (g_dense_trace && lane == 0) {
         unsigned long long dend;
         DT(dend)

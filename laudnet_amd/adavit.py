@@ -1,8 +1,9 @@
 """Token skipping on the HIP path (BASELINE config 5: AdaViT / DeiT-S shaped blocks, "dynamic-token packed MHA").
 
 The reference ships no model for this configuration, only the latency model of its operators
-(DyNetSimulator/adavit/simulate_adavit.py:77-182): q / k / v for every token, attention among the SELECTED tokens, projection /
-MLP / residual updates on the selected tokens only.  This module executes that operator list on PACKED token lists with the
+(DyNetSimulator/adavit/simulate_adavit.py:77-182): q / k / v, attention among the SELECTED tokens, projection /
+MLP / residual updates on the selected tokens only (the latency model prices q / k / v on every token, :90-93; a dropped token is neither
+query nor key, so they are computed for the attending tokens only -- TokenSkipBlock.qkv_kept_only).  This module executes that operator list on PACKED token lists with the
 kernels of libldn_hip.so: the keep mask becomes a row list (ldn_mask_to_index on a [B, L, 1] mask), the linears are the packed-row
 1x1 kernel (k_dense: gather rows in, scatter-add rows out, fused bias + residual), the attention is ldn_packed_mha (one workgroup
 per image and head over the image's kept tokens).  HEAD skipping (a per-image head mask: q / k / v masked in the linear's epilogue, the
@@ -115,7 +116,12 @@ class TokenSkipBlock(nn.Module):
         B, Lt = keep.shape
         ka = keep if attn_keep is None else keep * attn_keep.view(B, 1).to(keep.dtype)
         a_list = ops.token_lists(ka.contiguous())
-        m_list = None if mlp_keep is None else ops.token_lists((keep * mlp_keep.view(B, 1).to(keep.dtype)).contiguous())
+        # the MLP sub-block has its OWN list whenever either decision is given: with attn_keep alone the attention list above has lost the
+        # images whose attention is skipped, but their MLP still runs (mlp_keep None = run: the MLP list is then the plain token list)
+        if mlp_keep is not None:
+            m_list = ops.token_lists((keep * mlp_keep.view(B, 1).to(keep.dtype)).contiguous())
+        else:
+            m_list = None if attn_keep is None else ops.token_lists(keep.contiguous())
         q_rows = None
         if attn_keep is not None:
             r, _, c = ops.token_lists(attn_keep.view(B, 1).to(keep.dtype).expand(B, Lt).contiguous())
@@ -141,6 +147,11 @@ class TokenSkipViT(nn.Module):
     def __init__(self, depth=12, dim=384, heads=6, mlp_ratio=4.0):
         super().__init__()
         self.blocks = nn.ModuleList(TokenSkipBlock(dim, heads, mlp_ratio) for _ in range(depth))
+
+    @staticmethod
+    def blocks_qkv_kept_only():
+        """Do the blocks compute q / k / v for the attending tokens only (the class-level switch of TokenSkipBlock)?"""
+        return bool(TokenSkipBlock.qkv_kept_only)
 
     def forward(self, x, keeps, head_keeps=None, attn_keeps=None, mlp_keeps=None):
         """keeps[i] [B, L]; optional per-block head_keeps[i] [B, heads], attn_keeps[i] / mlp_keeps[i] [B] (head / layer skipping)."""

@@ -321,22 +321,32 @@ __global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ pa
 // ---- round 4: decision + counts + prefix over the images + lists in ONE launch (k_plan) -------------------------------------------
 // k_mask_count + k_mask_index were two launches because image b's first packed position is the sum of the counts of the images in
 // front of it.  Here workgroup b publishes its three counts (+ 1, so that 0 means "not yet") and waits for the counts of the
-// workgroups in front of it, which were dispatched before it; the waiting loop is bounded (a failed wait leaves the lists
-// unwritten and the counts 0, never a hang).
+// workgroups in front of it, which were dispatched before it; the waiting loop is bounded in TIME (never a hang).  A failed wait is
+// safe and loud: the workgroup raises the launch's failure word sync[0] BEFORE anything else and counts the event
+// in g_plan_timeouts (sticky, ldn_plan_timeouts()); every workgroup re-reads sync[0] at its very end, after its own writes of the
+// counts / prefixes have been acknowledged (write-through stores + vmcnt(0)), and a workgroup that finds it raised -- as well as the
+// failing one -- zeroes cnt, stats and EVERY prefix.  Whatever the interleaving, the last write to each of those words is a zero
+// (a successful workgroup either checked after the flag went up and zeroes behind its own values, or finished its writes before the
+// flag went up and the failing workgroup zeroes behind them): consumers see empty lists, never uninitialised rows or prefixes.
 // Two extras of the fused spatial path (models/utils.py:47-65 behind conv3's epilogue):
 //   * decide mode (patch == nullptr): the patch decisions come from the POOLED CHANNEL MEANS [B][S*Sx][C] (the stand-alone masker's
 //     `pool_work`, refreshed by the previous block's conv3 epilogue) -- k_spatial_masker's head, same arithmetic, no read of x;
 //   * patch_major: idx3 lists the kept pixels patch by patch (row-major inside a patch) instead of row-major over the image, so
 //     that the rows of one patch are contiguous in the packed tensors (conv3's epilogue then owns whole patches).  Same SET of
 //     pixels, same counts / prefixes / statistics; pos3 / nbr follow the order.  Even grids only (Ho % S == 0, Wo % Sx == 0).
+__device__ unsigned g_plan_timeouts = 0u;      // launches' failed prefix waits since the last reset (release builds too)
+#ifdef LDN_DEBUG
+__device__ int g_plan_stall = -1;              // test hook (ldn_debug_plan_stall): this image never publishes its counts
+#endif
 struct PlanArgs {
     IdxGeom g;
     int patch_major;
     const float* patch;
     const float* pool; int C; const float* w; const float* bias; float* mask_out; float* logits;
-    int32_t* sync;                 // [1 + 3 B], zeroed in front of the launch: (unused word); per image count3 + 1, count1 + 1, patches + 1
+    int32_t* sync;                 // [1 + 3 B], zeroed in front of the launch: failure word; per image count3 + 1, count1 + 1, patches + 1
     int32_t *idx3, *pos3, *idx1, *pos1, *nbr, *cnt, *pre3, *pre1;
     float* stats;
+    long long timeout_ticks;       // bound of the prefix wait in wall_clock64() ticks (100 MHz); set by launch_plan
 };
 
 // (the flags are read and written with relaxed agent-scope atomics: the flag IS the payload, nothing else is published through it --
@@ -445,10 +455,16 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
         }
     }
     __syncthreads();
-    if (tid < 3) __hip_atomic_store(&a.sync[1 + tid * g.B + b], s_red[tid] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef LDN_DEBUG
+    const bool publish = b != g_plan_stall;
+#else
+    constexpr bool publish = true;
+#endif
+    if (tid < 3 && publish) __hip_atomic_store(&a.sync[1 + tid * g.B + b], s_red[tid] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // 3. exclusive prefix over the images in front of this one
     {
         int a3 = 0, a1 = 0, ap = 0, failed = 0;
+        long long t_start = 0;
         for (int i = tid; i < b; i += NT) {
             int v3, v1, vp, n = 0;
             for (;;) {             // the three loads are in flight together (each is a trip to the coherence point)
@@ -457,7 +473,11 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
                 vp = __hip_atomic_load(&a.sync[1 + 2 * g.B + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (v3 != 0 && v1 != 0 && vp != 0) break;
                 __builtin_amdgcn_s_sleep(4);
-                if (++n > (1 << 18)) { failed = 1; v3 = v1 = vp = 1; break; }
+                if ((++n & 255) == 0) {           // bounded in wall-clock time (a constant 100 MHz counter), looked at every 256 polls
+                    const long long now = (long long)wall_clock64();
+                    if (t_start == 0) t_start = now;
+                    else if (now - t_start > a.timeout_ticks) { failed = 1; v3 = v1 = vp = 1; break; }
+                }
             }
             a3 += v3 - 1; a1 += v1 - 1; ap += vp - 1;
         }
@@ -470,23 +490,39 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
         }
     }
     __syncthreads();
-    if (s_fail) {                   // (never observed: a predecessor that did not publish within ~1 s) no list is written, the counts read 0
-        if (tid == 0) { a.cnt[0] = 0; a.cnt[1] = 0; }
+    // every word a consumer sizes its work by (cnt, stats, all prefixes) zeroed by one wave: the failure path (see the header comment)
+    auto poison = [&]() {
+        for (int i = lane; i <= g.B; i += 64) {
+            __hip_atomic_store(&a.pre3[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.pre1[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane < 2) __hip_atomic_store(&a.cnt[lane], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 3) __hip_atomic_store(reinterpret_cast<int*>(a.stats) + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (s_fail) {                   // (never observed outside the test hook: a predecessor that did not publish within the bound)
+        if (wave == 0) {
+            if (lane == 0) {        // flag first, then the zeroes
+                __hip_atomic_store(&a.sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&g_plan_timeouts, 1u);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            poison();
+        }
         return;
     }
     const int base3 = s_base[0], base1 = s_base[1], own3 = s_red[0];
-    if (tid == 0) {
-        a.pre3[b] = base3;
-        a.pre1[b] = base1;
+    if (tid == 0) {                 // write-through (agent-scope) stores: acknowledged at the coherence point before the end check below
+        __hip_atomic_store(&a.pre3[b], base3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.pre1[b], base1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b == g.B - 1) {
             const int tot3 = base3 + own3, tot1 = base1 + s_red[1];
-            a.pre3[g.B] = tot3;
-            a.pre1[g.B] = tot1;
-            a.cnt[0] = tot3;
-            a.cnt[1] = tot1;
-            a.stats[0] = (float)(s_base[2] + s_red[2]) / (float)((long)g.B * SS);
-            a.stats[1] = (float)tot3 / (float)((long)g.B * HWo);
-            a.stats[2] = (float)tot1 / (float)((long)g.B * HWi);
+            __hip_atomic_store(&a.pre3[g.B], tot3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.pre1[g.B], tot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.cnt[0], tot3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.cnt[1], tot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.stats[0], (float)(s_base[2] + s_red[2]) / (float)((long)g.B * SS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.stats[1], (float)tot3 / (float)((long)g.B * HWo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.stats[2], (float)tot1 / (float)((long)g.B * HWi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // 4. ordered compaction of the kept output pixels (row-major, or patch by patch) and of the dilated input pixels
@@ -540,6 +576,11 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
         const bool inb = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
         LDN_DCHECK(!inb || s_pos1[iy * g.Wi + ix] >= 0, 203);
         a.nbr[(size_t)base3 * 9 + e] = inb ? s_pos1[iy * g.Wi + ix] : -1;
+    }
+    // 6. end check (wave 0, behind the acknowledgement of its own stores): did ANY workgroup of this launch fail its prefix wait?
+    if (wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__hip_atomic_load(&a.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) poison();
     }
 }
 
@@ -1045,6 +1086,30 @@ extern "C" int ldn_debug_violations(int* count, int* first_code, int reset) {
 #endif
 }
 
+// Prefix waits of ldn_mask_plan / ldn_mask_to_index launches that ran into their time bound since the last reset (0 on a healthy
+// device).  Such a launch leaves EMPTY lists (counts, prefixes and statistics zero), never uninitialised ones; this counter is how a
+// caller finds out.  Synchronises the device.
+extern "C" int ldn_plan_timeouts(int* count, int reset) {
+    LDN_REQUIRE(count != nullptr, "ldn_plan_timeouts: null pointer");
+    if (hipDeviceSynchronize() != hipSuccess) { set_error("ldn_plan_timeouts: device error"); return LDN_EHIP; }
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_plan_timeouts), sizeof(v)) != hipSuccess) { set_error("ldn_plan_timeouts: cannot read the counter"); return LDN_EHIP; }
+    *count = (int)v;
+    if (reset && v) {
+        const unsigned z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_plan_timeouts), &z, sizeof(z)) != hipSuccess) { set_error("ldn_plan_timeouts: cannot reset the counter"); return LDN_EHIP; }
+    }
+    return LDN_OK;
+}
+
+#ifdef LDN_DEBUG
+// test hook of the debug build: workgroup `image` of every following k_plan launch never publishes its counts, so the workgroups
+// behind it run into the time bound (-1 = off)
+extern "C" int ldn_debug_plan_stall(int image) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_plan_stall), &image, sizeof(image)) == hipSuccess ? LDN_OK : LDN_EHIP;
+}
+#endif
+
 extern "C" int ldn_device_cus(int* cus) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1136,6 +1201,10 @@ static int launch_plan(PlanArgs& a, int32_t* work, hipStream_t st) {
     const size_t lds = plan_lds(g.S, g.Sx, g.Ho, g.Wo, g.stride);
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_plan), lds), "k_plan: cannot reserve %zu B of LDS", lds);
     a.sync = work;
+    // bound of the prefix wait: 2 s by default (a predecessor workgroup of the SAME launch publishes within microseconds of its start;
+    // only a queue pre-empted for that long could exceed it); LDN_PLAN_TIMEOUT_MS overrides (tests)
+    static const long timeout_ms = getenv("LDN_PLAN_TIMEOUT_MS") ? atol(getenv("LDN_PLAN_TIMEOUT_MS")) : 2000;
+    a.timeout_ticks = (long long)timeout_ms * 100000ll;
     // the flag words are zeroed by a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph faulted on the second replay
     // of the graph (ROCm 7.2, measured: tools/experiments/repro_graph.py), a kernel node replays fine
     const int nsync = 3 * g.B + 1;

@@ -114,3 +114,72 @@ def recompute_for(model, x_shape):
     """The `recompute` callable for a laudnet_amd model and an input shape [B_local, C, H, W] (the per-image FLOPs table does
     not depend on the batch size)."""
     return lambda s3, s2, s1, cs: model.flops_from_sparsities(tuple(x_shape), s3, s2, s1, cs)
+
+
+def broadcast_state(module, src: int = 0, group=None):
+    """Every parameter and buffer of `module` becomes rank `src`'s (replicated weights really are replicas: e.g. maskers calibrated
+    per rank on different shards).  The reference loads ONE checkpoint on every rank (train/main.py:187).  Prepared (folded / split)
+    weight caches of the modules are dropped so that the next forward re-derives them from the broadcast tensors."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
+                dist.broadcast(t.data, src=src, group=group)
+    for m in module.modules():
+        drop = getattr(m, "_drop_cache", None)
+        if callable(drop):
+            drop()
+
+
+def ranks_seen(device=None, group=None) -> int:
+    """all_reduce(SUM) of a one: how many ranks the backend's collective really spans (the JSON line of bench.py carries it)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    t = torch.ones(1, device=device if device is not None else "cpu", dtype=torch.float32)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(round(float(t.item())))
+
+
+def gpu_numa_node(local_rank: int):
+    """NUMA node of the local_rank-th visible AMD GPU from sysfs (/sys/class/drm/card*/device/numa_node), or None when the platform
+    does not say (single-node hosts report -1)."""
+    import glob
+    cards = []
+    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if open(os.path.join(d, "vendor")).read().strip() != "0x1002":      # AMD
+                continue
+            cards.append(int(open(os.path.join(d, "numa_node")).read().strip()))
+        except (OSError, ValueError):
+            continue
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    idx = local_rank
+    if vis:
+        try:
+            idx = int(vis.split(",")[local_rank])
+        except (ValueError, IndexError):
+            idx = local_rank
+    if idx >= len(cards) or cards[idx] < 0:
+        return None
+    return cards[idx]
+
+
+def pin_to_gpu_numa_node(local_rank: int):
+    """Restrict this process to the CPUs of its GPU's NUMA node (os.sched_setaffinity): with one process per GPU the launch path of every
+    rank then runs next to its device instead of wherever the scheduler put it.  Returns the node, or None if nothing was changed."""
+    node = gpu_numa_node(local_rank)
+    if node is None:
+        return None
+    try:
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            return node
+    except (OSError, ValueError):
+        pass
+    return None

@@ -725,6 +725,8 @@ class Bottleneck(_PrepCache):
         ix = None
         fresh = (pS is not None and carry_in is not None and len(carry_in) > 4 and carry_in[4] and carry_in[0] is not None
                  and tuple(carry_in[2] or ()) == (B, Hi, Wi, Cin, pS))
+        # (tests / bench audits) did this block's decision come from the pooled means the previous block's conv3 epilogue left?
+        self.last_fused_decision = bool(fresh) and self.forced_spatial_mask is None
         if self.forced_spatial_mask is not None:
             patch = self.forced_spatial_mask.to(device=x.device, dtype=torch.float32).contiguous()
         elif fresh and layer:

@@ -150,6 +150,17 @@ def _empty_index(B, out_h, out_w, stride, dev):
     return ix, work
 
 
+def plan_timeouts(reset=False, raise_on_error=False):
+    """Prefix waits of the one-launch list build that ran into their time bound since the last reset (ldn_plan_timeouts; 0 on a
+    healthy device; such a launch leaves EMPTY lists, never uninitialised ones).  Synchronises the device."""
+    import ctypes
+    n = ctypes.c_int(0)
+    L.check(L.load().ldn_plan_timeouts(ctypes.byref(n), 1 if reset else 0), "ldn_plan_timeouts")
+    if raise_on_error and n.value:
+        raise L.LdnError(f"{n.value} list-build launches ran into their time bound: their blocks saw empty pixel lists (results invalid)")
+    return n.value
+
+
 def mask_plan_fits(S, Sx, out_h, out_w, stride=1):
     """Whether the one-launch list build (ldn_mask_plan) holds a map of this size (per-image tables in one workgroup's LDS)."""
     return bool(L.load().ldn_mask_plan_fits(S, Sx, out_h, out_w, stride))

@@ -3,7 +3,8 @@
 BASELINE config 5 ("AdaViT / DeiT-S token skipping") has NO model code in the reference: only the latency formulas of
 DyNetSimulator/adavit/simulate_adavit.py:77-182 (the arithmetic lives in the un-vendored external repo MengLcool/AdaViT, no pinned
 version).  What those formulas fix is the operator list of a block with token skipping:
-  layernorm -> q / k / v linears on EVERY token (:90-93) -> attention [B, heads, L_select, d] among the SELECTED tokens (:113-121)
+  layernorm -> q / k / v linears (priced on EVERY token by the latency model, :90-93; only the selected tokens' q / k / v are ever
+  used: this dense restatement computes all of them, the packed execution computes the selected ones -- same results) -> attention [B, heads, L_select, d] among the SELECTED tokens (:113-121)
   -> output projection on the selected tokens (:123-133) -> residual add on them (:169-171) -> layernorm -> fc1 / GELU / fc2 on the
   selected tokens (:136-150) -> residual add (:173-177); tokens that are not selected keep their value.  Head skipping (:81-88: attention
   over the selected heads of an image) and layer skipping (:140-182: the attention / MLP sub-block of an image runs or not) are per-image

@@ -135,3 +135,50 @@ def test_rccl_two_rank_bench_line():
     assert line["n_gpus"] == 2 and line["config"]["backend"] == "nccl" and line["config"]["world_size"] == 2
     assert line["config"]["global_batch"] == 64 and line["value"] > 0
     assert 0.2 < line["config"]["mean_block_flops_ratio"] < 0.9     # the all-reduced sparsities are global-batch means, not garbage
+
+
+def _bcast_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    sys.path.insert(0, ROOT)
+    import laudnet_amd
+    from laudnet_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    model = laudnet_amd.uni_resnet50(**KW).eval()
+    with torch.no_grad():      # every rank "calibrates" differently, as bench.py's ranks do on their own shards
+        for p in model.parameters():
+            p.add_(float(rank + 1))
+        model.layer1[0].bn1.running_mean.fill_(float(rank + 5))
+    blk = model.layer1[0]
+    blk._cache_store({"stale": rank})          # a prepared-weight cache derived from the pre-broadcast weights
+    assert blk._cache_valid()
+    D.broadcast_state(model, src=0)
+    seen = D.ranks_seen()
+    torch.save({"sd": {k: v.clone() for k, v in model.state_dict().items()}, "seen": seen, "cache_valid": blk._cache_valid()},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_state_makes_replicas_and_counts_ranks(tmp_path):
+    """the ranks of bench.py calibrate their maskers on their own shards; rank 0's weights are broadcast so
+    that the replicas ARE replicas, prepared-weight caches are dropped, and the JSON line's `rccl_ranks_seen` is an all-reduce of ones."""
+    world = 2
+    mp.spawn(_bcast_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(str(tmp_path / "rank0.pt"), weights_only=False)
+    r1 = torch.load(str(tmp_path / "rank1.pt"), weights_only=False)
+    assert r0["seen"] == r1["seen"] == world
+    assert not r0["cache_valid"] and not r1["cache_valid"]
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    assert float(r1["sd"]["layer1.0.bn1.running_mean"][0]) == 5.0       # rank 0's value
+
+
+def test_numa_helpers_do_not_fail_without_gpus():
+    from laudnet_amd import distributed as D
+    before = os.sched_getaffinity(0)
+    node = D.pin_to_gpu_numa_node(0)          # no AMD GPU / no NUMA information here: nothing changes, None is returned
+    assert node is None or isinstance(node, int)
+    if node is None:
+        assert os.sched_getaffinity(0) == before
+    os.sched_setaffinity(0, before)

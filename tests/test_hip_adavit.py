@@ -204,3 +204,36 @@ def test_head_and_layer_skipping_vs_oracle(B, L, dim, heads):
     scale = max(1.0, want.abs().max().item())
     assert (got - want).abs().max().item() < 2e-4 * scale, (got - want).abs().max().item()
     assert (one - want1).abs().max().item() < 1e-4 * max(1.0, want1.abs().max().item())
+
+
+@pytest.mark.parametrize("which", ["attn_only", "mlp_only"])
+def test_layer_skipping_with_one_decision_only(which):
+    """attn_keep WITHOUT mlp_keep (and the reverse).  None means "the sub-block runs": an image whose attention is
+    skipped still gets its MLP update (oracle/adavit_ref.py: km = keep when mlp_keep is None), and vice versa."""
+    from laudnet_amd import ops
+    from laudnet_amd.adavit import TokenSkipBlock
+    B, L, dim, heads = 6, 40, 128, 2
+    ref = AR.TokenSkipBlockRef(dim, heads).eval()
+    torch.manual_seed(17)
+    for p_ in ref.parameters():
+        if p_.dim() > 1:
+            torch.nn.init.normal_(p_, std=0.05)
+    hip = TokenSkipBlock(dim, heads).eval()
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(DEV)
+    x = seeded_randn((B, L, dim), 52)
+    keep = _keep(B, L, 0.5, 61)
+    dec = seeded_bernoulli((B,), 0.5, 62)
+    dec[0], dec[1] = 0.0, 1.0
+    kw = dict(attn_keep=dec) if which == "attn_only" else dict(mlp_keep=dec)
+    with torch.no_grad():
+        want = ref(x, keep, None, kw.get("attn_keep"), kw.get("mlp_keep"))
+    ops.set_math_mode("bf16x3")
+    try:
+        with torch.no_grad():
+            got = hip(x.to(DEV), keep.to(DEV), **{k: v.to(DEV) for k, v in kw.items()}).cpu()
+    finally:
+        ops.set_math_mode("fp32")
+    # image 0 skips one sub-block and must still be updated by the other
+    assert not torch.equal(got[0], x[0])
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), (got - want).abs().max().item()

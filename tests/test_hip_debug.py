@@ -83,3 +83,66 @@ def test_debug_build_audits_index_lists():
     assert dbg["logits"] == rel["logits"], "debug and release builds must compute identical results"
     n, code = dbg["corrupted"]
     assert n > 0 and 300 <= code < 400, f"the corrupted channel list was not flagged by the fused tail's checks: {dbg['corrupted']}"
+
+
+STALL_SCRIPT = r"""
+import ctypes, json, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests/golden")
+import torch
+from laudnet_amd import _lib, ops
+from fill import seeded_bernoulli
+lib = _lib.load()
+ops.set_math_mode("bf16x3")
+stall = lib.ldn_debug_plan_stall
+stall.argtypes, stall.restype = [ctypes.c_int], ctypes.c_int
+B, S, Ho = 12, 7, 28
+patch = seeded_bernoulli((B, S, S), 0.5, 7).cuda()
+res = {"t0": ops.plan_timeouts(reset=True)}
+good = ops.mask_to_index(patch, Ho, Ho, 1, patch_major=True)
+torch.cuda.synchronize()
+res["good_cnt"] = good.cnt.tolist()
+res["t1"] = ops.plan_timeouts()
+assert stall(5) == 0                      # image 5 never publishes: images 6 .. 11 run into the time bound
+bad = ops.mask_to_index(patch, Ho, Ho, 1, patch_major=True)
+torch.cuda.synchronize()
+res["bad_cnt"] = bad.cnt.tolist()
+res["bad_pre3"] = bad.pre3.tolist()
+res["bad_pre1"] = bad.pre1.tolist()
+res["bad_stats"] = bad.stats.tolist()
+res["t2"] = ops.plan_timeouts()
+try:
+    ops.plan_timeouts(raise_on_error=True)
+    res["raised"] = False
+except _lib.LdnError:
+    res["raised"] = True
+# a consumer of the poisoned lists does no work and touches nothing
+h = torch.full((bad.cap3, 8), 3.0).cuda()
+src = torch.randn(B * Ho * Ho, 8).cuda()
+ops.conv_rows(src, torch.randn(8, 1, 8).cuda(), None, torch.zeros(8).cuda(), h, a_rows=bad.idx1, taps=1, m_count=bad.cnt[1:2], m_cap=bad.cap1)
+torch.cuda.synchronize()
+res["consumer_untouched"] = bool((h == 3.0).all())
+assert stall(-1) == 0
+res["t3"] = ops.plan_timeouts(reset=True)
+again = ops.mask_to_index(patch, Ho, Ho, 1, patch_major=True)
+torch.cuda.synchronize()
+res["again_equal"] = bool(torch.equal(again.cnt, good.cnt) and torch.equal(again.pre3, good.pre3) and torch.equal(again.idx3[: int(good.cnt[0])], good.idx3[: int(good.cnt[0])]))
+res["t4"] = ops.plan_timeouts()
+print("RESULT " + json.dumps(res))
+"""
+
+
+def test_plan_timeout_leaves_empty_lists_and_is_counted():
+    """a prefix wait of the one-launch list build (k_plan) that runs into its time bound must leave EMPTY lists -- counts,
+    every prefix and the statistics zero, whatever the interleaving -- never uninitialised ones, and must be visible to the caller
+    (ldn_plan_timeouts).  The debug build's hook makes one image never publish its counts; the bound is shortened to 150 ms."""
+    env = dict(os.environ, LDN_LIB_PATH=os.path.join(ROOT, "laudnet_amd", "libldn_hip_debug.so"), LDN_PLAN_TIMEOUT_MS="150")
+    p = subprocess.run([sys.executable, "-c", STALL_SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert r["t0"] == 0 and r["t1"] == 0 and r["good_cnt"][0] > 0
+    assert r["bad_cnt"] == [0, 0], r["bad_cnt"]
+    assert all(v == 0 for v in r["bad_pre3"]) and all(v == 0 for v in r["bad_pre1"]), "a prefix survived the failure"
+    assert all(v == 0.0 for v in r["bad_stats"][:3])
+    assert r["t2"] >= 1 and r["raised"] and r["t3"] == r["t2"]
+    assert r["consumer_untouched"]
+    assert r["again_equal"] and r["t4"] == 0, "the next launch must be healthy again"

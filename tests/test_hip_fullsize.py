@@ -152,7 +152,35 @@ def test_headline_bs256_masker_produced_masks(math_mode):
     _check(got, want, f"headline bs256/{math_mode}")
 
 
-@pytest.mark.parametrize("name", ["r101_channel2222", "r101_spatial4421"])
+@pytest.mark.parametrize("name", ["r101_spatial4421", "r101_layer"])
+def test_spatial_and_layer_bs64_masker_produced_masks(name, math_mode):
+    """the DEFAULT spatial / layer product path -- in-place residual, fused masker on (decisions taken from the
+    pooled means conv3's epilogue leaves, lists from ldn_mask_plan / ldn_layer_index) -- against the oracle with the masks the HIP path
+    itself produced replayed into it.  bf16x3 (the mode the fused masker runs in): at least 20 of the 33 blocks must have decided from
+    pooled means, otherwise this test is not testing the path the bench times."""
+    sys.path.insert(0, ROOT)
+    import bench
+    _set_mode(math_mode)
+    hip, ref, x = _pair(name)
+    bench.calibrate_maskers(hip, x, None, 0.5)
+    ref.load_state_dict({k: v.detach().clone() for k, v in hip.state_dict().items()})
+    assert hip.inplace_residual, "the default of the model is the in-place residual stream"
+    with torch.no_grad():
+        got = hip(x, 1.0)
+        fused = kept = 0
+        for hb, rb in zip(_hip_blocks(hip), _ref_blocks(ref)):
+            rb.forced_spatial_mask = hb.last_spatial_mask.clone()
+            fused += 1 if hb.last_fused_decision else 0
+            kept += float(hb.last_spatial_mask.mean())
+        want = ref(x, 1.0)
+    torch.cuda.synchronize()
+    assert 0.3 < kept / 33 < 0.7, "calibration failed: the test must run near the target-0.5 operating point"
+    if math_mode == "bf16x3":
+        assert fused >= 20, f"only {fused} blocks decided from pooled means: the fused masker is not on the tested path"
+    _check(got, want, f"{name} bs64 own masks/{math_mode}")
+
+
+@pytest.mark.parametrize("name", ["r101_channel2222", "r101_spatial4421", "r101_layer"])
 def test_masker_decisions_vs_oracle_maskers(name):
     """Per arithmetic mode: decisions of the HIP maskers that differ from the oracle's own maskers ON THE SAME BLOCK INPUT.
     Bound: <= 0.05 % of all decisions, and every differing decision sits on a near-tie of the oracle's logits
@@ -161,7 +189,7 @@ def test_masker_decisions_vs_oracle_maskers(name):
     import bench
     from laudnet_amd import ops
     hip, ref, x = _pair(name)
-    bench.calibrate_maskers(hip, x, 0.62 if "channel" in name else None, 0.5 if "spatial" in name else None)
+    bench.calibrate_maskers(hip, x, 0.62 if "channel" in name else None, None if "channel" in name else 0.5)
     ref.load_state_dict({k: v.detach().clone() for k, v in hip.state_dict().items()})
     res = bench.audit_masker_decisions(hip, ref, x, ops, "fp32")
     print("masker decision audit", name, res)
@@ -169,6 +197,8 @@ def test_masker_decisions_vs_oracle_maskers(name):
         assert r["decisions_total"] > 0
         assert r["decisions_differing_from_oracle_maskers"] <= 5e-4 * r["decisions_total"], (mode, r)
         assert r["largest_oracle_logit_margin_at_a_differing_decision"] <= 2e-3, (mode, r)
+    if "channel" not in name:   # teacher-forced WITH the in-place residual on: the audited decisions are the fused masker's (item 3a)
+        assert res["bf16x3"]["blocks_decided_from_pooled_means"] >= 20, res["bf16x3"]
 
 
 @pytest.mark.parametrize("name", ["r101_channel2222", "r101_spatial4421", "regnety800_layerskip"])

@@ -202,6 +202,27 @@ int ldn_conv_rows_pool(const float* a, int lda, const int32_t* a_rows, const int
                        int cin, int cout, const float* scale, const float* shift, int relu, const int32_t* relu_if_neg,
                        const int32_t* out_rows, const float* residual, int ldr, float* out, int ldo, float* pool, int S,
                        int Sx, int Ho, int Wo, int math_mode, void* stream);
+
+/* Round 5: the packed spatial / layer path keeps its intermediates PRE-SPLIT between its three launches, so that no operand is split
+ * into bf16 hi / lo inside a K loop (models/laud_resnet.py:115-144 on the active pixels; the operator list the reference's simulator
+ * times: conv1 on the dilated list, gather_conv2, conv3 + scatter_add, DyNetSimulator/eval_example.py:39-48).  A pre-split row holds, per
+ * octet of channels, 8 bf16 hi then 8 bf16 lo (x = hi + lo + O(2^-17 |x|), both round-to-nearest-even) -- the layout of the pre-split
+ * weights (ldn_conv_rows_split: `w_split`); an element still takes 4 bytes, strides (`lda`, `ldo`) still count 4-byte elements.
+ *
+ * ldn_conv_rows_ps: ldn_conv_rows_split with taps = 1 where `a` (a_presplit != 0) and / or `out` (out_presplit != 0) are pre-split rows.
+ *   A pre-split output takes no residual, scatter (out_rows) or pooled means.  pool != NULL: as ldn_conv_rows_pool (S, Sx, Ho, Wo).
+ *   bf16x3 arithmetic; cin % 32 == 0, cout % 64 == 0; results are bit-identical to ldn_conv_rows_split on the same values.
+ * ldn_conv3x3_rows_ps: out[m, :] = act(scale * sum_{tap, k} a[nbr[m][tap], k] * w[:, tap, k] + shift) over the first min(*m_count, m_cap)
+ *   packed rows (m_count NULL: m_cap): `a_presplit` pre-split rows, nbr [m_cap][9] (row of `a` per tap, -1 = zero), w_split the pre-split
+ *   [cout][9][cin] weights, relu 0 | 1, out fp32 or pre-split rows (out_presplit).  rows_hint >= 0: about how many rows *m_count will hold
+ *   (tile shapes only; -1 = unknown).  cin % 64 == 0, cout % 64 == 0.  Bit-identical to ldn_conv_rows_split(taps = 9) on the same values. */
+int ldn_conv_rows_ps(const float* a, int lda, int a_presplit, const int32_t* a_rows, const int32_t* m_count, int m_cap,
+                     const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
+                     const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr, float* out, int ldo,
+                     int out_presplit, float* pool, int S, int Sx, int Ho, int Wo, void* stream);
+int ldn_conv3x3_rows_ps(const void* a_presplit, int lda, const int32_t* nbr, const int32_t* m_count, int m_cap, const void* w_split,
+                        int cin, int cout, const float* scale, const float* shift, int relu, void* out, int ldo, int out_presplit,
+                        int rows_hint, void* stream);
 /* stats[r] = {mean, 1 / sqrt(biased variance + eps)} of row r of x [rows][ld >= C] (nn.LayerNorm's statistics), C % 4 == 0, C <= 2048 */
 int ldn_row_stats(const float* x, int ld, int rows, int C, float eps, float* stats, void* stream);
 /* the same for the rows list[0 .. *count) only (stats of the other rows are left untouched): the LayerNorm statistics of the tokens a

@@ -31,6 +31,8 @@ SIGNATURES = {
     "ldn_layer_head": ([_P, _I, _I, _I, _P, _P, _I, _P, _P, _P], _I),
     "ldn_mask_plan": ([_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "ldn_conv_rows_pool": ([_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P], _I),
+    "ldn_conv_rows_ps": ([_P, _I, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P], _I),
+    "ldn_conv3x3_rows_ps": ([_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P], _I),
     "ldn_gather_rows": ([_P, _I, _P, _P, _I, _I, _P, _I, _P], _I),
     "ldn_scatter_add_relu": ([_P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P], _I),
     "ldn_conv_rows": ([_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P], _I),

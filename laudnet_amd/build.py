@@ -8,7 +8,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libldn_hip.so")
-SOURCES = ["ldn_conv_image.hip", "ldn_index.hip", "ldn_regnet.hip", "ldn_tail.hip", "ldn_dense.hip", "ldn_stem.hip", "ldn_attn.hip", "ldn_grouped.hip", "ldn_small.hip"]
+SOURCES = ["ldn_conv_image.hip", "ldn_index.hip", "ldn_regnet.hip", "ldn_tail.hip", "ldn_dense.hip", "ldn_stem.hip", "ldn_attn.hip", "ldn_grouped.hip", "ldn_small.hip", "ldn_rows3.hip"]
 HEADERS = [os.path.join(CSRC, "ldn_common.h"), os.path.join(os.path.dirname(PKG), "include", "ldn_hip.h")]
 
 

@@ -61,9 +61,19 @@ int tu_violations_regnet(unsigned* count, unsigned* code, int reset);
 int tu_violations_tail(unsigned* count, unsigned* code, int reset);
 int tu_violations_dense(unsigned* count, unsigned* code, int reset);
 int tu_violations_small(unsigned* count, unsigned* code, int reset);
+int tu_violations_rows3(unsigned* count, unsigned* code, int reset);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// lane ^ 1 exchange (DPP quad_perm [1,0,3,2]).  Inline asm on purpose: hipcc 7.2 merges several __builtin_amdgcn_update_dpp calls
+// of one unrolled loop into ONE v_mov_b32_dpp of the first operand and uses its result for all of them (seen in the pre-split
+// epilogues of round 5: every lane got its partner's element 0 four times).  The s_nop covers the VALU-write -> DPP-read wait states.
+__device__ __forceinline__ float dpp_swap_pair(float v) {
+    float r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
 
 constexpr int kWave = 64;   // CDNA wavefront
 constexpr int kXcds = 8;    // MI355X: 8 XCDs, block b is dispatched to XCD b % 8

@@ -91,7 +91,11 @@ constexpr int D_ROW_RELU = 1 << 30;
 // 32x32x2 instructions (instruction i pairs k-slot i of lane half 0 with k-slot i of lane half 1) instead of three 32x32x16 ones.
 // R: rows per workgroup -- 256 (eight waves), or 128 (four waves, ring depth 2: two workgroups per CU fit) for the launches whose grid
 // of 256-row tiles would leave CUs with one workgroup or none (the stage-3 3x3 of the spatial workload, stage 4)
-template <int NSUB, bool T9, bool FULL, bool F32 = false, int R = 256>
+// PS (round 5): the activation rows arrive PRE-SPLIT, [row][cin / 8][8 hi | 8 lo] bf16 (the layout the weights have; 4 bytes per element, so
+// every address computation is the fp32 one): a B fragment is two ds_read_b128 and NO VALU -- the K loop splits nothing.
+// OF (round 5): the epilogue STORES pre-split rows (the producer side of PS: conv1 of a spatial / layer block writes h1 for the packed
+// 3x3, k_rows3, which writes h2 for conv3): two neighbouring lanes pair their four channels into one octet, one stores 8 hi, the other 8 lo.
+template <int NSUB, bool T9, bool FULL, bool F32 = false, int R = 256, bool PS = false, bool OF = false>
 __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
     constexpr int NT = NSUB * 32;
     constexpr int D = (NSUB >= 6 || R == 128) ? 2 : 3;
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
             const unsigned sl = 4u * half + 2u * h;
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + ((sl ^ xsw) << 4));
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + xrow * 128 + (((sl + 1) ^ xsw) << 4));
-            if constexpr (F32) {
+            if constexpr (F32 || PS) {     // (PS: 16-byte unit 2 o = the octet's 8 hi, unit 2 o + 1 = its 8 lo -- the fragment as it is)
                 bh[half] = __builtin_bit_cast(bf16x8, x0);
                 bl[half] = __builtin_bit_cast(bf16x8, x1);
             } else {
@@ -463,8 +467,29 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
                 for (int e = 0; e < 4; ++e) x[e] = 0.5f * x[e] * (1.f + erff(x[e] * 0.70710678118654752f));
             }
             x = (x - ps) * cm[it];
-            if (orw[it] >= 0 && cok)
-                *reinterpret_cast<f32x4*>(p.out + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + tc * 4) = x;
+            if constexpr (OF) {
+                // pre-split rows: lanes tc = 2 q and 2 q + 1 hold channels 0-3 and 4-7 of octet 4 j + q (+ n0 / 8); they exchange their
+                // quads (DPP quad_perm [1,0,3,2]); the even lane stores the octet's 8 hi, the odd lane its 8 lo (16 bytes each, adjacent)
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    y[e] = dpp_swap_pair(x[e]);
+                const bool odd = tc & 1;
+                const f32x4 c03 = odd ? y : x, c47 = odd ? x : y;      // channels 0-3 / 4-7 of the octet
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = e < 4 ? c03[e] : c47[e - 4];
+                    const __bf16 hb = (__bf16)v;
+                    o[e] = odd ? (__bf16)(v - (float)hb) : hb;
+                }
+                if (orw[it] >= 0 && cok)
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + (tc & ~1) * 4) * 4 +
+                                               (odd ? 16 : 0)) = o;
+            } else {
+                if (orw[it] >= 0 && cok)
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + tc * 4) = x;
+            }
             xs4[it] = x;
         }
         if constexpr (!T9 && FULL) {
@@ -568,16 +593,16 @@ __global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, 
 
 LDN_DEFINE_TU_VIOLATIONS(tu_violations_dense)
 
-template <int NSUB, bool T9, bool FULL, bool F32 = false, int R = 256>
+template <int NSUB, bool T9, bool FULL, bool F32 = false, int R = 256, bool PS = false, bool OF = false>
 static int launch_dense_f(DenseArgs& a, hipStream_t st) {
     constexpr int NT = NSUB * 32;
     constexpr int D = (NSUB >= 6 || R == 128) ? 2 : 3;
     const size_t lds = (size_t)(T9 ? 12 : 2) * R * 4 + (size_t)D * (R + NT) * 128;
     a.ntn = ceil_div(a.cout, NT);
     a.mtn = ceil_div(a.m_cap, R);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB, T9, FULL, F32, R>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense<NSUB, T9, FULL, F32, R, PS, OF>), lds), "k_dense: cannot reserve %zu B of LDS", lds);
     const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
-    hipLaunchKernelGGL((k_dense<NSUB, T9, FULL, F32, R>), dim3(grid), dim3(2 * R), lds, st, a);
+    hipLaunchKernelGGL((k_dense<NSUB, T9, FULL, F32, R, PS, OF>), dim3(grid), dim3(2 * R), lds, st, a);
     LDN_CHECK_LAUNCH("k_dense");
     return LDN_OK;
 }
@@ -604,7 +629,7 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
                                 float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
                                 int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
                                 const float* ln_stats, const float* ln_c1, bool f32, void* stream, float* pool = nullptr, int pool_S = 0,
-                                int pool_Sx = 0);
+                                int pool_Sx = 0, bool ps = false, bool of = false);
 
 // Advisory: about how many rows the NEXT ldn_conv_rows_split / _pool call of this thread will find in its device-side count (which the
 // host cannot read without a synchronisation) -- e.g. the count of the previous forward.  Used to choose the tile width only.
@@ -646,12 +671,30 @@ extern "C" int ldn_conv_rows_pool(const float* a, int lda, const int32_t* a_rows
                                 out, ldo, nullptr, nullptr, 0, 1, nullptr, 0, 0, Ho, Wo, 1, nullptr, nullptr, math_mode == 0, stream, pool, S, Sx);
 }
 
+// The 1x1 form on PRE-SPLIT rows (round 5: the packed spatial / layer path keeps h1 and h2 pre-split between its three launches, so no
+// operand is split in a K loop).  a_presplit: the rows of `a` are [cin / 8][8 hi | 8 lo] bf16 (lda still counts 4-byte elements);
+// out_presplit: the rows of `out` are written in that layout (ldo likewise; no residual / pool with it).  Everything else as
+// ldn_conv_rows_split with taps = 1; bf16x3 arithmetic; cin % 32 == 0, cout % 64 == 0.  With pool != NULL the pooled patch means of
+// the output are left as by ldn_conv_rows_pool (S, Sx, Ho, Wo: its arguments).
+extern "C" int ldn_conv_rows_ps(const float* a, int lda, int a_presplit, const int32_t* a_rows, const int32_t* m_count, int m_cap,
+                                const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
+                                const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr, float* out, int ldo,
+                                int out_presplit, float* pool, int S, int Sx, int Ho, int Wo, void* stream) {
+    LDN_REQUIRE(a_presplit || out_presplit, "ldn_conv_rows_ps: neither side is pre-split (use ldn_conv_rows_split)");
+    LDN_REQUIRE(cin % 32 == 0 && cout % 64 == 0, "ldn_conv_rows_ps: cin must be a multiple of 32 and cout of 64 (got %d, %d)", cin, cout);
+    LDN_REQUIRE(!out_presplit || (!residual && !pool && !out_rows), "ldn_conv_rows_ps: a pre-split output takes no residual, scatter or pooled means");
+    return conv_rows_dense_impl(a, lda, a_rows, 1, m_count, m_cap, w_split, cin, cout, scale, shift, relu, relu_if_neg, out_rows, residual, ldr,
+                                out, ldo, nullptr, nullptr, 0, 1, nullptr, 0, 0, Ho, Wo, 1, nullptr, nullptr, false, stream, pool, S, Sx,
+                                a_presplit != 0, out_presplit != 0);
+}
+
 static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                                 const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
                                 const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
                                 float* out, int ldo, const float* post_sub, const float* chan_mask, int rows_per_image,
                                 int shift_classes, const int32_t* pix_map, int Hi, int Wi, int Ho, int Wo, int stride,
-                                const float* ln_stats, const float* ln_c1, bool f32, void* stream, float* pool, int pool_S, int pool_Sx) {
+                                const float* ln_stats, const float* ln_c1, bool f32, void* stream, float* pool, int pool_S, int pool_Sx,
+                                bool ps, bool of) {
     const long hint = g_rows_hint;      // (consumed by this call whatever path it takes)
     g_rows_hint = -1;
     LDN_REQUIRE(a && w_split && shift && out, "ldn_conv_rows_split: null pointer");
@@ -713,6 +756,31 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
         const long wgs = mtl * (cout / (ns * 32));
         return (double)((wgs + 255) / 256) * (double)(chunks * (mc[0] + mc[1] * ns) + mc[2] * ns);
     };
+    if (ps || of) {      // pre-split rows on one or both sides: 1x1, whole column tiles of 256 / 128 / 64
+        int best = 0;
+        double best_cost = 0.0;
+        if (use_model && rows_known > 0) {
+            for (int ns : {8, 4, 2}) {
+                if (cout % (ns * 32) != 0) continue;
+                const double cost = tile_cost(ns);
+                if (!best || cost < best_cost) { best = ns; best_cost = cost; }
+            }
+        }
+        if (!best) best = (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) ? 8 : (cout % 128 == 0 ? 4 : 2);
+        if (ps && !of) {
+            switch (best) {
+                case 8: return launch_dense_f<8, false, true, false, 256, true, false>(d, st);
+                case 4: return launch_dense_f<4, false, true, false, 256, true, false>(d, st);
+                default: return launch_dense_f<2, false, true, false, 256, true, false>(d, st);
+            }
+        }
+        LDN_REQUIRE(!ps, "ldn_conv_rows_ps: pre-split on both sides is not built");
+        switch (best) {
+            case 8: return launch_dense_f<8, false, true, false, 256, false, true>(d, st);
+            case 4: return launch_dense_f<4, false, true, false, 256, false, true>(d, st);
+            default: return launch_dense_f<2, false, true, false, 256, false, true>(d, st);
+        }
+    }
     if (taps == 9) {
         if (small_grid) return launch_dense_f<4, true, true, false, 128>(d, st);
         if (use_model && rows_known > 0 && cout % 128 == 0 && tile_cost(2) < tile_cost(4)) return launch_dense_f<2, true, true>(d, st);

@@ -1079,6 +1079,7 @@ extern "C" int ldn_debug_violations(int* count, int* first_code, int reset) {
     if (!rc) rc = tu_violations_tail(&c, &code, reset);
     if (!rc) rc = tu_violations_dense(&c, &code, reset);
     if (!rc) rc = tu_violations_small(&c, &code, reset);
+    if (!rc) rc = tu_violations_rows3(&c, &code, reset);
     if (rc) { set_error("ldn_debug_violations: cannot read the counters"); return rc; }
     *count = (int)c;
     if (first_code) *first_code = (int)code;

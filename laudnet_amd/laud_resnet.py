@@ -765,11 +765,18 @@ class Bottleneck(_PrepCache):
             hint = self._rows_hint = ops.RowsHint(2)
         n3, n1 = hint.get(0), hint.get(1)
         hint.update(ix.cnt)
-        h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
-        ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1, rows_hint=n1)
-        h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
-        ops.conv_rows(h1, p["w2"], p["s2"], p["t2"], h2, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3, rows_hint=n3)
         cout = p["w3"].shape[0]
+        # round 5: h1 and h2 stay PRE-SPLIT (bf16 hi | lo per octet, the weights' layout) between the three launches -- conv1's epilogue
+        # writes h1 that way, the packed 3x3 (k_rows3) and conv3 split nothing in their K loops; same values, bit-identical results
+        ps = ops.rows_ps_ok(Cin, W, cout)
+        h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
+        h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
+        if ps:
+            ops.conv_rows_ps(x2d, p["w1"], p["s1"], p["t1"], h1, out_presplit=True, a_rows=ix.idx1, m_count=ix.cnt[1:2], m_cap=ix.cap1, rows_hint=n1)
+            ops.conv3x3_rows_ps(h1, ix.nbr, p["w2"], p["s2"], p["t2"], h2, m_count=ix.cnt[0:1], m_cap=ix.cap3, out_presplit=True, rows_hint=n3)
+        else:
+            ops.conv_rows(x2d, p["w1"], p["s1"], p["t1"], h1, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1, rows_hint=n1)
+            ops.conv_rows(h1, p["w2"], p["s2"], p["t2"], h2, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3, rows_hint=n3)
         if G == 1:
             groups = [(ix, None, slice(0, cout))]
         else:
@@ -794,7 +801,12 @@ class Bottleneck(_PrepCache):
         else:
             resid, out2d = x2d, torch.relu(x2d)
         for ig, rows, cs in groups:
-            ops.conv_rows(h2, p["w3"][cs], None, p["t3"][cs], out2d[:, cs], a_rows=rows, taps=1, m_count=ig.cnt[0:1],
+            if ps and (cs.stop - cs.start) % 64 == 0:
+                ops.conv_rows_ps(h2, p["w3"][cs], None, p["t3"][cs], out2d[:, cs], a_presplit=True, a_rows=rows, m_count=ig.cnt[0:1],
+                                 m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs], rows_hint=n3 if G == 1 else None,
+                                 pool=pool, pool_grid=(pS, pS, Ho, Wo) if pool is not None else None)
+                continue
+            ops.conv_rows(h2 if not ps else ops.unsplit_rows(h2), p["w3"][cs], None, p["t3"][cs], out2d[:, cs], a_rows=rows, taps=1, m_count=ig.cnt[0:1],
                           m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs], rows_hint=n3 if G == 1 else None, pool=pool,
                           pool_grid=(pS, pS, Ho, Wo) if pool is not None else None)
         self.last_spatial_mask = patch

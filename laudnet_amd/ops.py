@@ -448,6 +448,72 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
     return out2d
 
 
+USE_ROWS_PS = os.environ.get("LDN_ROWS_PS", "1") != "0"      # the pre-split packed path (k_dense<PS / OF> + k_rows3); 0 = round 4's three launches
+
+
+def rows_ps_ok(cin, width, cout):
+    """Can a spatial / layer block keep h1 / h2 pre-split between its launches (ldn_conv_rows_ps + ldn_conv3x3_rows_ps)?  bf16x3 mode on
+    the k_dense path, widths the kernels tile (conv1: cin % 32, width % 64; 3x3: width % 64; conv3: cout % 64)."""
+    return (USE_ROWS_PS and USE_DENSE_KERNEL and get_math_mode() == "bf16x3" and cin % 32 == 0 and width % 64 == 0 and cout % 64 == 0)
+
+
+def conv_rows_ps(a2d, w, scale, shift, out2d, *, a_presplit=False, out_presplit=False, a_rows=None, m_count=None, m_cap=None, relu=1,
+                 relu_if_neg=None, out_rows=None, residual2d=None, rows_hint=None, pool=None, pool_grid=None):
+    """1x1 packed-row convolution with pre-split rows on the input and / or output side (see ldn_conv_rows_ps).  a2d / out2d are float32
+    tensors either way (a pre-split row is the same 4 bytes per element); w [cout, 1, cin] fp32 (its pre-split copy is cached)."""
+    L.require_device(a2d, w, out2d)
+    lib = L.load()
+    cout, t, cin = w.shape
+    if t != 1:
+        raise L.LdnError("conv_rows_ps: 1x1 weights expected")
+    if m_cap is None:
+        m_cap = a2d.shape[0] if a_rows is None else a_rows.numel()
+    if rows_hint is not None and m_count is not None and USE_ROWS_HINT:
+        lib.ldn_hint_rows(int(rows_hint))
+    S, Sx, ho, wo = pool_grid if pool is not None else (0, 0, 0, 0)
+    L.check(lib.ldn_conv_rows_ps(L.ptr(_f32rows(a2d, "a")), a2d.stride(0), 1 if a_presplit else 0, L.ptr(_i32c(a_rows, "a_rows")),
+                                 L.ptr(_i32c(m_count, "m_count")), m_cap, L.ptr(split_rows_weight(w)), cin, cout,
+                                 L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu, L.ptr(_i32c(relu_if_neg, "relu_if_neg")),
+                                 L.ptr(_i32c(out_rows, "out_rows")), L.ptr(_f32rows(residual2d, "residual")),
+                                 residual2d.stride(0) if residual2d is not None else 0, L.ptr(_f32rows(out2d, "out")), out2d.stride(0),
+                                 1 if out_presplit else 0, L.ptr(_f32c(pool, "pool")), S, Sx, ho, wo, L.stream_ptr(out2d)), "ldn_conv_rows_ps")
+    return out2d
+
+
+def conv3x3_rows_ps(a2d, nbr, w, scale, shift, out2d, *, m_count=None, m_cap=None, relu=1, out_presplit=False, rows_hint=None):
+    """The packed 3x3 on pre-split rows (k_rows3, see ldn_conv3x3_rows_ps): a2d [rows, cin] pre-split h1, nbr [m_cap, 9], w [cout, 9, cin]."""
+    L.require_device(a2d, nbr, w, out2d)
+    lib = L.load()
+    cout, t, cin = w.shape
+    if t != 9:
+        raise L.LdnError("conv3x3_rows_ps: 3x3 weights [cout, 9, cin] expected")
+    if m_cap is None:
+        m_cap = nbr.numel() // 9
+    hint = int(rows_hint) if (rows_hint is not None and USE_ROWS_HINT) else -1
+    L.check(lib.ldn_conv3x3_rows_ps(L.ptr(_f32rows(a2d, "a")), a2d.stride(0), L.ptr(_i32c(nbr, "nbr")), L.ptr(_i32c(m_count, "m_count")), m_cap,
+                                    L.ptr(split_rows_weight(w)), cin, cout, L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,
+                                    L.ptr(_f32rows(out2d, "out")), out2d.stride(0), 1 if out_presplit else 0, hint, L.stream_ptr(out2d)),
+            "ldn_conv3x3_rows_ps")
+    return out2d
+
+
+def presplit_rows(x2d):
+    """fp32 rows -> pre-split rows ([row][C / 8][8 hi | 8 lo] bf16 viewed as float32 [rows, C]); host-side helper for tests and tools
+    (the kernels produce this layout themselves)."""
+    rows, C = x2d.shape
+    hi = x2d.to(torch.bfloat16)
+    lo = (x2d - hi.float()).to(torch.bfloat16)
+    packed = torch.stack((hi.view(rows, C // 8, 8), lo.view(rows, C // 8, 8)), dim=2).contiguous()     # [rows, C/8, 2, 8] bf16
+    return packed.view(torch.float32).reshape(rows, C)
+
+
+def unsplit_rows(ps2d):
+    """Inverse of presplit_rows (hi + lo in fp32)."""
+    rows, C = ps2d.shape
+    b = ps2d.contiguous().view(torch.bfloat16).reshape(rows, C // 8, 2, 8).float()
+    return (b[:, :, 0] + b[:, :, 1]).reshape(rows, C)
+
+
 # ---------------------------------------------------------------------------------------- a2
 def channel_masker(x_nhwc, w1, b1, w2, b2, groups, gran, mask_in=None, want_logits=False, gap_partial=None, hw=None):
     """Masker_channel_MLP eval forward + active channel lists (see ldn_channel_masker).

@@ -6,7 +6,7 @@ R=$(cd $(dirname $0)/.. && pwd)
 name=$1; src=$2; shift 2
 mkdir -p $R/tools/ablate
 objs=""
-for f in ldn_conv_image ldn_index ldn_regnet ldn_tail ldn_dense ldn_stem ldn_attn ldn_grouped ldn_small; do
+for f in ldn_conv_image ldn_index ldn_regnet ldn_tail ldn_dense ldn_stem ldn_attn ldn_grouped ldn_small ldn_rows3; do
   if [ "$f.hip" = "$src" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -c -o $R/tools/ablate/$f.$name.o $R/laudnet_amd/csrc/$f.hip
     objs="$objs $R/tools/ablate/$f.$name.o"

@@ -494,6 +494,39 @@ class KernelTimer:
             return out
         return timed
 
+    def wrap_rows_ps(self, fn):
+        """ops.conv_rows_ps: the 1x1 launches of the pre-split packed path (conv1 writing pre-split h1, conv3 reading pre-split h2)."""
+        def timed(*a, **kw):
+            if not self.sampled("rows_1x1"):
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            cap = kw.get("m_cap")
+            if cap is None:
+                cap = a[0].shape[0] if kw.get("a_rows") is None else kw["a_rows"].numel()
+            self.rows.append(("rows_1x1", e0, e1, kw.get("m_count"), cap, tuple(a[1].shape), kw.get("residual2d") is not None))
+            return out
+        return timed
+
+    def wrap_rows3(self, fn):
+        """ops.conv3x3_rows_ps: the packed 3x3 on pre-split rows (k_rows3) -- "rows_3x3"."""
+        def timed(*a, **kw):
+            if not self.sampled("rows_3x3"):
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            cap = kw.get("m_cap")
+            if cap is None:
+                cap = a[1].numel() // 9
+            self.rows.append(("rows_3x3", e0, e1, kw.get("m_count"), cap, tuple(a[2].shape), False))
+            self.rows3_kernel = True
+            return out
+        return timed
+
     def wrap_grouped_images(self, fn):
         """ops.grouped16_conv3x3_images: LAD-RegNet conv b (grouped 3x3, 16 channels per group) on whole kept images (k_grouped16_img)."""
         def timed(*a, **kw):
@@ -709,6 +742,7 @@ def main():
     orig_tail = ops.bottleneck_tail
     orig_chain = ops.bottleneck_chain
     orig_grouped = ops.grouped16_conv3x3_images
+    orig_rows_ps, orig_rows3 = ops.conv_rows_ps, ops.conv3x3_rows_ps
     ev_steps = 0
     if rank == 0 and graphed is None and not os.environ.get("LDN_BENCH_NO_EVENTS"):
         ops.conv_image = timer.wrap(orig_conv_image)
@@ -716,6 +750,8 @@ def main():
         ops.bottleneck_tail = timer.wrap_tail(orig_tail)
         ops.bottleneck_chain = timer.wrap_chain(orig_chain)
         ops.grouped16_conv3x3_images = timer.wrap_grouped_images(orig_grouped)
+        ops.conv_rows_ps = timer.wrap_rows_ps(orig_rows_ps)
+        ops.conv3x3_rows_ps = timer.wrap_rows3(orig_rows3)
         ev_steps = max(2, min(args.steps, 10))
         try:
             t1 = time.perf_counter()
@@ -730,6 +766,7 @@ def main():
             ops.bottleneck_tail = orig_tail
             ops.bottleneck_chain = orig_chain
             ops.grouped16_conv3x3_images = orig_grouped
+            ops.conv_rows_ps, ops.conv3x3_rows_ps = orig_rows_ps, orig_rows3
     if world > 1:
         torch.distributed.barrier()
 
@@ -847,7 +884,9 @@ def main():
                 "grouped16_img": grouped_roofline}
         objs = {k: pick.get(k, mfma_roofline)(*v) for k, v in agg.items()}
         if "rows_3x3" in objs:
-            objs["rows_3x3"]["kernel"] = ("k_dense<.., T9> (3x3 conv over packed active rows through the neighbour table, shared weights, bf16x3)"
+            objs["rows_3x3"]["kernel"] = ("k_rows3 (3x3 conv over packed active rows on PRE-SPLIT h1 through the neighbour table, shared weights in K64 steps, bf16x3)"
+                                          if getattr(timer, "rows3_kernel", False) else
+                                          "k_dense<.., T9> (3x3 conv over packed active rows through the neighbour table, shared weights, bf16x3)"
                                           if mode != "fp32" and 9 in ops.DENSE_TAPS and ops.USE_DENSE_KERNEL else
                                           objs["rows_3x3"]["kernel"].replace("3x3 per-image channel-subset conv", "3x3 conv over packed active rows, shared weights"))
             objs["rows_3x3"]["traffic_scope"] = objs["rows_3x3"]["traffic"] = None

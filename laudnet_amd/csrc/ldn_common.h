@@ -75,6 +75,39 @@ __device__ __forceinline__ float dpp_swap_pair(float v) {
     return r;
 }
 
+// One lane's 16 bytes of a PRE-SPLIT octet ([8 hi | 8 lo] bf16): lanes 2q / 2q + 1 hold channels 0-3 / 4-7 of the octet as fp32 quads.
+// Each lane splits its OWN quad (hi = bf16(x), lo = bf16(x - hi), both round-to-nearest-even: the in-loop split of the un-split kernels),
+// then the pair exchanges what the other one stores: the even lane stores the octet's 8 hi (its own 4 + the partner's), the odd lane the
+// 8 lo (the partner's 4 + its own).  Two DPP moves of packed pairs per lane.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t presplit_store_quad(const f32x4 x, bool odd) {
+    unsigned hi[2], lo[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const __bf16 h0 = (__bf16)x[2 * q], h1 = (__bf16)x[2 * q + 1];
+        const bf16x2_t hp = {h0, h1};
+        const bf16x2_t lp = {(__bf16)(x[2 * q] - (float)h0), (__bf16)(x[2 * q + 1] - (float)h1)};
+        hi[q] = __builtin_bit_cast(unsigned, hp);
+        lo[q] = __builtin_bit_cast(unsigned, lp);
+    }
+    const float r0 = dpp_swap_pair(__builtin_bit_cast(float, odd ? hi[0] : lo[0]));     // even sends its lo, odd sends its hi
+    const float r1 = dpp_swap_pair(__builtin_bit_cast(float, odd ? hi[1] : lo[1]));
+    const unsigned p0 = __builtin_bit_cast(unsigned, r0), p1 = __builtin_bit_cast(unsigned, r1);
+    return odd ? u32x4_t{p0, p1, lo[0], lo[1]} : u32x4_t{hi[0], hi[1], p0, p1};
+}
+
+// 16-byte global store, optionally WRITE-THROUGH (sc0 sc1: the line leaves the XCD's L2 at once instead of staying dirty until the
+// end-of-kernel write-back).  LDN_WT_STORES is a tuning switch (the ~5.6 us behind every large row kernel).
+template <typename V>
+__device__ __forceinline__ void store16(void* ptr, const V v) {
+#ifdef LDN_WT_STORES
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(ptr), "v"(v) : "memory");
+#else
+    *reinterpret_cast<V*>(ptr) = v;
+#endif
+}
+
 constexpr int kWave = 64;   // CDNA wavefront
 constexpr int kXcds = 8;    // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
 

@@ -9,6 +9,7 @@
 // source address) and are split by the one wave that owns the 32 rows; no producer waves -- every wave issues its share of the
 // DMA (inline asm) with counted vmcnt over a ring of 2-3 slots.  One workgroup = 256 rows x NT columns (NT = 64 / 128 / 256).
 #include "ldn_common.h"
+#include <type_traits>
 
 namespace ldn {
 
@@ -36,7 +37,7 @@ struct DenseArgs {
                                                       // lists of k_plan) -- the next spatial masker's pooled means (models/utils.py:48-52)
 };
 
-__device__ __attribute__((aligned(16))) float g_dense_zero[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float g_dense_zero[2048] = {0.f};     // a whole zero ROW for k_dense2 (cin <= 2048); k_dense reads its first 16 bytes
 #ifdef LDN_TRACE   // tuning only: per-workgroup cycle split of the K loop (tools/trace_dense.py)
 __device__ unsigned long long* g_dense_trace = nullptr;
 #define DT(x) x = __builtin_amdgcn_s_memtime();
@@ -81,6 +82,154 @@ __device__ __forceinline__ unsigned d_lds_off(const void* ptr) {
 
 constexpr int D_ROWS_MAX = 256;
 constexpr int D_ROW_RELU = 1 << 30;
+
+// The epilogue of the row kernels (k_dense, k_dense2): per n-subtile, C layout (lane = row, register = channel) -> rows of 32 channels through
+// a per-wave 32 x 32 transpose scratch `scr` (4 KB of LDS owned by the wave), then the affine / residual / activation / mask terms and 16-byte stores.
+template <int NSUB, bool T9, bool FULL, bool OF>
+__device__ __forceinline__ void dense_epilogue(const DenseArgs& p, f32x16 (&acc)[NSUB], const int* s_arow, const int* s_orow, const int* s_cls,
+                                               float* scr, int wave, int lane, int n0, int nsub) {
+    const int l31 = lane & 31, h = lane >> 5;
+    // ---- epilogue: per n-subtile, C layout (lane = row, register = channel) -> rows of 32 channels, 16-byte accesses
+    const int trw = lane >> 3, tc = lane & 7;
+    int orw[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) orw[it] = s_orow[wave * 32 + trw + 8 * it];
+    const bool gelu = p.relu == 3;
+    // pooled patch means (1x1, whole column tiles): which patch row of `pool` this lane stores, -1 = none.  16-pixel patches: the wave's
+    // rows 0-15 / 16-31; the lanes with row-in-octet 0 of each half store.  4-pixel patches: rows 4q .. 4q+3, every lane stores one.
+    long poff = -1;
+    const int pb3 = (lane >> 3) & 1, pb4 = (lane >> 4) & 1;
+    if constexpr (!T9 && FULL) {
+        if (p.pool) {
+            const int it_sel = p.pool_gy * p.pool_gx == 16 ? (lane >= 32 ? 2 : 0) : pb3 + 2 * pb4;
+            const int o = it_sel == 0 ? orw[0] : it_sel == 1 ? orw[1] : it_sel == 2 ? orw[2] : orw[3];
+            if (o >= 0 && (p.pool_gy * p.pool_gx == 4 || (lane & 0x18) == 0)) {
+                const int f = o & (D_ROW_RELU - 1), hw = p.Ho * p.Wo;
+                const int b = f / hw, pix = f - b * hw, y = pix / p.Wo, x = pix - y * p.Wo;
+                poff = ((long)b * (p.Ho / p.pool_gy) * p.pool_Sx + (y / p.pool_gy) * p.pool_Sx + x / p.pool_gx) * p.cout;
+            }
+        }
+    }
+    auto load_res = [&](int j, f32x4 (&res)[4], f32x4& sc, f32x4& sh, f32x4& ps) {
+        const int cb = n0 + 32 * j + tc * 4;
+        const bool cok = FULL || cb < p.cout;                    // (a ragged last subtile: columns beyond cout are neither read nor stored)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float* src = (p.residual && orw[it] >= 0 && cok) ? p.residual + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldr + cb : g_dense_zero;
+            res[it] = *reinterpret_cast<const f32x4*>(src);
+        }
+        sh = cok ? *reinterpret_cast<const f32x4*>(p.shift + cb) : f32x4{0.f, 0.f, 0.f, 0.f};   // (one class; the 16-class table is read per row below)
+        sc = (p.scale && cok) ? *reinterpret_cast<const f32x4*>(p.scale + cb) : f32x4{1.f, 1.f, 1.f, 1.f};
+        ps = (p.post_sub && cok) ? *reinterpret_cast<const f32x4*>(p.post_sub + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+        if (j >= nsub) continue;
+        f32x4 res[4], sc, sh, ps;
+        load_res(j, res, sc, sh, ps);
+        f32x4 cm[4];
+        const bool cok = FULL || n0 + 32 * j + tc * 4 < p.cout;
+        // LayerNorm of the activation rows, applied AFTER the GEMM: LN(x) . w = rstd (x . w' - mean sum_k w'[k]) + const, w' = gamma * w
+        float2 lst[4];
+        f32x4 lc1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.ln_stats) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int ar = s_arow[wave * 32 + trw + 8 * it];
+                lst[it] = ar >= 0 ? *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)ar) : float2{0.f, 1.f};
+            }
+            if (cok) lc1 = *reinterpret_cast<const f32x4*>(p.ln_c1 + n0 + 32 * j + tc * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float* src = (p.chmask && orw[it] >= 0 && cok) ? p.chmask + (size_t)((orw[it] & (D_ROW_RELU - 1)) / p.rows_per_img) * p.cout + n0 + 32 * j + tc * 4
+                                                          : nullptr;
+            cm[it] = src ? *reinterpret_cast<const f32x4*>(src) : f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = {acc[j][4 * q4], acc[j][4 * q4 + 1], acc[j][4 * q4 + 2], acc[j][4 * q4 + 3]};
+            *reinterpret_cast<f32x4*>(scr + l31 * 32 + (((2 * q4 + h) ^ (l31 & 7)) << 2)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // residual / scale / shift registers touched before the first store (gfx9: a load first used after a store waits vmcnt(0)
+        // for that store's acknowledgement)
+        asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sc), "+v"(sh), "+v"(ps));
+        asm volatile("" : "+v"(cm[0]), "+v"(cm[1]), "+v"(cm[2]), "+v"(cm[3]));
+        f32x4 xs4[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = trw + 8 * it;
+            f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
+            const f32x4 shr = (T9 && p.shift_classes > 1 && cok) ? *reinterpret_cast<const f32x4*>(p.shift + s_cls[wave * 32 + row] + n0 + 32 * j + tc * 4) : sh;
+            if (p.ln_stats) x = (x - lc1 * lst[it].x) * lst[it].y;
+            x = x * sc + shr + res[it];
+            if (orw[it] & D_ROW_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+            }
+            if (gelu) {   // exact (erf) GELU of the token-skip MLP: the hidden activations never make a second trip through HBM
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = 0.5f * x[e] * (1.f + erff(x[e] * 0.70710678118654752f));
+            }
+            x = (x - ps) * cm[it];
+            if constexpr (OF) {
+                // pre-split rows: lanes tc = 2 q and 2 q + 1 hold channels 0-3 and 4-7 of octet 4 j + q (+ n0 / 8); they exchange their
+                // quads (DPP quad_perm [1,0,3,2]); the even lane stores the octet's 8 hi, the odd lane its 8 lo (16 bytes each, adjacent)
+                const bool odd = tc & 1;
+                const u32x4_t o = presplit_store_quad(x, odd);
+                if (orw[it] >= 0 && cok)
+                    store16(reinterpret_cast<unsigned char*>(p.out) + ((size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + (tc & ~1) * 4) * 4 + (odd ? 16 : 0), o);
+            } else {
+                if (orw[it] >= 0 && cok)
+                    store16(p.out + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + tc * 4, x);
+            }
+            xs4[it] = x;
+        }
+        if constexpr (!T9 && FULL) {
+            if (p.pool) {   // (wave-uniform) fixed-order sums over the rows of each patch: a register tree across the lanes that hold the patch
+                // cross-lane steps on the VALU (gfx950: v_permlane32_swap / v_permlane16_swap exchange half-waves / 16-lane rows of
+                // two registers, DPP row_ror:8 reaches lane ^ 8) -- no trip through the LDS crossbar; swap(a, b) leaves {a.lo, b.lo} and
+                // {a.hi, b.hi}: their sum is a's pair sum in the lower lanes and b's in the upper ones
+                // (inline asm: hipcc 7.2 folds the builtin's two results into one register when they are only added -- `v_add v0, v0, v0`
+                // behind the swap; the s_nop covers the VALU-write -> permlane-read wait states the compiler would insert)
+                auto swap32_sum = [](float a, float b) {
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+                    return a + b;
+                };
+                auto swap16_sum = [](float a, float b) {
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+                    return a + b;
+                };
+                auto ror8 = [](float a) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false)); };
+                f32x4 m;
+                if (p.pool_gy * p.pool_gx == 16) {
+                    const f32x4 sa = xs4[0] + xs4[1], sb = xs4[2] + xs4[3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = swap32_sum(sa[e], sb[e]);      // lanes 0-31: rows 0-15 (sa), lanes 32-63: rows 16-31 (sb)
+                        v = swap16_sum(v, v);                    // (by value: two registers -- the instruction exchanges rows BETWEEN its operands)
+                        m[e] = v + ror8(v);
+                    }
+                    m *= 0.0625f;
+                } else {
+                    const f32x4 k0 = pb3 ? xs4[1] : xs4[0], g0 = pb3 ? xs4[0] : xs4[1];
+                    const f32x4 k2 = pb3 ? xs4[3] : xs4[2], g2 = pb3 ? xs4[2] : xs4[3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float k01 = k0[e] + ror8(g0[e]), k23 = k2[e] + ror8(g2[e]);
+                        m[e] = swap16_sum(k01, k23);             // even 16-lane rows: k01's pair sum, odd rows: k23's
+                    }
+                    m *= 0.25f;
+                }
+                if (poff >= 0) *reinterpret_cast<f32x4*>(p.pool + poff + n0 + 32 * j + tc * 4) = m;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 // NSUB = n-subtiles of 32 columns per workgroup (2, 4, 5, 6, 8); D = ring depth (2 for NSUB >= 6, 3 otherwise)
 // T9: 3x3 over a neighbour table (compiled apart: the 1x1 form carries none of its tables or branches); FULL: cout is a multiple of
@@ -372,179 +521,9 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
     d_lds_barrier();       // every wave is out of the ring: it becomes the per-wave 32 x 32 transpose scratch
     if (!active) return;
 
-    // ---- epilogue: per n-subtile, C layout (lane = row, register = channel) -> rows of 32 channels, 16-byte accesses
-    float* const scr = reinterpret_cast<float*>(s_ring + wave * 4096);
-    const int trw = lane >> 3, tc = lane & 7;
-    int orw[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) orw[it] = s_orow[wave * 32 + trw + 8 * it];
-    const bool gelu = p.relu == 3;
-    // pooled patch means (1x1, whole column tiles): which patch row of `pool` this lane stores, -1 = none.  16-pixel patches: the wave's
-    // rows 0-15 / 16-31; the lanes with row-in-octet 0 of each half store.  4-pixel patches: rows 4q .. 4q+3, every lane stores one.
-    long poff = -1;
-    const int pb3 = (lane >> 3) & 1, pb4 = (lane >> 4) & 1;
-    if constexpr (!T9 && FULL) {
-        if (p.pool) {
-            const int it_sel = p.pool_gy * p.pool_gx == 16 ? (lane >= 32 ? 2 : 0) : pb3 + 2 * pb4;
-            const int o = it_sel == 0 ? orw[0] : it_sel == 1 ? orw[1] : it_sel == 2 ? orw[2] : orw[3];
-            if (o >= 0 && (p.pool_gy * p.pool_gx == 4 || (lane & 0x18) == 0)) {
-                const int f = o & (D_ROW_RELU - 1), hw = p.Ho * p.Wo;
-                const int b = f / hw, pix = f - b * hw, y = pix / p.Wo, x = pix - y * p.Wo;
-                poff = ((long)b * (p.Ho / p.pool_gy) * p.pool_Sx + (y / p.pool_gy) * p.pool_Sx + x / p.pool_gx) * p.cout;
-            }
-        }
-    }
-    auto load_res = [&](int j, f32x4 (&res)[4], f32x4& sc, f32x4& sh, f32x4& ps) {
-        const int cb = n0 + 32 * j + tc * 4;
-        const bool cok = FULL || cb < p.cout;                    // (a ragged last subtile: columns beyond cout are neither read nor stored)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const float* src = (p.residual && orw[it] >= 0 && cok) ? p.residual + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldr + cb : g_dense_zero;
-            res[it] = *reinterpret_cast<const f32x4*>(src);
-        }
-        sh = cok ? *reinterpret_cast<const f32x4*>(p.shift + cb) : f32x4{0.f, 0.f, 0.f, 0.f};   // (one class; the 16-class table is read per row below)
-        sc = (p.scale && cok) ? *reinterpret_cast<const f32x4*>(p.scale + cb) : f32x4{1.f, 1.f, 1.f, 1.f};
-        ps = (p.post_sub && cok) ? *reinterpret_cast<const f32x4*>(p.post_sub + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-#ifdef LDN_TRACE_EPI
-    unsigned long long e0, e1, e2, e3, e4, ea = 0, eb = 0, ec = 0, ed = 0;
-#define ET(x) x = __builtin_amdgcn_s_memtime();
-#else
-#define ET(x)
-#endif
-#pragma unroll
-    for (int j = 0; j < NSUB; ++j) {
-        if (j >= nsub) continue;
-        f32x4 res[4], sc, sh, ps;
-        ET(e0)
-        load_res(j, res, sc, sh, ps);
-        f32x4 cm[4];
-        const bool cok = FULL || n0 + 32 * j + tc * 4 < p.cout;
-        // LayerNorm of the activation rows, applied AFTER the GEMM: LN(x) . w = rstd (x . w' - mean sum_k w'[k]) + const, w' = gamma * w
-        float2 lst[4];
-        f32x4 lc1 = {0.f, 0.f, 0.f, 0.f};
-        if (p.ln_stats) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int ar = s_arow[wave * 32 + trw + 8 * it];
-                lst[it] = ar >= 0 ? *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)ar) : float2{0.f, 1.f};
-            }
-            if (cok) lc1 = *reinterpret_cast<const f32x4*>(p.ln_c1 + n0 + 32 * j + tc * 4);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const float* src = (p.chmask && orw[it] >= 0 && cok) ? p.chmask + (size_t)((orw[it] & (D_ROW_RELU - 1)) / p.rows_per_img) * p.cout + n0 + 32 * j + tc * 4
-                                                          : nullptr;
-            cm[it] = src ? *reinterpret_cast<const f32x4*>(src) : f32x4{1.f, 1.f, 1.f, 1.f};
-        }
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 v = {acc[j][4 * q4], acc[j][4 * q4 + 1], acc[j][4 * q4 + 2], acc[j][4 * q4 + 3]};
-            *reinterpret_cast<f32x4*>(scr + l31 * 32 + (((2 * q4 + h) ^ (l31 & 7)) << 2)) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        ET(e1)
-        // residual / scale / shift registers touched before the first store (gfx9: a load first used after a store waits vmcnt(0)
-        // for that store's acknowledgement)
-        asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sc), "+v"(sh), "+v"(ps));
-        asm volatile("" : "+v"(cm[0]), "+v"(cm[1]), "+v"(cm[2]), "+v"(cm[3]));
-        ET(e2)
-        f32x4 xs4[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = trw + 8 * it;
-            f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
-            const f32x4 shr = (T9 && p.shift_classes > 1 && cok) ? *reinterpret_cast<const f32x4*>(p.shift + s_cls[wave * 32 + row] + n0 + 32 * j + tc * 4) : sh;
-            if (p.ln_stats) x = (x - lc1 * lst[it].x) * lst[it].y;
-            x = x * sc + shr + res[it];
-            if (orw[it] & D_ROW_RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
-            }
-            if (gelu) {   // exact (erf) GELU of the token-skip MLP: the hidden activations never make a second trip through HBM
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = 0.5f * x[e] * (1.f + erff(x[e] * 0.70710678118654752f));
-            }
-            x = (x - ps) * cm[it];
-            if constexpr (OF) {
-                // pre-split rows: lanes tc = 2 q and 2 q + 1 hold channels 0-3 and 4-7 of octet 4 j + q (+ n0 / 8); they exchange their
-                // quads (DPP quad_perm [1,0,3,2]); the even lane stores the octet's 8 hi, the odd lane its 8 lo (16 bytes each, adjacent)
-                f32x4 y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    y[e] = dpp_swap_pair(x[e]);
-                const bool odd = tc & 1;
-                const f32x4 c03 = odd ? y : x, c47 = odd ? x : y;      // channels 0-3 / 4-7 of the octet
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = e < 4 ? c03[e] : c47[e - 4];
-                    const __bf16 hb = (__bf16)v;
-                    o[e] = odd ? (__bf16)(v - (float)hb) : hb;
-                }
-                if (orw[it] >= 0 && cok)
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + (tc & ~1) * 4) * 4 +
-                                               (odd ? 16 : 0)) = o;
-            } else {
-                if (orw[it] >= 0 && cok)
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)(orw[it] & (D_ROW_RELU - 1)) * p.ldo + n0 + 32 * j + tc * 4) = x;
-            }
-            xs4[it] = x;
-        }
-        if constexpr (!T9 && FULL) {
-            if (p.pool) {   // (wave-uniform) fixed-order sums over the rows of each patch: a register tree across the lanes that hold the patch
-                // cross-lane steps on the VALU (gfx950: v_permlane32_swap / v_permlane16_swap exchange half-waves / 16-lane rows of
-                // two registers, DPP row_ror:8 reaches lane ^ 8) -- no trip through the LDS crossbar; swap(a, b) leaves {a.lo, b.lo} and
-                // {a.hi, b.hi}: their sum is a's pair sum in the lower lanes and b's in the upper ones
-                // (inline asm: hipcc 7.2 folds the builtin's two results into one register when they are only added -- `v_add v0, v0, v0`
-                // behind the swap; the s_nop covers the VALU-write -> permlane-read wait states the compiler would insert)
-                auto swap32_sum = [](float a, float b) {
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-                    return a + b;
-                };
-                auto swap16_sum = [](float a, float b) {
-                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-                    return a + b;
-                };
-                auto ror8 = [](float a) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false)); };
-                f32x4 m;
-                if (p.pool_gy * p.pool_gx == 16) {
-                    const f32x4 sa = xs4[0] + xs4[1], sb = xs4[2] + xs4[3];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = swap32_sum(sa[e], sb[e]);      // lanes 0-31: rows 0-15 (sa), lanes 32-63: rows 16-31 (sb)
-                        v = swap16_sum(v, v);                    // (by value: two registers -- the instruction exchanges rows BETWEEN its operands)
-                        m[e] = v + ror8(v);
-                    }
-                    m *= 0.0625f;
-                } else {
-                    const f32x4 k0 = pb3 ? xs4[1] : xs4[0], g0 = pb3 ? xs4[0] : xs4[1];
-                    const f32x4 k2 = pb3 ? xs4[3] : xs4[2], g2 = pb3 ? xs4[2] : xs4[3];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float k01 = k0[e] + ror8(g0[e]), k23 = k2[e] + ror8(g2[e]);
-                        m[e] = swap16_sum(k01, k23);             // even 16-lane rows: k01's pair sum, odd rows: k23's
-                    }
-                    m *= 0.25f;
-                }
-                if (poff >= 0) *reinterpret_cast<f32x4*>(p.pool + poff + n0 + 32 * j + tc * 4) = m;
-            }
-        }
-        ET(e3)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#ifdef LDN_TRACE_EPI
-        ET(e4)
-        ea += e1 - e0; eb += e2 - e1; ec += e3 - e2; ed += e4 - e3;
-#endif
-    }
-#ifdef LDN_TRACE_EPI
-    if (g_dense_trace && lane == 0) {
-        unsigned long long* r = g_dense_trace + ((size_t)blockIdx.x * 8 + wave) * 8;
-        r[0] = ea; r[1] = eb; r[2] = ec; r[3] = ed; r[4] = 0; r[5] = 1; r[6] = ea + eb + ec + ed; r[7] = nchunks;
-    }
-#elif defined(LDN_TRACE)
+    // ---- epilogue
+    dense_epilogue<NSUB, T9, FULL, OF>(p, acc, s_arow, s_orow, s_cls, reinterpret_cast<float*>(s_ring + wave * 4096), wave, lane, n0, nsub);
+#if defined(LDN_TRACE)
     if (g_dense_trace && lane == 0) {
         unsigned long long dend;
         DT(dend)
@@ -552,6 +531,257 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
         r[0] = a_wait; r[1] = a_bar; r[2] = a_issue; r[3] = a_prep; r[4] = a_mfma; r[5] = d_loop - d_start; r[6] = dend - d_loop; r[7] = nchunks;
     }
 #endif
+}
+
+// k_dense2 (round 5) -- k_dense's arithmetic (the same products in the same order: bit-identical results) on the staging structure that took the
+// packed 3x3 from 21 % to 35 % matrix-pipe busy (k_rows3, csrc/ldn_rows3.hip), for the whole-tile bf16x3 launches:
+//   * only the WEIGHT tile is shared between waves: ring of two slots of one K step (64 wide for tiles of <= 128 columns, 32 wide above), ONE
+//     workgroup barrier per step (k_dense: one per 32-wide chunk over a common ring that also held the activation rows);
+//   * a wave's 32 activation rows are staged by that wave alone into a private double buffer of K32 sub-chunks, ordered by its own vmcnt;
+//   * B fragments are double-buffered in registers: sub-chunk s + 1 is read -- and, unless the rows arrive pre-split (PS), split into bf16
+//     hi / lo -- BETWEEN the MFMA steps of sub-chunk s, the LDS-DMA of sub-chunk s + 3 reuses its slot right behind; the matrix pipe never
+//     waits for a split, a DMA issue or a fragment read at a chunk boundary.
+// Whole column tiles only (cout % NT == 0), cin a multiple of the K step, cin <= 2048; T9 = the 3x3 through a neighbour table (tap-major K).
+template <int NSUB, bool T9, bool PS, bool OF>
+__global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
+    constexpr int NT = NSUB * 32;
+    constexpr int KS = NSUB <= 4 ? 64 : 32;               // K elements of one weight step
+    constexpr int SPS = KS / 32;                          // K32 sub-chunks per step
+    constexpr int WROWB = KS * 4;                         // bytes of a staged weight row
+    constexpr int UPR = WROWB / 16;                       // its 16-byte units (16 / 8), XOR-swizzled by the row
+    constexpr int RPI = 1024 / WROWB;                     // weight rows per 1-KB DMA instruction (4 / 8)
+    constexpr int NWI = (NT + 8 * RPI - 1) / (8 * RPI);   // weight DMA instructions per wave and step
+    constexpr int WSLOT = NWI * 8 * 1024;                 // (160-column tiles: padded to whole instructions)
+    constexpr int RSLOT = 32 * 128;                       // one wave's 32 rows of one K32 sub-chunk
+    constexpr int D_ROWS = 256, NST = 2 * NSUB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* const s_arow = reinterpret_cast<int*>(smem);
+    int* const s_orow = s_arow + D_ROWS;
+    int* const s_cls = s_orow + D_ROWS;                   // (T9 only)
+    int* const s_atap = s_cls + D_ROWS;                   // (T9 only) [256][9]
+    unsigned char* const s_w = smem + (T9 ? 12 : 2) * D_ROWS * 4;
+    unsigned char* const s_r = s_w + 2 * WSLOT;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+    const int nt = slot_i % p.ntn, mt = (slot_i / p.ntn) * 8 + xcd;
+    if (mt >= p.mtn) return;
+    const int M = p.m_count ? min(p.m_count[0], p.m_cap) : p.m_cap;
+    const int m0 = mt * D_ROWS;
+    if (m0 >= M) return;
+    const int rows = min(D_ROWS, M - m0);
+    const int n0 = nt * NT;
+
+    if (tid < D_ROWS) {
+        int ar = -1, orw = -1;
+        if (tid < rows) {
+            ar = (p.a_rows && !T9) ? p.a_rows[m0 + tid] : m0 + tid;
+            orw = p.out_rows ? p.out_rows[m0 + tid] : m0 + tid;
+            if (p.relu == 1 || (p.relu == 2 && p.relu_if_neg[m0 + tid] < 0)) orw |= D_ROW_RELU;
+        }
+        int cls = 0;
+        if (T9 && tid < rows && p.shift_classes > 1) {
+            const int q = p.pix_map[m0 + tid] % (p.Ho * p.Wo);
+            const int oy = q / p.Wo, ox = q - oy * p.Wo;
+            const int top = oy * p.stride - 1 < 0, bot = oy * p.stride + 1 >= p.Hi;
+            const int lef = ox * p.stride - 1 < 0, rig = ox * p.stride + 1 >= p.Wi;
+            cls = ((top | (bot << 1)) * 4 + (lef | (rig << 1))) * p.cout;
+        }
+        LDN_DCHECK(tid >= rows || (ar >= -1 && (orw & (D_ROW_RELU - 1)) >= 0), 501);
+        s_arow[tid] = ar;
+        s_orow[tid] = orw;
+        if (T9) s_cls[tid] = cls;
+    }
+    if (T9)
+        for (int i = tid; i < D_ROWS * 9; i += 512) {
+            const int r = i / 9;
+            s_atap[i] = r < rows ? p.a_rows[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
+        }
+    __syncthreads();
+
+    const bool active = wave * 32 < rows;
+    const int cpt = p.cin >> 5;                           // K32 sub-chunks per tap
+    const int nsubc = (T9 ? 9 : 1) * cpt, nstep = nsubc / SPS;
+    const long wrow = (long)(T9 ? 9 : 1) * p.cin * 4;     // bytes per weight row
+    const unsigned lds_w = d_lds_off(s_w), lds_r = d_lds_off(s_r) + (unsigned)wave * 2u * RSLOT;
+    unsigned char* const my_r = s_r + wave * 2 * RSLOT;
+    const unsigned char* const zrow = reinterpret_cast<const unsigned char*>(g_dense_zero);
+
+    // per-lane sources (see k_rows3): weights advance by one step's bytes per step, steps past the end re-read the last one
+    const unsigned char* wsrc[NWI];
+#pragma unroll
+    for (int k = 0; k < NWI; ++k) {
+        const int rr = 8 * RPI * k + RPI * wave + lane / UPR;
+        const int sw = UPR == 16 ? (rr & 15) : ((rr >> 1) & 7);
+        wsrc[k] = rr < NT ? p.ws + (long)(n0 + rr) * wrow + (((lane % UPR) ^ sw) << 4) : zrow;
+    }
+    auto dma_w = [&](int S, int k) {
+        const bool pad = NT % (8 * RPI) != 0 && 8 * RPI * k + RPI * wave >= NT;       // (wave-uniform: a padding instruction of a 160-column tile)
+        d_dma16(wsrc[k] + (pad ? 0l : (long)min(S, nstep - 1) * WROWB),
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_w + (unsigned)(S & 1) * WSLOT + (unsigned)(8 * RPI * k + RPI * wave) * WROWB)));
+    };
+    const unsigned char* rsrc[4];
+    int tap_r = 0, ck_r = 0;
+    auto load_tap = [&](int tap) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 8 * k + (lane >> 3);
+            const int ar = T9 ? s_atap[(wave * 32 + r) * 9 + tap] : s_arow[wave * 32 + r];
+            const unsigned char* base = ar >= 0 ? reinterpret_cast<const unsigned char*>(p.a) + (long)ar * p.lda * 4 : zrow;
+            rsrc[k] = base + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        }
+    };
+    auto dma_r = [&](int s, int k) {
+        d_dma16(rsrc[k] + ck_r * 128, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_r + (unsigned)(s & 1) * RSLOT + (unsigned)k * 1024u)));
+    };
+    auto next_r = [&]() {
+        if (++ck_r == cpt) {
+            ck_r = 0;
+            if (T9) {
+                tap_r = min(tap_r + 1, 8);
+                load_tap(tap_r);
+            }
+        }
+    };
+
+    if (!active) {
+        for (int k = 0; k < NWI; ++k) dma_w(0, k);
+        for (int S = 0; S < nstep; ++S) {
+            d_wait_vm<0>();
+            d_lds_barrier();
+            for (int k = 0; k < NWI; ++k) dma_w(S + 1, k);
+        }
+        d_wait_vm<0>();
+        return;
+    }
+
+    f32x16 acc[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    bf16x8 bh[2][2], bl[2][2];          // B fragments: [register set = sub-chunk parity][K16 half]
+    f32x4 raw[4];                       // (!PS) a sub-chunk's fp32 values between their LDS read and their split
+    const unsigned xsw = ((unsigned)l31 >> 1) & 7u;
+    const unsigned wsw = UPR == 16 ? ((unsigned)l31 & 15u) : (((unsigned)l31 >> 1) & 7u);
+    auto read_b = [&](int s, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
+        const unsigned char* xs = my_r + (s & 1) * RSLOT + l31 * 128;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned sl = 4u * half + 2u * h;
+            if constexpr (PS) {
+                dh[half] = *reinterpret_cast<const bf16x8*>(xs + ((sl ^ xsw) << 4));
+                dl[half] = *reinterpret_cast<const bf16x8*>(xs + (((sl + 1) ^ xsw) << 4));
+            } else {
+                raw[2 * half] = *reinterpret_cast<const f32x4*>(xs + ((sl ^ xsw) << 4));
+                raw[2 * half + 1] = *reinterpret_cast<const f32x4*>(xs + (((sl + 1) ^ xsw) << 4));
+            }
+        }
+    };
+    auto split_b = [&](int half, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
+        if constexpr (!PS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = e < 4 ? raw[2 * half][e] : raw[2 * half + 1][e - 4];
+                const __bf16 hb = (__bf16)v;
+                dh[half][e] = hb;
+                dl[half][e] = (__bf16)(v - (float)hb);
+            }
+        }
+    };
+
+    // prologue: W(0), R(0), R(1); B(0) -> registers; R(2) into R(0)'s slot
+    load_tap(0);
+#pragma unroll
+    for (int k = 0; k < NWI; ++k) dma_w(0, k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_r(0, k);
+    next_r();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_r(1, k);
+    next_r();
+    d_wait_vm<4>();
+    read_b(0, bh[0], bl[0]);
+    split_b(0, bh[0], bl[0]);
+    split_b(1, bh[0], bl[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_r(2, k);
+    next_r();
+    if constexpr (SPS == 1) d_wait_vm<4>();         // (one sub-chunk per step: R(1) has landed before the loop's counted waits start)
+
+    // in-order completion: what may still be outstanding at each wait (see k_rows3):
+    //   two sub-chunks per step:  W(S): vmcnt(8);  R(s + 1): vmcnt(4 + NWI)        one per step:  W(S): vmcnt(4);  R(s + 1): vmcnt(4 + 2 NWI)
+    // one weight step: barrier, then its SPS sub-chunks; CUR0 = register set of its first sub-chunk (compile-time)
+    auto step = [&](int S, auto cur0_c) {
+        constexpr int CUR0 = decltype(cur0_c)::value;
+        d_wait_vm<SPS == 2 ? 8 : 4>();
+        d_lds_barrier();
+        const unsigned char* wsl = s_w + (S & 1) * WSLOT + l31 * WROWB;
+        // the body of one sub-chunk with B set CUR: MFMA steps with, between them, W(S + 1) (first sub-chunk of the step), the read (+ split) of
+        // sub-chunk s + 1 into the other set, and R(s + 3)
+        auto body = [&](auto sub_c, auto cur_c) {
+            constexpr int sub = decltype(sub_c)::value, CUR = decltype(cur_c)::value;
+            const int s = SPS * S + sub;
+            auto frag = [&](int st, bf16x8& ah, bf16x8& al) {
+                const int half = st / NSUB, j = st - half * NSUB;
+                const unsigned uu = 2u * ((SPS == 2 ? 4u * sub : 0u) + 2u * half + h);
+                ah = *reinterpret_cast<const bf16x8*>(wsl + j * (32 * WROWB) + ((uu ^ wsw) << 4));
+                al = *reinterpret_cast<const bf16x8*>(wsl + j * (32 * WROWB) + (((uu + 1) ^ wsw) << 4));
+            };
+            bf16x8 ah[2], al[2];
+            frag(0, ah[0], al[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int rd_at = sub == 0 ? (NWI < NST - 1 ? NWI : NST - 2) : 0;
+            int r_done = 0, w_done = 0, sp_done = PS ? 2 : 0;
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (st + 1 < NST) frag(st + 1, ah[(st + 1) & 1], al[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int half = st / NSUB, j = st - half * NSUB;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st & 1], bh[CUR][half], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bl[CUR][half], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bh[CUR][half], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sub == 0 && st < rd_at) {
+                    if (w_done < NWI) dma_w(S + 1, w_done++);
+                } else if (st == rd_at) {
+                    if (sub == 0)
+                        while (w_done < NWI) dma_w(S + 1, w_done++);
+                    d_wait_vm<SPS == 2 ? 4 + NWI : 4 + 2 * NWI>();
+                    read_b(s + 1, bh[CUR ^ 1], bl[CUR ^ 1]);
+                } else if (sp_done < 2) {
+                    split_b(sp_done++, bh[CUR ^ 1], bl[CUR ^ 1]);      // (waits for the raw reads: they were issued a whole MFMA step ago)
+                } else {
+                    if (r_done == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (r_done < 4) dma_r(s + 3, r_done++);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            while (sp_done < 2) split_b(sp_done++, bh[CUR ^ 1], bl[CUR ^ 1]);
+            if (r_done == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            while (r_done < 4) dma_r(s + 3, r_done++);
+            next_r();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        body(std::integral_constant<int, 0>{}, std::integral_constant<int, CUR0>{});
+        if constexpr (SPS == 2) body(std::integral_constant<int, 1>{}, std::integral_constant<int, CUR0 ^ 1>{});
+    };
+    if constexpr (SPS == 2) {
+        for (int S = 0; S < nstep; ++S) step(S, std::integral_constant<int, 0>{});
+    } else {      // one sub-chunk per step: the register sets alternate between steps -- two steps per iteration (cin % 64 == 0: an even count)
+        for (int S = 0; S < nstep; S += 2) {
+            step(S, std::integral_constant<int, 0>{});
+            step(S + 1, std::integral_constant<int, 1>{});
+        }
+    }
+    d_wait_vm<0>();        // the trailing re-reads have landed: this wave's row slots become its 32 x 32 transpose scratch (private: no barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    dense_epilogue<NSUB, T9, true, OF>(p, acc, s_arow, s_orow, s_cls, reinterpret_cast<float*>(my_r), wave, lane, n0, NSUB);
 }
 
 // LayerNorm statistics of the rows of a [rows, C] matrix: stats[r] = {mean, 1 / sqrt(var + eps)} (biased variance, as nn.LayerNorm),
@@ -605,6 +835,25 @@ static int launch_dense_f(DenseArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((k_dense<NSUB, T9, FULL, F32, R, PS, OF>), dim3(grid), dim3(2 * R), lds, st, a);
     LDN_CHECK_LAUNCH("k_dense");
     return LDN_OK;
+}
+
+template <int NSUB, bool T9, bool PS, bool OF>
+static int launch_dense2(DenseArgs& a, hipStream_t st) {
+    constexpr int NT = NSUB * 32, KS = NSUB <= 4 ? 64 : 32, WROWB = KS * 4, RPI = 1024 / WROWB, NWI = (NT + 8 * RPI - 1) / (8 * RPI);
+    const size_t lds = (size_t)(T9 ? 12 : 2) * 256 * 4 + 2 * (size_t)NWI * 8 * 1024 + 8 * 2 * (size_t)32 * 128;
+    a.ntn = a.cout / NT;
+    a.mtn = ceil_div(a.m_cap, 256);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense2<NSUB, T9, PS, OF>), lds), "k_dense2: cannot reserve %zu B of LDS", lds);
+    const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
+    hipLaunchKernelGGL((k_dense2<NSUB, T9, PS, OF>), dim3(grid), dim3(512), lds, st, a);
+    LDN_CHECK_LAUNCH("k_dense2");
+    return LDN_OK;
+}
+// can k_dense2 run this launch with tiles of ns * 32 columns?  (whole column tiles, cin a multiple of the tile's K step, a zero row of cin floats)
+static bool dense2_ok(int ns, int taps, int cin, int cout) {
+    static const bool on = !(getenv("LDN_DENSE_V2") && atoi(getenv("LDN_DENSE_V2")) == 0);
+    static const int max_ns = getenv("LDN_DENSE_V2_MAXNS") ? atoi(getenv("LDN_DENSE_V2_MAXNS")) : 8;      // (tuning: widest tile that takes k_dense2)
+    return on && ns <= max_ns && cout % (ns * 32) == 0 && cin % 64 == 0 && cin <= 2048 && (taps == 1 || ns <= 4);
 }
 
 template <int NSUB, bool T9, bool F32 = false>
@@ -767,23 +1016,27 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
             }
         }
         if (!best) best = (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) ? 8 : (cout % 128 == 0 ? 4 : 2);
+        const bool v2 = dense2_ok(best, 1, cin, cout);
         if (ps && !of) {
             switch (best) {
-                case 8: return launch_dense_f<8, false, true, false, 256, true, false>(d, st);
-                case 4: return launch_dense_f<4, false, true, false, 256, true, false>(d, st);
-                default: return launch_dense_f<2, false, true, false, 256, true, false>(d, st);
+                case 8: return v2 ? launch_dense2<8, false, true, false>(d, st) : launch_dense_f<8, false, true, false, 256, true, false>(d, st);
+                case 4: return v2 ? launch_dense2<4, false, true, false>(d, st) : launch_dense_f<4, false, true, false, 256, true, false>(d, st);
+                default: return v2 ? launch_dense2<2, false, true, false>(d, st) : launch_dense_f<2, false, true, false, 256, true, false>(d, st);
             }
         }
         LDN_REQUIRE(!ps, "ldn_conv_rows_ps: pre-split on both sides is not built");
         switch (best) {
-            case 8: return launch_dense_f<8, false, true, false, 256, false, true>(d, st);
-            case 4: return launch_dense_f<4, false, true, false, 256, false, true>(d, st);
-            default: return launch_dense_f<2, false, true, false, 256, false, true>(d, st);
+            case 8: return v2 ? launch_dense2<8, false, false, true>(d, st) : launch_dense_f<8, false, true, false, 256, false, true>(d, st);
+            case 4: return v2 ? launch_dense2<4, false, false, true>(d, st) : launch_dense_f<4, false, true, false, 256, false, true>(d, st);
+            default: return v2 ? launch_dense2<2, false, false, true>(d, st) : launch_dense_f<2, false, true, false, 256, false, true>(d, st);
         }
     }
     if (taps == 9) {
         if (small_grid) return launch_dense_f<4, true, true, false, 128>(d, st);
-        if (use_model && rows_known > 0 && cout % 128 == 0 && tile_cost(2) < tile_cost(4)) return launch_dense_f<2, true, true>(d, st);
+        if (use_model && rows_known > 0 && cout % 128 == 0 && tile_cost(2) < tile_cost(4))
+            return dense2_ok(2, 9, cin, cout) ? launch_dense2<2, true, false, false>(d, st) : launch_dense_f<2, true, true>(d, st);
+        if (cout % 128 == 0 && dense2_ok(4, 9, cin, cout)) return launch_dense2<4, true, false, false>(d, st);
+        if (cout % 128 != 0 && cout <= 64 && dense2_ok(2, 9, cin, cout)) return launch_dense2<2, true, false, false>(d, st);
         return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true>(d, st) : launch_dense<2, true>(d, st);
     }
     if (use_model && rows_known > 0 && !small_grid) {
@@ -794,19 +1047,20 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
             const double cost = tile_cost(ns);
             if (!best || cost < best_cost) { best = ns; best_cost = cost; }
         }
+        const bool v2 = best && dense2_ok(best, 1, cin, cout);
         switch (best) {
-            case 8: return launch_dense_f<8, false, true>(d, st);
-            case 6: return launch_dense_f<6, false, true>(d, st);
-            case 5: return launch_dense_f<5, false, true>(d, st);
-            case 4: return launch_dense_f<4, false, true>(d, st);
-            case 2: return launch_dense_f<2, false, true>(d, st);
+            case 8: return v2 ? launch_dense2<8, false, false, false>(d, st) : launch_dense_f<8, false, true>(d, st);
+            case 6: return v2 ? launch_dense2<6, false, false, false>(d, st) : launch_dense_f<6, false, true>(d, st);
+            case 5: return v2 ? launch_dense2<5, false, false, false>(d, st) : launch_dense_f<5, false, true>(d, st);
+            case 4: return v2 ? launch_dense2<4, false, false, false>(d, st) : launch_dense_f<4, false, true>(d, st);
+            case 2: return v2 ? launch_dense2<2, false, false, false>(d, st) : launch_dense_f<2, false, true>(d, st);
             default: break;
         }
     }
-    if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return launch_dense<8, false>(d, st);
+    if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return dense2_ok(8, 1, cin, cout) ? launch_dense2<8, false, false, false>(d, st) : launch_dense<8, false>(d, st);
     if (small_grid) return launch_dense_f<4, false, true, false, 128>(d, st);
-    if (cout % 128 == 0) return launch_dense<4, false>(d, st);
-    if (cout <= 64) return launch_dense<2, false>(d, st);
+    if (cout % 128 == 0) return dense2_ok(4, 1, cin, cout) ? launch_dense2<4, false, false, false>(d, st) : launch_dense<4, false>(d, st);
+    if (cout <= 64) return dense2_ok(2, 1, cin, cout) ? launch_dense2<2, false, false, false>(d, st) : launch_dense<2, false>(d, st);
     // 160-column tiles: layers whose width is a multiple of 160 (320: two whole tiles instead of 128 + 128 + 64), and ragged widths
     // above 128 (144 in one tile; 784 = 4 x 160 + 144) -- LAD-RegNet
     static const bool use5 = !getenv("LDN_DENSE_NO5");

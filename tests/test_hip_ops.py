@@ -497,7 +497,7 @@ def test_expand_mask_module_vs_reference_fixtures(ops):
 def test_dense_kernel_3x3_neighbour_table(ops, B, H, C, cout, stride, math_mode):
     """k_dense's 3x3 form (ldn_conv_rows_split / ldn_conv_rows_f32, taps == 9): same result as round 1's kernel on the spatial-mode slice
     mask -> index -> 3x3 through the neighbour table, in both arithmetic modes (round 4: the fp32 mode has its own k_dense form, opt-in)."""
-    f32_before = ops.USE_DENSE_F32
+    f32_before, taps_before = ops.USE_DENSE_F32, ops.DENSE_TAPS
     ops.USE_DENSE_F32 = True
     Ho = H // stride if stride > 1 else H
     patch = seeded_bernoulli((B, Ho, Ho), 0.5, 11)
@@ -513,7 +513,7 @@ def test_dense_kernel_3x3_neighbour_table(ops, B, H, C, cout, stride, math_mode)
             ops.conv_rows(h1, w, sc.to(DEV), sh.to(DEV), out, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1)
             outs.append(out.cpu())
         finally:
-            ops.DENSE_TAPS = (1,)
+            ops.DENSE_TAPS = taps_before          # (restored, not reset: later tests compare against the k_dense 3x3 form bit for bit)
             ops.USE_DENSE_F32 = f32_before if taps_set == (1, 9) else True
     n = int(ix.cnt[0])
     assert torch.allclose(outs[0][:n], outs[1][:n], atol=1e-4, rtol=1e-4)

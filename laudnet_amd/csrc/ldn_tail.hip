@@ -21,6 +21,7 @@
 // across the barriers of chunks c and c+1).
 #include "ldn_common.h"
 #include "ldn_mlp.h"
+#include <type_traits>
 
 namespace ldn {
 
@@ -282,29 +283,33 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
                                              : reinterpret_cast<const unsigned char*>(g_tail_zero);
         dma16(src, lds_h1 + buf * p.slice_bytes + q * 1024);
     };
-    auto dma_w2x = [&](int c, int s, int t) {       // chunk c (W2 slot c % 3) = tap t of K slice s
+    // W2 chunk c (W2 slot c % 3) = tap t of K slice s; e = 0 / 1: this wave's first / second k-pair row (the two halves of its share)
+    auto dma_w2e = [&](int c, int s, int t, int e) {
         const unsigned slot = lds_w2 + (c % T_W2_SLOTS) * W2_SLOT;
+        const int u = 2 * wave + (NS == 2 ? (lane >> 5) : e);            // k-pair row of the slice
+        const int kch = s_kidx[32 * s + 2 * u];                          // -1 beyond the image's list
+        const long rowoff = ((long)t * (W / 2) + (kch >> 1)) * (W / 2) * 16;
+        if (NS == 2) {
+            if (e == 1) return;
+            const unsigned char* src = (kch >= 0 && npo[0] >= 0) ? p.w2p + rowoff + npo[0] : reinterpret_cast<const unsigned char*>(g_tail_zero);
+            dma16(src, slot + 2 * wave * W2_ROW);
+        } else if (NS == 4) {
+            const unsigned char* src = (kch >= 0 && npo[0] >= 0) ? p.w2p + rowoff + npo[0] : reinterpret_cast<const unsigned char*>(g_tail_zero);
+            dma16(src, slot + u * W2_ROW);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int u = 2 * wave + (NS == 2 ? (lane >> 5) : e);            // k-pair row of the slice
-            const int kch = s_kidx[32 * s + 2 * u];                          // -1 beyond the image's list
-            const long rowoff = ((long)t * (W / 2) + (kch >> 1)) * (W / 2) * 16;
-            if (NS == 2) {
-                if (e == 1) break;
-                const unsigned char* src = (kch >= 0 && npo[0] >= 0) ? p.w2p + rowoff + npo[0] : reinterpret_cast<const unsigned char*>(g_tail_zero);
-                dma16(src, slot + 2 * wave * W2_ROW);
-            } else if (NS == 4) {
-                const unsigned char* src = (kch >= 0 && npo[0] >= 0) ? p.w2p + rowoff + npo[0] : reinterpret_cast<const unsigned char*>(g_tail_zero);
-                dma16(src, slot + u * W2_ROW);
-            } else {
-#pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    if (f == 1 && Kp <= 128) break;
-                    const unsigned char* src = (kch >= 0 && npo[f] >= 0) ? p.w2p + rowoff + npo[f] : reinterpret_cast<const unsigned char*>(g_tail_zero);
-                    dma16(src, slot + u * W2_ROW + f * 1024);
-                }
+            for (int f = 0; f < 2; ++f) {
+                if (f == 1 && Kp <= 128) break;
+                const unsigned char* src = (kch >= 0 && npo[f] >= 0) ? p.w2p + rowoff + npo[f] : reinterpret_cast<const unsigned char*>(g_tail_zero);
+                dma16(src, slot + u * W2_ROW + f * 1024);
             }
         }
+    };
+    auto dma_w2x = [&](int c, int s, int t) { dma_w2e(c, s, t, 0); dma_w2e(c, s, t, 1); };
+    // the dummies that stand in for half e of a W2 tile beyond the K range (they keep the counted wait's arithmetic constant)
+    auto dma_w2_dummy = [&](int c, int e) {
+        const int n = NS == 2 ? (e == 0 ? 1 : 0) : (NS == 4 ? 1 : (Kp > 128 ? 2 : 1));
+        for (int i = 0; i < n; ++i) dma16(g_tail_zero, lds_w2 + (c % T_W2_SLOTS) * W2_SLOT + (2 * wave) * W2_ROW);
     };
     auto dma_w2 = [&](int c) { dma_w2x(c, c / 9, c % 9); };   // stride 1: taps in order
     auto wait_chunk = [&]() {   // everything but this wave's last n_w2 DMA instructions (= the W2 pieces of the NEXT chunk) has landed
@@ -375,6 +380,72 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
         dma_w2(1);                                              // nchunks >= 9
     }
     TT(tr1)
+#ifdef LDN_TAIL_HALF_MAJOR   // (measured neutral on the headline, round 5: 12.15-12.31 vs 12.25 ms; kept as a switch)
+    // Round 5: the chunk body in HALF-MAJOR order (K16 half 0 of every n-subtile, then half 1 -- per accumulator the same order of products)
+    // with the B fragment of the NEXT tap read in place: the next tap's rows are rows of the SAME resident slice, so its half-0 fragment
+    // replaces this tap's as soon as the half-0 steps have issued, its half-1 fragment at the end of the chunk -- no fragment read sits
+    // between the barrier and the first MFMA (once per slice, at tap 0, it still does), and the chunk's DMA instructions go out behind the
+    // first MFMA steps instead of in front of them.  (k_dense2 / k_rows3, DESIGN.md 4u: what the barrier -> first-MFMA path costs.)
+    bf16x8 bh[2], bl[2];
+    auto load_b_half = [&](const unsigned char* hs_, int tr, int half) {
+        const unsigned rbase = (unsigned)tr * 128u, rx = ((unsigned)tr >> 1) & 7u;
+        const unsigned sl = 2u * (2u * half + h);
+        bh[half] = *reinterpret_cast<const bf16x8*>(hs_ + rbase + ((sl ^ rx) << 4));
+        bl[half] = *reinterpret_cast<const bf16x8*>(hs_ + rbase + (((sl + 1) ^ rx) << 4));
+    };
+    for (int s = 0; s < nsub; ++s) {
+        const unsigned char* hs = s_h1 + (s % SLICE_BUFS) * p.slice_bytes;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {                           // chunk c = 9 s + t lives in W2 slot c % 3 == t % 3
+            const int c = 9 * s + t;
+            TT(ta)
+            wait_chunk();
+            lds_barrier();     // chunk c (and, when t == 0, slice s) is in LDS for every wave; every wave has left chunk c - 1
+            if (SLICE_BUFS == 1 && t == 0 && s > 0) {   // single slice slot: every wave has left slice s - 1 -> fetch slice s now (the
+                for (int q = wave; q < nq; q += 8) dma_h1(s, q);   // co-resident workgroup covers the stall)
+                wait_vm<0>();
+                lds_barrier();
+            }
+            TT(tb)
+            TT_ADD(w2wait, ta, tb)
+            // this chunk's DMA instructions in the order the counted wait relies on: group 0 = the next slice's share, groups 1, 2 = the two
+            // halves of this wave's share of the W2 tile of chunk c + 2
+            auto issue = [&](int g) {
+                if (g == 0) {
+                    if (SLICE_BUFS == 2 && s + 1 < nsub) { const int q = t * 8 + wave; if (q < nq) dma_h1(s + 1, q); }
+                } else if (c + 2 < nchunks) {
+                    dma_w2e(c + 2, (c + 2) / 9, (c + 2) % 9, g - 1);
+                } else {
+                    dma_w2_dummy(t + 2, g - 1);
+                }
+            };
+            if (!active) { issue(0); issue(1); issue(2); continue; }
+            if (t == 0) { load_b_half(hs, trow[0], 0); load_b_half(hs, trow[0], 1); }
+            const unsigned char* ws = s_w2 + (t % T_W2_SLOTS) * W2_SLOT;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    if (j < nsub) {
+                        u32x2 e[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = *reinterpret_cast<const u32x2*>(ws + a_lane + (8 * half + q) * W2_ROW + j * 256);
+                        const u32x4 ahu = F32 ? u32x4{e[0][0], e[0][1], e[1][0], e[1][1]} : u32x4{e[0][0], e[1][0], e[2][0], e[3][0]};
+                        const u32x4 alu = F32 ? u32x4{e[2][0], e[2][1], e[3][0], e[3][1]} : u32x4{e[0][1], e[1][1], e[2][1], e[3][1]};
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
+                        LDN_K16(F32, acc[j], ah, al, bh[half], bl[half])
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, F32 ? 8 : 3, 0);
+                    }
+                    if (j == 0) {      // (n-subtile 0 always exists) the DMA goes out behind the first step of each half
+                        if (half == 0) { issue(0); issue(1); } else issue(2);
+                    }
+                }
+                if (t < 8) load_b_half(hs, trow[t + 1], half);      // the next tap's fragment of this half, in place
+            }
+        }
+    }
+#else
     for (int s = 0; s < nsub; ++s) {
         const unsigned char* hs = s_h1 + (s % SLICE_BUFS) * p.slice_bytes;
 #pragma unroll
@@ -410,6 +481,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
 #endif
         }
     }
+#endif
     }   // ST == 1
     wait_vm<0>();
     lds_barrier();         // every wave is out of the conv2 loop: the slice / W2 regions are free
@@ -1187,9 +1259,221 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
     }
 }
 
+// head_body2 (round 5) -- conv1 of a channel-mode block on the staging structure of k_rows3 / k_dense2, bf16x3:
+//   * the image's gathered weight rows are the only thing the waves share: ring of TWO slots of one K32 step, one barrier per step;
+//   * a wave's 32 x rows are staged by that wave alone into a private double buffer (its own vmcnt, no barrier);
+//   * the B fragments are double-buffered in registers: step s + 1's rows are read and split BETWEEN the MFMAs of step s, the DMA of step
+//     s + 3 reuses their slot right behind -- nothing but the barrier itself sits between two steps' MFMAs.
+// Same products in the same order as head_body (chunk by chunk, K16 half 0 then half 1 per accumulator): bit-identical h1.
+template <int NS>
+__device__ __forceinline__ void head_body2(const HeadArgs& p, const int b, const int mb, unsigned char* const smem, const int tid) {
+    constexpr int W = NS * 32;
+    constexpr int WSLOT = W * 128;                    // a K32 step of (up to) W gathered weight rows, 16-byte units XOR-swizzled by ((row >> 1) & 7)
+    constexpr int RSLOT = 32 * 128;
+    constexpr int NWM = W / 64;                       // weight DMA instructions per wave and step when the image keeps every channel
+    int* const s_nidx = reinterpret_cast<int*>(smem);                    // [W + 32]
+    float* const s_tab = reinterpret_cast<float*>(smem + T_KIDX_BYTES);  // sc1 | sh1 | ps1 of the packed columns, 3 x W
+    unsigned char* const s_w = smem + T_KIDX_BYTES + 3 * W * 4;
+    unsigned char* const s_r = s_w + 2 * WSLOT;
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = mb * p.pix_per_blk;
+    const int npix = min(p.pix_per_blk, p.HW - m0);
+    const long row0 = (long)b * p.HW + m0;
+
+    const int Nb = min(p.n_cnt[b], W);
+    const int nsub = __builtin_amdgcn_readfirstlane(ceil_div(Nb, 32));
+    const int nw = __builtin_amdgcn_readfirstlane(ceil_div(max(Nb, 1), 64));      // weight DMA instructions per wave and step (64 rows each over the 8 waves)
+    if (tid < W + 32) s_nidx[tid] = tid < Nb ? p.n_idx[(size_t)b * W + tid] : -1;
+    __syncthreads();
+    for (int i = tid; i < 3 * W; i += 512) {
+        const int k = i / W, n = i - k * W;
+        const int ch = s_nidx[n];
+        const float* src = k == 0 ? p.sc1 : (k == 1 ? p.sh1 : p.ps1);
+        s_tab[i] = ch >= 0 ? src[ch] : 0.f;
+    }
+    const int nstep = p.cin / 32;
+    const unsigned lds_w = lds_off(s_w), lds_r = lds_off(s_r) + (unsigned)wave * 2u * RSLOT;
+    unsigned char* const my_r = s_r + wave * 2 * RSLOT;
+    const bool active = wave * 32 < npix;
+
+    // per-lane sources: weight instruction k covers list rows 64 k + 8 wave .. + 7 (rows beyond the image's list re-read its last channel: their
+    // accumulator columns meet zero epilogue tables); x instruction k covers the wave's pixels 8 k .. 8 k + 7 (beyond the block: its last pixel, never stored)
+    const unsigned char* wsrc[NWM];
+#pragma unroll
+    for (int k = 0; k < NWM; ++k) {
+        const int rr = 64 * k + 8 * wave + (lane >> 3);
+        const int ch = s_nidx[min(rr, max(Nb, 1) - 1)];
+        wsrc[k] = p.w1s + (long)max(ch, 0) * p.cin * 4 + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
+    }
+    const unsigned char* rsrc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = 8 * k + (lane >> 3);
+        rsrc[k] = reinterpret_cast<const unsigned char*>(p.x + (row0 + min(wave * 32 + r, npix - 1)) * p.ldx) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    }
+    auto dma_w = [&](int S, int k) {
+        dma16(wsrc[k] + (long)min(S, nstep - 1) * 128, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_w + (unsigned)(S & 1) * WSLOT + (unsigned)(64 * k + 8 * wave) * 128u)));
+    };
+    auto dma_w_all = [&](int S) {
+#pragma unroll
+        for (int k = 0; k < NWM; ++k)
+            if (k < nw) dma_w(S, k);
+    };
+    auto dma_r = [&](int s, int k) {
+        dma16(rsrc[k] + (long)min(s, nstep - 1) * 128, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_r + (unsigned)(s & 1) * RSLOT + (unsigned)k * 1024u)));
+    };
+
+    if (!active) {      // a wave without pixels only stages its share of the weights
+        dma_w_all(0);
+        for (int S = 0; S < nstep; ++S) {
+            wait_vm_n<0>();
+            lds_barrier();
+            dma_w_all(S + 1);
+        }
+        wait_vm_n<0>();
+        return;
+    }
+
+    f32x16 acc[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    bf16x8 bh[2][2], bl[2][2];
+    f32x4 raw[4];
+    const unsigned xsw = ((unsigned)l31 >> 1) & 7u;
+    auto read_raw = [&](int s) {
+        const unsigned char* xs = my_r + (s & 1) * RSLOT + l31 * 128;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned sl = 4u * half + 2u * h;
+            raw[2 * half] = *reinterpret_cast<const f32x4*>(xs + ((sl ^ xsw) << 4));
+            raw[2 * half + 1] = *reinterpret_cast<const f32x4*>(xs + (((sl + 1) ^ xsw) << 4));
+        }
+    };
+    auto split_b = [&](int half, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = e < 4 ? raw[2 * half][e] : raw[2 * half + 1][e - 4];
+            const __bf16 hb = (__bf16)v;
+            dh[half][e] = hb;
+            dl[half][e] = (__bf16)(v - (float)hb);
+        }
+    };
+
+    // prologue: W(0), R(0), R(1); B(0) -> registers; R(2) into R(0)'s slot; R(1) landed before the loop's counted waits start
+    dma_w_all(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_r(0, k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_r(1, k);
+    wait_vm_n<4>();
+    read_raw(0);
+    split_b(0, bh[0], bl[0]);
+    split_b(1, bh[0], bl[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_r(2, k);
+    wait_vm_n<4>();
+
+    // one step with B register set CUR: [W(S) landed: vmcnt(4)] barrier | MFMA steps (K16 half 0 of every n-subtile, then half 1) with, behind
+    // the first ones, W(S + 1), the raw read of x(S + 1) [x(S + 1) landed: vmcnt(4 + 2 nw)], its split into the other set, and R(S + 3)
+    auto step = [&](int S, auto cur_c) {
+        constexpr int CUR = decltype(cur_c)::value;
+        wait_vm_n<4>();
+        lds_barrier();
+        const unsigned char* wsl = s_w + (S & 1) * WSLOT + l31 * 128;
+        int stage = 0;      // what has gone out of: 0 W(S + 1), 1 read, 2 split 0, 3 split 1, 4 R(S + 3)
+        auto extra = [&]() {
+            if (stage == 0) dma_w_all(S + 1);
+            else if (stage == 1) { wait_vm_rt(4 + 2 * nw); read_raw(S + 1); }
+            else if (stage == 2) split_b(0, bh[CUR ^ 1], bl[CUR ^ 1]);
+            else if (stage == 3) split_b(1, bh[CUR ^ 1], bl[CUR ^ 1]);
+            else if (stage == 4) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dma_r(S + 3, k);
+            }
+            ++stage;
+        };
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned uu = 2u * (2u * half + h);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                if (j < nsub) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wsl + j * 4096 + ((uu ^ xsw) << 4));
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(wsl + j * 4096 + (((uu + 1) ^ xsw) << 4));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[CUR][half], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[CUR][half], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[CUR][half], acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                }
+                // compile-time positions (n-subtile 0 always exists, 1 and 2 almost always): one extra behind each of the first steps of a half
+                if (j <= 2 && j < nsub) { __builtin_amdgcn_sched_barrier(0); extra(); __builtin_amdgcn_sched_barrier(0); }
+            }
+        }
+        while (stage < 5) extra();       // (images with fewer than three n-subtiles: the rest goes out behind the last step)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int S = 0; S < nstep; S += 2) {      // (cin % 64 == 0: an even number of steps; the register sets alternate)
+        step(S, std::integral_constant<int, 0>{});
+        step(S + 1, std::integral_constant<int, 1>{});
+    }
+    wait_vm_n<0>();      // no LDS-DMA may be in flight when the workgroup's LDS is released
+
+    // ---- epilogue (as head_body): bn1 + ReLU - c1, split, pair the half-waves, 16-byte stores of [8 hi] (lanes 0-31) / [8 lo] (lanes 32-63)
+    const int pm = wave * 32 + l31;
+    unsigned char* orow = p.h1 + (row0 + min(pm, npix - 1)) * p.h1_row_bytes;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        if (j >= nsub) continue;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int n0 = 32 * j + 8 * q4 + 4 * h;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_tab + n0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(s_tab + W + n0);
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(s_tab + 2 * W + n0);
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            unsigned hi2[2], lo2[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float v0 = fmaxf(acc[j][4 * q4 + 2 * d] * sc[2 * d] + sh[2 * d], 0.f) - ps[2 * d];
+                const float v1 = fmaxf(acc[j][4 * q4 + 2 * d + 1] * sc[2 * d + 1] + sh[2 * d + 1], 0.f) - ps[2 * d + 1];
+                const bf16x2 hh = {(__bf16)v0, (__bf16)v1};
+                const bf16x2 ll = {(__bf16)(v0 - (float)hh[0]), (__bf16)(v1 - (float)hh[1])};
+                hi2[d] = __builtin_bit_cast(unsigned, hh);
+                lo2[d] = __builtin_bit_cast(unsigned, ll);
+            }
+            u32x4 outv;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const auto r = __builtin_amdgcn_permlane32_swap(hi2[d], lo2[d], false, false);
+                outv[d] = r[0];
+                outv[2 + d] = r[1];
+            }
+            if (pm < npix) *reinterpret_cast<u32x4*>(orow + (4 * j + q4) * 32 + h * 16) = outv;
+        }
+    }
+}
+
 template <int NS, bool F32 = false>
 __global__ __launch_bounds__(512, 2) void k_head(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef LDN_HEAD_V2      // (round 5: measured neutral on the headline -- 12.11-12.26 vs 12.20 ms: conv1 of a channel block is bound by the CU's fetch of x)
+    if constexpr (!F32) {
+        if (p.xs == nullptr && p.cin % 64 == 0) {     // (wave-uniform) the round-5 staging structure; the x_split by-product keeps the old body
+            head_body2<NS>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, threadIdx.x);
+            return;
+        }
+    }
+#endif
 #ifdef LDN_HEAD_NO_PRE
     head_body<NS, F32, false>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, 160 * 1024, threadIdx.x);
 #else
@@ -1357,6 +1641,10 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
             ha.w1s = uniform_ptr(cb->w1s); ha.n_idx = idx_i; ha.n_cnt = cnt_i;
             ha.sc1 = uniform_ptr(cb->sc1); ha.sh1 = uniform_ptr(cb->sh1); ha.ps1 = uniform_ptr(cb->ps1);
             ha.h1 = p.h1; ha.h1_row_bytes = p.h1_row_bytes; ha.pix_per_blk = HW; ha.mblocks = 1; ha.xs = nullptr;
+#ifdef LDN_HEAD_V2
+            if constexpr (!F32) head_body2<NS>(ha, b, 0, smem, opaque_tid());
+            else
+#endif
             head_body<NS, F32>(ha, b, 0, smem, p.lds_total, opaque_tid());
         }
         CT(c3)

@@ -19,5 +19,6 @@ from .laud_regnet import (LAD_RegNet, BlockParams, lad_regnet_y_400mf, lad_regne
                           lad_regnet_y_1_6gf, lad_regnet_y_3_2gf, lad_regnet_y_8gf, lad_regnet_y_16gf)
 
 from . import sparsity_loss  # noqa: F401,E402  (the criteria the caller applies to the 7-tuple, train/main.py:311,670)
+from . import training  # noqa: F401,E402  (forward + backward of spatial / layer blocks under frozen BatchNorm on the packed kernels)
 
 __version__ = "0.1.0"

@@ -82,6 +82,9 @@ __device__ __forceinline__ float dpp_swap_pair(float v) {
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4_t presplit_store_quad(const f32x4 x, bool odd) {
+#ifdef LDN_OF_NOP     // tuning only (wrong values): what the conversion itself costs
+    return __builtin_bit_cast(u32x4_t, x);
+#endif
     unsigned hi[2], lo[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {

@@ -53,8 +53,8 @@ def _fold_bn(bn: nn.BatchNorm2d):
 
 def _eval_only(module: nn.Module, x: torch.Tensor):
     if module.training:
-        raise LdnError("laudnet_amd implements the eval-mode (inference) hot path only; call model.eval() "
-                       "(training-mode Gumbel masks are SURVEY 8f-4, not built)")
+        raise LdnError("laudnet_amd.laud_resnet implements the eval-mode (inference) hot path; call model.eval().  The part of training that "
+                       "is sparse -- spatial / layer blocks under frozen BatchNorm -- is laudnet_amd.training.sparse_block_train")
     if not x.is_cuda:
         raise LdnError("laudnet_amd has no CPU path: move the model and input to a HIP device")
 

@@ -85,8 +85,9 @@ constexpr int D_ROW_RELU = 1 << 30;
 
 // The epilogue of the row kernels (k_dense, k_dense2): per n-subtile, C layout (lane = row, register = channel) -> rows of 32 channels through
 // a per-wave 32 x 32 transpose scratch `scr` (4 KB of LDS owned by the wave), then the affine / residual / activation / mask terms and 16-byte stores.
-// GELU: the exact (erf) GELU of relu == 3 is compiled in (the token-skip MLP's fc1 only: ~5 000 instructions of the unrolled epilogue otherwise).
-template <int NSUB, bool T9, bool FULL, bool OF, bool GELU = true>
+// FEAT: the rarely used terms are compiled in -- the exact (erf) GELU of relu == 3, the LayerNorm fold (ln_stats), the per-image channel mask
+// and post_sub of the dense channel execution.  Without them the unrolled epilogue is half as long (k_dense2's default instantiations).
+template <int NSUB, bool T9, bool FULL, bool OF, bool FEAT = true>
 __device__ __forceinline__ void dense_epilogue(const DenseArgs& p, f32x16 (&acc)[NSUB], const int* s_arow, const int* s_orow, const int* s_cls,
                                                float* scr, int wave, int lane, int n0, int nsub) {
     const int l31 = lane & 31, h = lane >> 5;
@@ -95,7 +96,7 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs& p, f32x16 (&acc)
     int orw[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) orw[it] = s_orow[wave * 32 + trw + 8 * it];
-    const bool gelu = GELU && p.relu == 3;
+    const bool gelu = FEAT && p.relu == 3;
     // pooled patch means (1x1, whole column tiles): which patch row of `pool` this lane stores, -1 = none.  16-pixel patches: the wave's
     // rows 0-15 / 16-31; the lanes with row-in-octet 0 of each half store.  4-pixel patches: rows 4q .. 4q+3, every lane stores one.
     long poff = -1;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs& p, f32x16 (&acc)
         }
         sh = cok ? *reinterpret_cast<const f32x4*>(p.shift + cb) : f32x4{0.f, 0.f, 0.f, 0.f};   // (one class; the 16-class table is read per row below)
         sc = (p.scale && cok) ? *reinterpret_cast<const f32x4*>(p.scale + cb) : f32x4{1.f, 1.f, 1.f, 1.f};
-        ps = (p.post_sub && cok) ? *reinterpret_cast<const f32x4*>(p.post_sub + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ps = (FEAT && p.post_sub && cok) ? *reinterpret_cast<const f32x4*>(p.post_sub + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
@@ -133,7 +134,7 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs& p, f32x16 (&acc)
         // LayerNorm of the activation rows, applied AFTER the GEMM: LN(x) . w = rstd (x . w' - mean sum_k w'[k]) + const, w' = gamma * w
         float2 lst[4];
         f32x4 lc1 = {0.f, 0.f, 0.f, 0.f};
-        if (p.ln_stats) {
+        if (FEAT && p.ln_stats) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int ar = s_arow[wave * 32 + trw + 8 * it];
@@ -143,7 +144,7 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs& p, f32x16 (&acc)
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const float* src = (p.chmask && orw[it] >= 0 && cok) ? p.chmask + (size_t)((orw[it] & (D_ROW_RELU - 1)) / p.rows_per_img) * p.cout + n0 + 32 * j + tc * 4
+            const float* src = (FEAT && p.chmask && orw[it] >= 0 && cok) ? p.chmask + (size_t)((orw[it] & (D_ROW_RELU - 1)) / p.rows_per_img) * p.cout + n0 + 32 * j + tc * 4
                                                           : nullptr;
             cm[it] = src ? *reinterpret_cast<const f32x4*>(src) : f32x4{1.f, 1.f, 1.f, 1.f};
         }
@@ -164,7 +165,7 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs& p, f32x16 (&acc)
             const int row = trw + 8 * it;
             f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tc ^ (row & 7)) << 2));
             const f32x4 shr = (T9 && p.shift_classes > 1 && cok) ? *reinterpret_cast<const f32x4*>(p.shift + s_cls[wave * 32 + row] + n0 + 32 * j + tc * 4) : sh;
-            if (p.ln_stats) x = (x - lc1 * lst[it].x) * lst[it].y;
+            if (FEAT && p.ln_stats) x = (x - lc1 * lst[it].x) * lst[it].y;
             x = x * sc + shr + res[it];
             if (orw[it] & D_ROW_RELU) {
 #pragma unroll
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
 //     hi / lo -- BETWEEN the MFMA steps of sub-chunk s, the LDS-DMA of sub-chunk s + 3 reuses its slot right behind; the matrix pipe never
 //     waits for a split, a DMA issue or a fragment read at a chunk boundary.
 // Whole column tiles only (cout % NT == 0), cin a multiple of the K step, cin <= 2048; T9 = the 3x3 through a neighbour table (tap-major K).
-template <int NSUB, bool T9, bool PS, bool OF, bool GELU = false>
+template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false>
 __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
     constexpr int NT = NSUB * 32;
     constexpr int KS = NSUB <= 4 ? 64 : 32;               // K elements of one weight step
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
     }
     d_wait_vm<0>();        // the trailing re-reads have landed: this wave's row slots become its 32 x 32 transpose scratch (private: no barrier)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    dense_epilogue<NSUB, T9, true, OF, GELU>(p, acc, s_arow, s_orow, s_cls, reinterpret_cast<float*>(my_r), wave, lane, n0, NSUB);
+    dense_epilogue<NSUB, T9, true, OF, FEAT || T9>(p, acc, s_arow, s_orow, s_cls, reinterpret_cast<float*>(my_r), wave, lane, n0, NSUB);
 }
 
 // LayerNorm statistics of the rows of a [rows, C] matrix: stats[r] = {mean, 1 / sqrt(var + eps)} (biased variance, as nn.LayerNorm),
@@ -838,18 +839,18 @@ static int launch_dense_f(DenseArgs& a, hipStream_t st) {
     return LDN_OK;
 }
 
-template <int NSUB, bool T9, bool PS, bool OF, bool GELU = false>
+template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false>
 static int launch_dense2(DenseArgs& a, hipStream_t st) {
-    if constexpr (!GELU && !T9 && !PS && !OF) {       // relu == 3 (GELU) has its own instantiation of the plain 1x1 form
-        if (a.relu == 3) return launch_dense2<NSUB, T9, PS, OF, true>(a, st);
+    if constexpr (!FEAT && !T9 && !PS && !OF) {       // the plain 1x1 form has a second instantiation with the rarely used epilogue terms (T9: always in)
+        if (a.relu == 3 || a.ln_stats || a.chmask || a.post_sub) return launch_dense2<NSUB, T9, PS, OF, true>(a, st);
     }
     constexpr int NT = NSUB * 32, KS = NSUB <= 4 ? 64 : 32, WROWB = KS * 4, RPI = 1024 / WROWB, NWI = (NT + 8 * RPI - 1) / (8 * RPI);
     const size_t lds = (size_t)(T9 ? 12 : 2) * 256 * 4 + 2 * (size_t)NWI * 8 * 1024 + 8 * 2 * (size_t)32 * 128;
     a.ntn = a.cout / NT;
     a.mtn = ceil_div(a.m_cap, 256);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense2<NSUB, T9, PS, OF, GELU>), lds), "k_dense2: cannot reserve %zu B of LDS", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense2<NSUB, T9, PS, OF, FEAT>), lds), "k_dense2: cannot reserve %zu B of LDS", lds);
     const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
-    hipLaunchKernelGGL((k_dense2<NSUB, T9, PS, OF, GELU>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_dense2<NSUB, T9, PS, OF, FEAT>), dim3(grid), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_dense2");
     return LDN_OK;
 }
@@ -1010,6 +1011,7 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
         return (double)((wgs + 255) / 256) * (double)(chunks * (mc[0] + mc[1] * ns) + mc[2] * ns);
     };
     LDN_REQUIRE(!((ps || of || taps == 9) && relu == 3), "ldn_conv_rows_split: the GELU epilogue exists on the plain 1x1 form only");
+    LDN_REQUIRE(!((ps || of) && (post_sub || chan_mask || ln_stats)), "ldn_conv_rows_ps: no post_sub / chan_mask / LayerNorm terms on the pre-split forms");
     if (ps || of) {      // pre-split rows on one or both sides: 1x1, whole column tiles of 256 / 128 / 64
         int best = 0;
         double best_cost = 0.0;

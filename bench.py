@@ -873,7 +873,7 @@ def main():
                     "algorithmic_mbytes_per_launch": nbytes / n / 1e6, "algorithmic_mbytes_per_block": nbytes / n / nb / 1e6}
 
         def rows1_roofline(n, ms, flops, nbytes):
-            return two_floor("k_dense (shared-weight 1x1 over packed pixel rows: conv1 / conv3 / projection shortcuts / RegNet a, c / "
+            return two_floor("k_dense2 / k_dense (shared-weight 1x1 over packed pixel rows: conv1 / conv3 / projection shortcuts / RegNet a, c / "
                              "token-skip linears; bf16x3, averaged over all such launches of a step)", n, ms, flops, nbytes, 3.0 if mode != "fp32" else 16.0)
 
         def grouped_roofline(n, ms, flops, nbytes):
@@ -886,7 +886,7 @@ def main():
         if "rows_3x3" in objs:
             objs["rows_3x3"]["kernel"] = ("k_rows3 (3x3 conv over packed active rows on PRE-SPLIT h1 through the neighbour table, shared weights in K64 steps, bf16x3)"
                                           if getattr(timer, "rows3_kernel", False) else
-                                          "k_dense<.., T9> (3x3 conv over packed active rows through the neighbour table, shared weights, bf16x3)"
+                                          "k_dense2<.., T9> (3x3 conv over packed active rows through the neighbour table, shared weights, bf16x3; rows split between the MFMA steps)"
                                           if mode != "fp32" and 9 in ops.DENSE_TAPS and ops.USE_DENSE_KERNEL else
                                           objs["rows_3x3"]["kernel"].replace("3x3 per-image channel-subset conv", "3x3 conv over packed active rows, shared weights"))
             objs["rows_3x3"]["traffic_scope"] = objs["rows_3x3"]["traffic"] = None

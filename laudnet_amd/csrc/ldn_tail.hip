@@ -71,6 +71,13 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
+// L2 prefetch (round 5): 4 bytes per lane through the LDS-DMA path into a scratch word -- no VGPR result to keep alive, counted in vmcnt like
+// every other DMA instruction.  What it buys is the LINE in the XCD's L2 ahead of the 16-byte DMA that will fetch it for real.
+__device__ __forceinline__ void dma4_touch(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N == 0 || N == 1 || N == 2 || N == 4, "add the immediate");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1013,13 +1020,18 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
     // ring geometry: slot = [256 x rows | wrows weight rows] x 128 B; as many slots as fit (2..4)
     const int xrows = round_up(npix, 32);                                // x rows staged per chunk: whole 32-pixel subtiles of busy waves
     const int slot_bytes = (xrows + wrows) * 128;
-    const int avail = lds_total - (T_KIDX_BYTES + 3 * W * 4);
+#ifdef LDN_HEAD_L2PF     // (round 5, measured: 12.43-12.49 vs 11.99 ms -- SLOWER: the phase is not waiting on HBM latency; kept as a switch, off)
+    constexpr int PF = 1;              // one L2-prefetch instruction per wave and chunk (see dma_chunk)
+#else
+    constexpr int PF = 0;
+#endif
+    const int avail = lds_total - (T_KIDX_BYTES + 3 * W * 4) - 256;     // (256 B at the end: the scratch the prefetch words land in)
     const int D = min(4, avail / slot_bytes);                            // >= 2 for W <= 256
     const int nchunks = p.cin / 32;
     const unsigned lds_ring = lds_off(s_ring);
     const int nw = wrows / 64;                                           // weight DMA instructions per wave and chunk (1..4)
     const bool active = wave * 32 < npix;
-    const int per_chunk = (active ? 4 : 0) + nw;                         // this wave's DMA instructions per chunk (4 = its 32 x rows)
+    const int per_chunk = (active ? 4 + PF : 0) + nw;                    // this wave's DMA instructions per chunk (4 = its 32 x rows, PF = the L2 prefetch)
 
     // DMA of chunk c into slot c % D.  Wave w moves x rows [32 w, 32 w + 32) and weight rows {64 i + 8 w .. + 7} (i < nw).
     // one instruction = 8 rows x 128 B: lane = (row r0 + (lane >> 3), physical slot lane & 7); XOR swizzle on the SOURCE address.
@@ -1047,6 +1059,14 @@ __device__ __forceinline__ void head_body(const HeadArgs& p, const int b, const 
         const unsigned slot = lds_ring + (c % D) * slot_bytes;
         const int cc = min(c, nchunks - 1);              // chunks beyond the K loop: the last one again (keeps the per-iteration DMA count constant)
         if (active) dma16_pieces<4>(xo, uniform_cptr(xbase + (long)cc * 128), __builtin_amdgcn_readfirstlane(slot + wave * 32 * 128));
+        if (PF && active) {
+            // L2 prefetch of this wave's x rows two and three chunks beyond the ring (round 5): the phase is bound by bytes in
+            // flight / HBM latency at one workgroup per CU; a touched line waits in the XCD's L2 when its 16-byte DMA comes (lanes 0-31: chunk
+            // c + 2, lanes 32-63: chunk c + 3; beyond the K range the last chunk again)
+            const int pc = min(c + 2 + (lane >> 5), nchunks - 1);
+            dma4_touch(reinterpret_cast<const unsigned char*>(p.x + (row0 + min(wave * 32 + l31, npix - 1)) * p.ldx) + (long)pc * 128,
+                       __builtin_amdgcn_readfirstlane((unsigned)(lds_ring + (unsigned)avail)));
+        }
         const void* wb = uniform_cptr(wbase + (long)cc * 128);
         const unsigned wl = __builtin_amdgcn_readfirstlane(slot + (xrows + wave * nw * 8) * 128);
         if (nw == 1) dma16_pieces<1>(wo, wb, wl);

@@ -220,13 +220,15 @@ SECONDARY = ("spatial", "layer", "regnet", "adavit")     # BASELINE.json configs
 
 def run_secondary(args):
     """The other BASELINE configs, timed in the SAME invocation as the headline: each one is this script
-    again (`--workload W --steps 10 --warmup 5 --brief`, its own process on the same GPU, after the headline's timed region and legs
+    again (`--workload W --steps 10 --warmup 5 --brief`; 30 + 10 for the two short workloads, its own process on the same GPU, after the headline's timed region and legs
     are done) -- 5 warm-up + 10 timed forwards at batch 256, masks produced by the maskers in the timed region, the oracle's dense
     emulation on the same GPU and the same-mask parity beside it.  Values are per-workload JSON lines reduced to the judged keys."""
     import subprocess
     out = {}
     for w in SECONDARY:
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "10", "--warmup", "5", "--batch", str(args.batch), "--brief"]
+        # (short workloads get more forwards: ten 3.5 ms RegNet steps right after a cold start read 2-3x slow on some boxes -- clocks still ramping)
+        n_steps, n_warm = ("30", "10") if w in ("regnet", "adavit") else ("10", "5")
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", n_steps, "--warmup", n_warm, "--batch", str(args.batch), "--brief"]
         t0 = time.perf_counter()
         try:
             pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)

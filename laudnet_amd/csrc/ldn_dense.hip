@@ -544,8 +544,11 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
 //     hi / lo -- BETWEEN the MFMA steps of sub-chunk s, the LDS-DMA of sub-chunk s + 3 reuses its slot right behind; the matrix pipe never
 //     waits for a split, a DMA issue or a fragment read at a chunk boundary.
 // Whole column tiles only (cout % NT == 0), cin a multiple of the K step, cin <= 2048; T9 = the 3x3 through a neighbour table (tap-major K).
-template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false>
+// RAG (1x1, fp32 rows): any cin % 8 == 0 (the K tail of the last sub-chunk / step is zero-sourced in both DMA streams) and a ragged last column tile (columns >= cout are
+// neither staged nor stored) -- LAD-RegNet's 144- and 784-wide layers.
+template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false, bool RAG = false>
 __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
+    static_assert(!RAG || (!T9 && !PS && !OF), "the ragged form is the plain 1x1");
     constexpr int NT = NSUB * 32;
     constexpr int KS = NSUB <= 4 ? 64 : 32;               // K elements of one weight step
     constexpr int SPS = KS / 32;                          // K32 sub-chunks per step
@@ -604,8 +607,9 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
     __syncthreads();
 
     const bool active = wave * 32 < rows;
-    const int cpt = p.cin >> 5;                           // K32 sub-chunks per tap
-    const int nsubc = (T9 ? 9 : 1) * cpt, nstep = nsubc / SPS;
+    const int cpt = RAG ? ceil_div(p.cin, 32) : p.cin >> 5;          // K32 sub-chunks per tap (RAG: the last one may be partial)
+    const int nsubc = (T9 ? 9 : 1) * cpt, nstep = RAG ? ceil_div(nsubc, SPS) : nsubc / SPS;
+    const int nsub_t = RAG ? min(NSUB, ceil_div(p.cout - n0, 32)) : NSUB;      // n-subtiles of this column tile
     const long wrow = (long)(T9 ? 9 : 1) * p.cin * 4;     // bytes per weight row
     const unsigned lds_w = d_lds_off(s_w), lds_r = d_lds_off(s_r) + (unsigned)wave * 2u * RSLOT;
     unsigned char* const my_r = s_r + wave * 2 * RSLOT;
@@ -613,15 +617,20 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
 
     // per-lane sources (see k_rows3): weights advance by one step's bytes per step, steps past the end re-read the last one
     const unsigned char* wsrc[NWI];
+    int wku[NWI];
 #pragma unroll
     for (int k = 0; k < NWI; ++k) {
+        wku[k] = 0;
         const int rr = 8 * RPI * k + RPI * wave + lane / UPR;
         const int sw = UPR == 16 ? (rr & 15) : ((rr >> 1) & 7);
-        wsrc[k] = rr < NT ? p.ws + (long)(n0 + rr) * wrow + (((lane % UPR) ^ sw) << 4) : zrow;
+        wsrc[k] = (rr < NT && (!RAG || n0 + rr < p.cout)) ? p.ws + (long)(n0 + rr) * wrow + (((lane % UPR) ^ sw) << 4) : zrow;
+        if (RAG) wku[k] = ((lane % UPR) ^ sw) * 4;         // k offset (floats) of this lane's source unit inside a step
     }
     auto dma_w = [&](int S, int k) {
         const bool pad = NT % (8 * RPI) != 0 && 8 * RPI * k + RPI * wave >= NT;       // (wave-uniform: a padding instruction of a 160-column tile)
-        d_dma16(wsrc[k] + (pad ? 0l : (long)min(S, nstep - 1) * WROWB),
+        const int Sc = min(S, nstep - 1);
+        const bool ktail = RAG && Sc * KS + wku[k] >= p.cin;                          // (per lane) this unit lies beyond K: zero
+        d_dma16(ktail ? zrow : wsrc[k] + (pad || wsrc[k] == zrow ? 0l : (long)Sc * WROWB),
                 (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_w + (unsigned)(S & 1) * WSLOT + (unsigned)(8 * RPI * k + RPI * wave) * WROWB)));
     };
     const unsigned char* rsrc[4];
@@ -636,9 +645,17 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
         }
     };
     auto dma_r = [&](int s, int k) {
-        d_dma16(rsrc[k] + ck_r * 128, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_r + (unsigned)(s & 1) * RSLOT + (unsigned)k * 1024u)));
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_r + (unsigned)(s & 1) * RSLOT + (unsigned)k * 1024u));
+        if constexpr (RAG) {
+            const int r = 8 * k + (lane >> 3);
+            const int ku = ((lane & 7) ^ ((r >> 1) & 7)) * 4;
+            d_dma16(ck_r * 32 + ku < p.cin ? rsrc[k] + ck_r * 128 : zrow, dst);
+        } else {
+            d_dma16(rsrc[k] + ck_r * 128, dst);
+        }
     };
     auto next_r = [&]() {
+        if constexpr (RAG) { ++ck_r; return; }          // (no wrap: sub-chunks past K are zero-sourced)
         if (++ck_r == cpt) {
             ck_r = 0;
             if (T9) {
@@ -745,9 +762,11 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
                 if (st + 1 < NST) frag(st + 1, ah[(st + 1) & 1], al[(st + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 const int half = st / NSUB, j = st - half * NSUB;
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st & 1], bh[CUR][half], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bl[CUR][half], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bh[CUR][half], acc[j], 0, 0, 0);
+                if (!RAG || j < nsub_t) {       // (wave-uniform; a ragged last tile skips its empty n-subtiles)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st & 1], bh[CUR][half], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bl[CUR][half], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st & 1], bh[CUR][half], acc[j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (sub == 0 && st < rd_at) {
                     if (w_done < NWI) dma_w(S + 1, w_done++);
@@ -778,12 +797,12 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
     } else {      // one sub-chunk per step: the register sets alternate between steps -- two steps per iteration (cin % 64 == 0: an even count)
         for (int S = 0; S < nstep; S += 2) {
             step(S, std::integral_constant<int, 0>{});
-            step(S + 1, std::integral_constant<int, 1>{});
+            if (!RAG || S + 1 < nstep) step(S + 1, std::integral_constant<int, 1>{});
         }
     }
     d_wait_vm<0>();        // the trailing re-reads have landed: this wave's row slots become its 32 x 32 transpose scratch (private: no barrier)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    dense_epilogue<NSUB, T9, true, OF, FEAT || T9>(p, acc, s_arow, s_orow, s_cls, reinterpret_cast<float*>(my_r), wave, lane, n0, NSUB);
+    dense_epilogue<NSUB, T9, !RAG, OF, FEAT || T9>(p, acc, s_arow, s_orow, s_cls, reinterpret_cast<float*>(my_r), wave, lane, n0, nsub_t);
 }
 
 // LayerNorm statistics of the rows of a [rows, C] matrix: stats[r] = {mean, 1 / sqrt(var + eps)} (biased variance, as nn.LayerNorm),
@@ -839,18 +858,18 @@ static int launch_dense_f(DenseArgs& a, hipStream_t st) {
     return LDN_OK;
 }
 
-template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false>
+template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false, bool RAG = false>
 static int launch_dense2(DenseArgs& a, hipStream_t st) {
-    if constexpr (!FEAT && !T9 && !PS && !OF) {       // the plain 1x1 form has a second instantiation with the rarely used epilogue terms (T9: always in)
+    if constexpr (!FEAT && !T9 && !PS && !OF && !RAG) {       // the plain 1x1 form has a second instantiation with the rarely used epilogue terms (T9: always in)
         if (a.relu == 3 || a.ln_stats || a.chmask || a.post_sub) return launch_dense2<NSUB, T9, PS, OF, true>(a, st);
     }
     constexpr int NT = NSUB * 32, KS = NSUB <= 4 ? 64 : 32, WROWB = KS * 4, RPI = 1024 / WROWB, NWI = (NT + 8 * RPI - 1) / (8 * RPI);
     const size_t lds = (size_t)(T9 ? 12 : 2) * 256 * 4 + 2 * (size_t)NWI * 8 * 1024 + 8 * 2 * (size_t)32 * 128;
-    a.ntn = a.cout / NT;
+    a.ntn = ceil_div(a.cout, NT);
     a.mtn = ceil_div(a.m_cap, 256);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense2<NSUB, T9, PS, OF, FEAT>), lds), "k_dense2: cannot reserve %zu B of LDS", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense2<NSUB, T9, PS, OF, FEAT, RAG>), lds), "k_dense2: cannot reserve %zu B of LDS", lds);
     const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
-    hipLaunchKernelGGL((k_dense2<NSUB, T9, PS, OF, FEAT>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_dense2<NSUB, T9, PS, OF, FEAT, RAG>), dim3(grid), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_dense2");
     return LDN_OK;
 }
@@ -1000,6 +1019,8 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
     // (DESIGN.md 4n / 4t), rounds = ceil(live workgroups / 256) (one workgroup per CU: 115-159 KB of LDS), tile time = chunks x (1700 + 500
     // NSUB) + 12000 NSUB cycles (the per-chunk law of 4r; the second constant, fitted: epilogue + pipeline fill per 32-column subtile).  Results do not depend on the choice.
     static const bool use_model = !(getenv("LDN_DENSE_MODEL") && atoi(getenv("LDN_DENSE_MODEL")) == 0);
+    // the ragged form of k_dense2 (any cin % 8 == 0, ragged last column tile; 64- and 160-column tiles: LAD-RegNet's widths)
+    static const bool rag2 = !(getenv("LDN_DENSE_V2") && atoi(getenv("LDN_DENSE_V2")) == 0) && !getenv("LDN_DENSE_NO_RAG");
     const long rows_known = !m_count ? (long)m_cap : (hint >= 0 ? (hint < m_cap ? hint : (long)m_cap) : -1);
     static long mc[3] = {1700, 500, 12000};   // LDN_DENSE_MODEL_C="a,b,c" overrides (tuning)
     static const bool mc_env = [] { const char* e = getenv("LDN_DENSE_MODEL_C"); if (e) sscanf(e, "%ld,%ld,%ld", &mc[0], &mc[1], &mc[2]); return e != nullptr; }();
@@ -1058,20 +1079,23 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
         switch (best) {
             case 8: return v2 ? launch_dense2<8, false, false, false>(d, st) : launch_dense_f<8, false, true>(d, st);
             case 6: return v2 ? launch_dense2<6, false, false, false>(d, st) : launch_dense_f<6, false, true>(d, st);
-            case 5: return v2 ? launch_dense2<5, false, false, false>(d, st) : launch_dense_f<5, false, true>(d, st);
+            case 5: return v2 ? launch_dense2<5, false, false, false>(d, st) : (rag2 && cin <= 2048 ? launch_dense2<5, false, false, false, true, true>(d, st) : launch_dense_f<5, false, true>(d, st));
             case 4: return v2 ? launch_dense2<4, false, false, false>(d, st) : launch_dense_f<4, false, true>(d, st);
-            case 2: return v2 ? launch_dense2<2, false, false, false>(d, st) : launch_dense_f<2, false, true>(d, st);
+            case 2: return v2 ? launch_dense2<2, false, false, false>(d, st) : (rag2 && cin <= 2048 ? launch_dense2<2, false, false, false, true, true>(d, st) : launch_dense_f<2, false, true>(d, st));
             default: break;
         }
     }
     if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return dense2_ok(8, 1, cin, cout) ? launch_dense2<8, false, false, false>(d, st) : launch_dense<8, false>(d, st);
     if (small_grid) return launch_dense_f<4, false, true, false, 128>(d, st);
     if (cout % 128 == 0) return dense2_ok(4, 1, cin, cout) ? launch_dense2<4, false, false, false>(d, st) : launch_dense<4, false>(d, st);
-    if (cout <= 64) return dense2_ok(2, 1, cin, cout) ? launch_dense2<2, false, false, false>(d, st) : launch_dense<2, false>(d, st);
+    if (cout <= 64) return dense2_ok(2, 1, cin, cout) ? launch_dense2<2, false, false, false>(d, st) : (rag2 && cin <= 2048 ? launch_dense2<2, false, false, false, true, true>(d, st) : launch_dense<2, false>(d, st));
     // 160-column tiles: layers whose width is a multiple of 160 (320: two whole tiles instead of 128 + 128 + 64), and ragged widths
     // above 128 (144 in one tile; 784 = 4 x 160 + 144) -- LAD-RegNet
     static const bool use5 = !getenv("LDN_DENSE_NO5");
-    if (use5 && (cout % 160 == 0 || (cout % 32 != 0 && cout > 128))) return launch_dense<5, false>(d, st);
+    if (use5 && (cout % 160 == 0 || (cout % 32 != 0 && cout > 128))) {
+        if (rag2 && cin <= 2048) return launch_dense2<5, false, false, false, true, true>(d, st);      // (the ragged form carries every epilogue term)
+        return launch_dense<5, false>(d, st);
+    }
     if (cout % 32 != 0 && cout > 128 && cout <= 256) return launch_dense<8, false>(d, st);   // a ragged layer in ONE column tile (144, 168, 216 ...)
     return launch_dense<4, false>(d, st);
 }

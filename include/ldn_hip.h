@@ -473,6 +473,26 @@ int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B, int C, in
                   float* work, void* stream);
 size_t ldn_se_packed_workspace_bytes(int B, int C, int max_rows_per_image);
 
+/* The SE block folded into its neighbours (layer skip on whole images; laud_regnet.py:194-197 `x = self.b(x); x = self.se(x); x = self.c(x)`):
+ *   1. ldn_grouped16_conv3x3_images_gap = ldn_grouped16_conv3x3_images that also leaves the channel SUMS of its output per kept image:
+ *      gap_partial [images_cap][bands][C], bands = ldn_grouped16_images_bands(Hi, Wi, Ho, stride, C) (1 when a workgroup holds a whole image);
+ *      a fixed order of additions (a tree over each tile of 16 pixels, tiles in order): deterministic;
+ *   2. ldn_se_gate_slots: gate[k][:] = sigmoid(W2 relu(W1 (sum over bands / rows_per_image) + b1) + b2) for every kept image k
+ *      (k * rows_per_image < *m_count), gate [images_cap][C]; w1 [S][C], w2 [C][S];
+ *   3. ldn_conv_rows_gated: conv c reads h_b and multiplies row r by gate[r / gate_rows][:] in flight (bf16x3; products formed from
+ *      fp32(h_b * gate): bit-identical to scaling h_b first); any cin % 8 == 0 (<= 2048), cout % 4 == 0; relu 0 / 1 / 2; residual /
+ *      out_rows as ldn_conv_rows_split.
+ * Three launches (conv b, the SE head, conv c) instead of six; h_b is read once by conv c and never rewritten. */
+int ldn_grouped16_images_bands(int Hi, int Wi, int Ho, int stride, int C);
+int ldn_grouped16_conv3x3_images_gap(const float* a, int lda, const int32_t* m_count, int images_cap, int Hi, int Wi, int Ho, int Wo,
+                                     int stride, const void* w_frag, int C, const float* scale, const float* shift, int relu, float* out,
+                                     int ldo, float* gap_partial, void* stream);
+int ldn_se_gate_slots(const float* gap_partial, int splits, const int32_t* m_count, int images_cap, int rows_per_image, int C, int S,
+                      const float* w1, const float* b1, const float* w2, const float* b2, float* gate, void* stream);
+int ldn_conv_rows_gated(const float* a, int lda, const int32_t* m_count, int m_cap, const void* w_split, int cin, int cout,
+                        const float* scale, const float* shift, int relu, const int32_t* relu_if_neg, const int32_t* out_rows,
+                        const float* residual, int ldr, float* out, int ldo, const float* gate, int gate_rows, void* stream);
+
 /* ---- a14: token skipping (BASELINE config 5, AdaViT / DeiT-S shaped blocks).  The reference holds no model code for it, only the
  * latency model of the operator (DyNetSimulator/adavit/simulate_adavit.py:77-131: q / k / v for every token, attention
  * [B, heads, L_select, d] over the selected tokens): parity of this entry point is therefore UNPINNED -- it is tested against a

@@ -53,6 +53,10 @@ SIGNATURES = {
     "ldn_grouped16_conv3x3_rows": ([_P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P], _I),
     "ldn_grouped16_images_fit": ([_I, _I, _I], _I),
     "ldn_grouped16_conv3x3_images": ([_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P], _I),
+    "ldn_grouped16_images_bands": ([_I, _I, _I, _I, _I], _I),
+    "ldn_grouped16_conv3x3_images_gap": ([_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], _I),
+    "ldn_se_gate_slots": ([_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
+    "ldn_conv_rows_gated": ([_P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P], _I),
     "ldn_grouped_conv3x3_image": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P], _I),
     "ldn_se_packed": ([_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P], _I),
     "ldn_se_packed_workspace_bytes": ([_I, _I, _I], C.c_size_t),

@@ -35,6 +35,8 @@ struct DenseArgs {
     float* pool; int pool_gy, pool_gx, pool_Sx;       // optional [B][S * Sx][cout]: the mean of the FINAL output over every patch of gy x gx pixels
                                                       // this launch writes (gy * gx = 4 or 16 consecutive packed rows = one patch: patch-major
                                                       // lists of k_plan) -- the next spatial masker's pooled means (models/utils.py:48-52)
+    const float* a_gate; int gate_rows;               // optional (k_dense2<.., AG>) [slots][cin]: A row r is multiplied by a_gate[r / gate_rows][:] before the
+                                                      // product -- the excitation of an SE block applied where conv c reads h_b (laud_regnet.py:196-197)
 };
 
 __device__ __attribute__((aligned(16))) float g_dense_zero[2048] = {0.f};     // a whole zero ROW for k_dense2 (cin <= 2048); k_dense reads its first 16 bytes
@@ -546,9 +548,13 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
 // Whole column tiles only (cout % NT == 0), cin a multiple of the K step, cin <= 2048; T9 = the 3x3 through a neighbour table (tap-major K).
 // RAG (1x1, fp32 rows): any cin % 8 == 0 (the K tail of the last sub-chunk / step is zero-sourced in both DMA streams) and a ragged last column tile (columns >= cout are
 // neither staged nor stored) -- LAD-RegNet's 144- and 784-wide layers.
-template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false, bool RAG = false>
+// AG (1x1, fp32 rows, no gather): every A row is scaled by the gate vector of its image (p.a_gate[row / p.gate_rows]) between its LDS read and its
+// split -- the values the separate k_rows_scale pass would have written, so the results are bit-identical to scaling first; the gate vectors of
+// the (few) images a 256-row tile touches sit in LDS.
+template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false, bool RAG = false, bool AG = false>
 __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
     static_assert(!RAG || (!T9 && !PS && !OF), "the ragged form is the plain 1x1");
+    static_assert(!AG || (!T9 && !PS), "the gated form reads fp32 rows of a 1x1");
     constexpr int NT = NSUB * 32;
     constexpr int KS = NSUB <= 4 ? 64 : 32;               // K elements of one weight step
     constexpr int SPS = KS / 32;                          // K32 sub-chunks per step
@@ -566,6 +572,7 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
     int* const s_atap = s_cls + D_ROWS;                   // (T9 only) [256][9]
     unsigned char* const s_w = smem + (T9 ? 12 : 2) * D_ROWS * 4;
     unsigned char* const s_r = s_w + 2 * WSLOT;
+    float* const s_gate = reinterpret_cast<float*>(s_r + 8 * 2 * RSLOT);      // (AG) [slots of this tile][cin rounded up to 32, zero-padded]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -604,6 +611,16 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
             const int r = i / 9;
             s_atap[i] = r < rows ? p.a_rows[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
         }
+    int goff = 0;                                         // (AG) this lane's row: offset of its image's gate vector in s_gate
+    if constexpr (AG) {
+        const int gld = round_up(p.cin, 32), q4 = gld >> 2;
+        const int slot0 = m0 / p.gate_rows, nsl = (m0 + rows - 1) / p.gate_rows - slot0 + 1;
+        for (int i = tid; i < nsl * q4; i += 512) {
+            const int sl = i / q4, k = (i - sl * q4) * 4;
+            reinterpret_cast<f32x4*>(s_gate)[i] = k < p.cin ? *reinterpret_cast<const f32x4*>(p.a_gate + (size_t)(slot0 + sl) * p.cin + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        goff = ((m0 + min(wave * 32 + (lane & 31), rows - 1)) / p.gate_rows - slot0) * gld + 8 * (lane >> 5);
+    }
     __syncthreads();
 
     const bool active = wave * 32 < rows;
@@ -684,6 +701,7 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
 
     bf16x8 bh[2][2], bl[2][2];          // B fragments: [register set = sub-chunk parity][K16 half]
     f32x4 raw[4];                       // (!PS) a sub-chunk's fp32 values between their LDS read and their split
+    f32x4 gq[4];                        // (AG) the gate values of the same positions
     const unsigned xsw = ((unsigned)l31 >> 1) & 7u;
     const unsigned wsw = UPR == 16 ? ((unsigned)l31 & 15u) : (((unsigned)l31 >> 1) & 7u);
     auto read_b = [&](int s, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
@@ -697,6 +715,11 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
             } else {
                 raw[2 * half] = *reinterpret_cast<const f32x4*>(xs + ((sl ^ xsw) << 4));
                 raw[2 * half + 1] = *reinterpret_cast<const f32x4*>(xs + (((sl + 1) ^ xsw) << 4));
+                if constexpr (AG) {      // (sub-chunks past K are read ahead and never multiplied: any finite vector does)
+                    const float* g = s_gate + goff + min(s, cpt - 1) * 32 + 16 * half;
+                    gq[2 * half] = *reinterpret_cast<const f32x4*>(g);
+                    gq[2 * half + 1] = *reinterpret_cast<const f32x4*>(g + 4);
+                }
             }
         }
     };
@@ -704,7 +727,11 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
         if constexpr (!PS) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = e < 4 ? raw[2 * half][e] : raw[2 * half + 1][e - 4];
+                float v = e < 4 ? raw[2 * half][e] : raw[2 * half + 1][e - 4];
+                if constexpr (AG) {      // the product ROUNDED to fp32, like the stored one (opaque to the compiler: no FMA contraction into the lo part below)
+                    v *= e < 4 ? gq[2 * half][e] : gq[2 * half + 1][e - 4];
+                    asm("" : "+v"(v));
+                }
                 const __bf16 hb = (__bf16)v;
                 dh[half][e] = hb;
                 dl[half][e] = (__bf16)(v - (float)hb);
@@ -858,18 +885,19 @@ static int launch_dense_f(DenseArgs& a, hipStream_t st) {
     return LDN_OK;
 }
 
-template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false, bool RAG = false>
+template <int NSUB, bool T9, bool PS, bool OF, bool FEAT = false, bool RAG = false, bool AG = false>
 static int launch_dense2(DenseArgs& a, hipStream_t st) {
     if constexpr (!FEAT && !T9 && !PS && !OF && !RAG) {       // the plain 1x1 form has a second instantiation with the rarely used epilogue terms (T9: always in)
         if (a.relu == 3 || a.ln_stats || a.chmask || a.post_sub) return launch_dense2<NSUB, T9, PS, OF, true>(a, st);
     }
     constexpr int NT = NSUB * 32, KS = NSUB <= 4 ? 64 : 32, WROWB = KS * 4, RPI = 1024 / WROWB, NWI = (NT + 8 * RPI - 1) / (8 * RPI);
-    const size_t lds = (size_t)(T9 ? 12 : 2) * 256 * 4 + 2 * (size_t)NWI * 8 * 1024 + 8 * 2 * (size_t)32 * 128;
+    const size_t lds = (size_t)(T9 ? 12 : 2) * 256 * 4 + 2 * (size_t)NWI * 8 * 1024 + 8 * 2 * (size_t)32 * 128 +
+                       (AG ? (size_t)(255 / a.gate_rows + 2) * round_up(a.cin, 32) * 4 : 0);      // (AG: the gate vectors of the images a tile touches)
     a.ntn = ceil_div(a.cout, NT);
     a.mtn = ceil_div(a.m_cap, 256);
-    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense2<NSUB, T9, PS, OF, FEAT, RAG>), lds), "k_dense2: cannot reserve %zu B of LDS", lds);
+    LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_dense2<NSUB, T9, PS, OF, FEAT, RAG, AG>), lds), "k_dense2: cannot reserve %zu B of LDS", lds);
     const unsigned grid = (unsigned)round_up(a.mtn, 8) * a.ntn;
-    hipLaunchKernelGGL((k_dense2<NSUB, T9, PS, OF, FEAT, RAG>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_dense2<NSUB, T9, PS, OF, FEAT, RAG, AG>), dim3(grid), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_dense2");
     return LDN_OK;
 }
@@ -961,6 +989,33 @@ extern "C" int ldn_conv_rows_ps(const float* a, int lda, int a_presplit, const i
                                 a_presplit != 0, out_presplit != 0);
 }
 
+// The 1x1 form with a per-image GATE on its input rows (the excitation of an SE block folded into the conv that follows it,
+// laud_regnet.py:196-197 `x = self.se(x); x = self.c(x)`): row r of `a` (rows are whole images of gate_rows rows each, in order: packed
+// rows of a layer-skip list, or a dense batch) is multiplied by gate[r / gate_rows][0..cin) before the product.  The products are formed
+// from fp32(a * gate), the values a separate scaling pass would store: bit-identical to scaling first.  bf16x3 arithmetic; any cin % 8 == 0
+// (<= 2048), any cout % 4 == 0; everything else as ldn_conv_rows_split with taps = 1 and no a_rows.
+extern "C" int ldn_conv_rows_gated(const float* a, int lda, const int32_t* m_count, int m_cap, const void* w_split, int cin, int cout,
+                                   const float* scale, const float* shift, int relu, const int32_t* relu_if_neg, const int32_t* out_rows,
+                                   const float* residual, int ldr, float* out, int ldo, const float* gate, int gate_rows, void* stream) {
+    LDN_REQUIRE(a && w_split && shift && out && gate, "ldn_conv_rows_gated: null pointer");
+    LDN_REQUIRE(cin > 0 && cin % 8 == 0 && cin <= 2048 && cout > 0 && cout % 4 == 0, "ldn_conv_rows_gated: cin must be a multiple of 8, at most 2048, and cout a multiple of 4 (got %d, %d)", cin, cout);
+    LDN_REQUIRE(gate_rows > 0, "ldn_conv_rows_gated: gate_rows must be positive");
+    LDN_REQUIRE(lda % 4 == 0 && lda >= cin && ldo % 4 == 0 && ldo >= cout && (!residual || (ldr % 4 == 0 && ldr >= cout)),
+                "ldn_conv_rows_gated: strides must be multiples of 4 and cover the row");
+    LDN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || relu_if_neg), "ldn_conv_rows_gated: bad relu mode (0 none, 1 ReLU, 2 ReLU on the rows with relu_if_neg < 0)");
+    LDN_REQUIRE((uintptr_t)a % 16 == 0 && (uintptr_t)w_split % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 &&
+                (uintptr_t)shift % 16 == 0 && (uintptr_t)scale % 16 == 0 && (uintptr_t)gate % 16 == 0, "ldn_conv_rows_gated: pointers must be 16-byte aligned");
+    if (m_cap <= 0) return LDN_OK;
+    DenseArgs d{a, lda, nullptr, m_count, m_cap, static_cast<const unsigned char*>(w_split), cin, cout, scale, shift, relu,
+                relu_if_neg, out_rows, residual, ldr, out, ldo, 1, 1, nullptr, 0, 0, 1, 1, 1, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0,
+                gate, gate_rows};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    g_rows_hint = -1;
+    if (cout % 128 == 0 || (cout > 64 && cout <= 128)) return launch_dense2<4, false, false, false, true, true, true>(d, st);
+    if (cout <= 64) return launch_dense2<2, false, false, false, true, true, true>(d, st);
+    return launch_dense2<5, false, false, false, true, true, true>(d, st);
+}
+
 static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, int taps, const int32_t* m_count, int m_cap,
                                 const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
                                 const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr,
@@ -996,7 +1051,7 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
     if (m_cap <= 0) return LDN_OK;
     DenseArgs d{a, lda, a_rows, m_count, m_cap, static_cast<const unsigned char*>(w_split), cin, cout, scale, shift, relu,
                 relu_if_neg, out_rows, residual, ldr, out, ldo, taps, shift_classes, pix_map, Hi, Wi, Ho > 0 ? Ho : 1, Wo > 0 ? Wo : 1,
-                stride, post_sub, chan_mask, rows_per_image > 0 ? rows_per_image : 1, 0, 0, ln_stats, ln_c1, pool, pool_gy, pool_gx, pool_Sx};
+                stride, post_sub, chan_mask, rows_per_image > 0 ? rows_per_image : 1, 0, 0, ln_stats, ln_c1, pool, pool_gy, pool_gx, pool_Sx, nullptr, 1};
     hipStream_t st = static_cast<hipStream_t>(stream);
     // columns per workgroup: as wide as the layer allows (fewer passes over the activation rows) while the grid still fills the chip
     const int mt = ceil_div(m_cap, D_ROWS_MAX);
@@ -1081,14 +1136,14 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
             case 6: return v2 ? launch_dense2<6, false, false, false>(d, st) : launch_dense_f<6, false, true>(d, st);
             case 5: return v2 ? launch_dense2<5, false, false, false>(d, st) : (rag2 && cin <= 2048 ? launch_dense2<5, false, false, false, true, true>(d, st) : launch_dense_f<5, false, true>(d, st));
             case 4: return v2 ? launch_dense2<4, false, false, false>(d, st) : launch_dense_f<4, false, true>(d, st);
-            case 2: return v2 ? launch_dense2<2, false, false, false>(d, st) : (rag2 && cin <= 2048 ? launch_dense2<2, false, false, false, true, true>(d, st) : launch_dense_f<2, false, true>(d, st));
+            case 2: return v2 ? launch_dense2<2, false, false, false>(d, st) : (rag2 && cin <= 2048 && cin > 64 ? launch_dense2<2, false, false, false, true, true>(d, st) : launch_dense_f<2, false, true>(d, st));
             default: break;
         }
     }
     if (cout % 256 == 0 && (long)mt * (cout / 256) >= 384) return dense2_ok(8, 1, cin, cout) ? launch_dense2<8, false, false, false>(d, st) : launch_dense<8, false>(d, st);
     if (small_grid) return launch_dense_f<4, false, true, false, 128>(d, st);
     if (cout % 128 == 0) return dense2_ok(4, 1, cin, cout) ? launch_dense2<4, false, false, false>(d, st) : launch_dense<4, false>(d, st);
-    if (cout <= 64) return dense2_ok(2, 1, cin, cout) ? launch_dense2<2, false, false, false>(d, st) : (rag2 && cin <= 2048 ? launch_dense2<2, false, false, false, true, true>(d, st) : launch_dense<2, false>(d, st));
+    if (cout <= 64) return dense2_ok(2, 1, cin, cout) ? launch_dense2<2, false, false, false>(d, st) : (rag2 && cin <= 2048 && cin > 64 ? launch_dense2<2, false, false, false, true, true>(d, st) : launch_dense<2, false>(d, st));
     // 160-column tiles: layers whose width is a multiple of 160 (320: two whole tiles instead of 128 + 128 + 64), and ragged widths
     // above 128 (144 in one tile; 784 = 4 x 160 + 144) -- LAD-RegNet
     static const bool use5 = !getenv("LDN_DENSE_NO5");

@@ -119,7 +119,25 @@ struct GiArgs {
     int Hi, Wi, Ho, Wo, stride;
     int gchunk, in_ld;                      // groups per workgroup; floats per staged pixel (16 gchunk + 4)
     int R, nbands;                          // output rows per workgroup (Ho: the whole image), bands per image
+    float* gap;                             // optional [kept image][band][C]: channel sums of this launch's FINAL output over the band's pixels
+                                            // (the squeeze of the SE block that follows conv b, laud_regnet.py:194: no second pass over h_b)
 };
+
+// sum over the 16 lanes of a DPP row (inline asm: hipcc 7.2 merges neighbouring update_dpp calls, see dpp_swap_pair); fixed order
+__device__ __forceinline__ float row16_sum(float v) {
+    float t;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "=&v"(t) : "v"(v));
+    return t;
+}
 
 __global__ __launch_bounds__(512, 2) void k_grouped16_img(const GiArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(512, 2) void k_grouped16_img(const GiArgs p) {
     const int n = lane & 15, kg = lane >> 4;
     const int npix = rows_out * p.Wo;                                      // output pixels of the band
     const int ntile = (npix + 15) / 16;
+    float* const s_gap = s_in + ((size_t)HWi + 1) * p.in_ld;              // (gap) [group][tile][16 channels]: per-tile channel sums
     for (int w = wave; w < ntile * ng; w += 8) {
         const int gl = w / ntile, tile = w - gl * ntile;
         const int q = tile * 16 + n;
@@ -188,6 +207,21 @@ __global__ __launch_bounds__(512, 2) void k_grouped16_img(const GiArgs p) {
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (valid) *reinterpret_cast<f32x4*>(p.out + ((size_t)k * HWo + (size_t)y0 * p.Wo + q) * p.ldo + c) = v;
+        if (p.gap) {      // (uniform) channel sums of the tile: a fixed tree over its 16 pixels, tiles added in order below
+            f32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = row16_sum(valid ? v[e] : 0.f);
+            if (n == 0) *reinterpret_cast<f32x4*>(s_gap + (size_t)w * 16 + 4 * kg) = t;
+        }
+    }
+    if (p.gap) {
+        __syncthreads();
+        if (tid < ng * 16) {
+            const int gl = tid >> 4, ch = tid & 15;
+            float s = 0.f;
+            for (int t = 0; t < ntile; ++t) s += s_gap[((size_t)gl * ntile + t) * 16 + ch];
+            p.gap[((size_t)k * p.nbands + band) * p.C + (g0 + gl) * 16 + ch] = s;
+        }
     }
 }
 
@@ -250,9 +284,9 @@ extern "C" int ldn_grouped16_images_fit(int Hi, int Wi, int C) {
     return (Hi > 0 && Wi > 0 && C > 0 && C % 16 == 0 && gi_plan(Hi, Wi, (Hi - 1) / 2 + 1, 2, C / 16, &ng, &R)) ? ng : 0;
 }
 
-extern "C" int ldn_grouped16_conv3x3_images(const float* a, int lda, const int32_t* m_count, int images_cap, int Hi, int Wi, int Ho,
-                                            int Wo, int stride, const void* w_frag, int C, const float* scale, const float* shift,
-                                            int relu, float* out, int ldo, void* stream) {
+static int grouped16_images(const float* a, int lda, const int32_t* m_count, int images_cap, int Hi, int Wi, int Ho,
+                            int Wo, int stride, const void* w_frag, int C, const float* scale, const float* shift,
+                            int relu, float* out, int ldo, float* gap, void* stream) {
     LDN_REQUIRE(a && m_count && w_frag && scale && shift && out, "ldn_grouped16_conv3x3_images: null pointer");
     LDN_REQUIRE(C > 0 && C % 16 == 0, "ldn_grouped16_conv3x3_images: channels must be a multiple of the group width 16 (got %d)", C);
     LDN_REQUIRE(lda % 4 == 0 && ldo % 4 == 0 && lda >= C && ldo >= C, "ldn_grouped16_conv3x3_images: strides must be multiples of 4");
@@ -264,17 +298,37 @@ extern "C" int ldn_grouped16_conv3x3_images(const float* a, int lda, const int32
     GiArgs g{};
     g.a = a; g.lda = lda; g.m_count = m_count; g.wf = static_cast<const unsigned char*>(w_frag); g.C = C;
     g.scale = scale; g.shift = shift; g.relu = relu; g.out = out; g.ldo = ldo;
-    g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.stride = stride;
+    g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.gap = gap;
     const int G = C / 16;
     LDN_REQUIRE(gi_plan(Hi, Wi, Ho, stride, G, &g.gchunk, &g.R),
                 "ldn_grouped16_conv3x3_images: three rows of a %d-wide map do not fit the LDS (ldn_grouped16_images_fit)", Wi);
     g.nbands = ceil_div(Ho, g.R);
     g.in_ld = 16 * g.gchunk + 4;
     const int in_rows = g.R == Ho ? Hi : min(Hi, (g.R - 1) * stride + 3);
-    const size_t lds = (size_t)g.gchunk * GM_FRAG + ((size_t)in_rows * Wi + 1) * g.in_ld * 4;
+    const size_t lds = (size_t)g.gchunk * GM_FRAG + ((size_t)in_rows * Wi + 1) * g.in_ld * 4 +
+                       (gap ? (size_t)g.gchunk * ceil_div(g.R * Wo, 16) * 64 : 0);        // (gap: per-tile channel sums)
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_grouped16_img), lds), "k_grouped16_img: cannot reserve %zu B of LDS", lds);
     hipLaunchKernelGGL(k_grouped16_img, dim3((unsigned)(ceil_div(G, g.gchunk) * g.nbands), (unsigned)images_cap), dim3(512), lds,
                        static_cast<hipStream_t>(stream), g);
     LDN_CHECK_LAUNCH("k_grouped16_img");
     return LDN_OK;
+}
+
+extern "C" int ldn_grouped16_conv3x3_images(const float* a, int lda, const int32_t* m_count, int images_cap, int Hi, int Wi, int Ho,
+                                            int Wo, int stride, const void* w_frag, int C, const float* scale, const float* shift,
+                                            int relu, float* out, int ldo, void* stream) {
+    return grouped16_images(a, lda, m_count, images_cap, Hi, Wi, Ho, Wo, stride, w_frag, C, scale, shift, relu, out, ldo, nullptr, stream);
+}
+
+extern "C" int ldn_grouped16_images_bands(int Hi, int Wi, int Ho, int stride, int C) {
+    int ng = 0, R = 0;
+    if (!(Hi > 0 && Wi > 0 && Ho > 0 && stride >= 1 && C > 0 && C % 16 == 0 && gi_plan(Hi, Wi, Ho, stride, C / 16, &ng, &R))) return 0;
+    return ceil_div(Ho, R);
+}
+
+extern "C" int ldn_grouped16_conv3x3_images_gap(const float* a, int lda, const int32_t* m_count, int images_cap, int Hi, int Wi, int Ho,
+                                                int Wo, int stride, const void* w_frag, int C, const float* scale, const float* shift,
+                                                int relu, float* out, int ldo, float* gap_partial, void* stream) {
+    LDN_REQUIRE(gap_partial, "ldn_grouped16_conv3x3_images_gap: null pointer");
+    return grouped16_images(a, lda, m_count, images_cap, Hi, Wi, Ho, Wo, stride, w_frag, C, scale, shift, relu, out, ldo, gap_partial, stream);
 }

@@ -142,14 +142,16 @@ __global__ __launch_bounds__(NT) void k_se_head(const float* __restrict__ partia
                                                   int C, int S, int splits, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, const int32_t* __restrict__ ch_idx,
-                                                  const int32_t* __restrict__ ch_cnt, float* __restrict__ gate) {
+                                                  const int32_t* __restrict__ ch_cnt, float* __restrict__ gate,
+                                                  int slot_rows, const int32_t* __restrict__ m_count) {
     extern __shared__ __attribute__((aligned(16))) float s_f[];
     float* s_mean = s_f;        // [C]
     float* s_hid = s_f + C;     // [S]
     int* s_ch = reinterpret_cast<int*>(s_f + C + S);   // [C] channel of column j
     constexpr int NW = NT / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = prefix[b + 1] - prefix[b];
+    // slot form (slot_rows > 0): b is the b-th KEPT image, whole images of slot_rows rows each, *m_count rows in all
+    const int n = slot_rows > 0 ? ((long)b * slot_rows < (long)m_count[0] ? slot_rows : 0) : prefix[b + 1] - prefix[b];
     if (n == 0) return;         // skipped image: its gate is never read
     const int Cb = ch_idx ? ch_cnt[b] : C;
     const float inv = 1.f / (float)n;
@@ -369,12 +371,23 @@ extern "C" int ldn_se_packed(float* a, int lda, const int32_t* row_prefix, int B
     hipLaunchKernelGGL(k_rows_gap, dim3(splits, B), dim3(256), 0, st, a, lda, row_prefix, C, splits, partial);
     LDN_CHECK_LAUNCH("k_rows_gap");
     hipLaunchKernelGGL(k_se_head<1024>, dim3(B), dim3(1024), (size_t)(2 * C + S) * sizeof(float), st, partial, row_prefix, C, S, splits,
-                       w1, b1, w2, b2, ch_idx, ch_cnt, gate);
+                       w1, b1, w2, b2, ch_idx, ch_cnt, gate, 0, nullptr);
     LDN_CHECK_LAUNCH("k_se_head");
     int chunks = (max_rows_per_image * (C / 4) + 255) / 256;
     if (chunks > 64) chunks = 64;
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(k_rows_scale, dim3(chunks, B), dim3(256), 0, st, a, lda, row_prefix, C, gate);
     LDN_CHECK_LAUNCH("k_rows_scale");
+    return LDN_OK;
+}
+
+extern "C" int ldn_se_gate_slots(const float* gap_partial, int splits, const int32_t* m_count, int images_cap, int rows_per_image, int C, int S,
+                                 const float* w1, const float* b1, const float* w2, const float* b2, float* gate, void* stream) {
+    LDN_REQUIRE(gap_partial && m_count && w1 && b1 && w2 && b2 && gate, "ldn_se_gate_slots: null pointer");
+    LDN_REQUIRE(images_cap >= 0 && splits > 0 && rows_per_image > 0 && C > 0 && S > 0, "ldn_se_gate_slots: bad shape");
+    if (images_cap == 0) return LDN_OK;
+    hipLaunchKernelGGL(k_se_head<1024>, dim3(images_cap), dim3(1024), (size_t)(2 * C + S) * sizeof(float), static_cast<hipStream_t>(stream),
+                       gap_partial, nullptr, C, S, splits, w1, b1, w2, b2, nullptr, nullptr, gate, rows_per_image, m_count);
+    LDN_CHECK_LAUNCH("k_se_head");
     return LDN_OK;
 }

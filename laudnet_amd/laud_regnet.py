@@ -159,6 +159,7 @@ def _conv_b_rows(p, f, h_a, nbr, h_b, m_count, m_cap, images=None):
 
 USE_GROUPED_MFMA = os.environ.get("LDN_GROUPED_MFMA", "1") != "0"    # tuning switch (A/B)
 USE_GROUPED_IMAGES = os.environ.get("LDN_GROUPED_IMAGES", "1") != "0"   # ... the whole-image form of it
+USE_SE_FUSED = os.environ.get("LDN_SE_FUSED", "1") != "0"               # ... the SE block folded into conv b's epilogue and conv c's input rows
 
 
 class ResBottleneckBlock(_PrepCache):
@@ -256,8 +257,17 @@ class ResBottleneckBlock(_PrepCache):
         h_a = torch.empty(ix.cap1, w_b, device=dev, dtype=torch.float32)
         ops.conv_rows(x2d, p["wa"], p["sa"], p["ta"], h_a, a_rows=ix.idx1, taps=1, m_count=ix.cnt[1:2], m_cap=ix.cap1, rows_hint=n1)
         h_b = torch.empty(ix.cap3, w_b, device=dev, dtype=torch.float32)
-        _conv_b_rows(p, f, h_a, ix.nbr, h_b, ix.cnt[0:1], ix.cap3, images=(B, Hi, Wi, Ho, Wo, self.stride))
-        ops.se_packed(h_b, ix.pre3, p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo)
+        # the SE block folded into its neighbours (whole kept images in order): conv b leaves the channel sums of its output, the SE head
+        # turns them into a gate per kept image, conv c multiplies its input rows by it in flight -- three launches instead of six
+        gate = None
+        if (USE_SE_FUSED and "wb_frag" in p and ops.get_math_mode() == "bf16x3" and USE_GROUPED_MFMA and USE_GROUPED_IMAGES
+                and w_b <= 2048 and ops.grouped16_images_fit(Hi, Wi, w_b) > 0):
+            gap = ops.grouped16_conv3x3_images_gap(h_a, p["wb_frag"], p["sb"], p["tb"], h_b, m_count=ix.cnt[0:1],
+                                                   images=(B, Hi, Wi, Ho, Wo, self.stride), relu=1)
+            gate = ops.se_gate_slots(gap, ix.cnt[0:1], Ho * Wo, p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"])
+        else:
+            _conv_b_rows(p, f, h_a, ix.nbr, h_b, ix.cnt[0:1], ix.cap3, images=(B, Hi, Wi, Ho, Wo, self.stride))
+            ops.se_packed(h_b, ix.pre3, p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo)
         cout = p["wc"].shape[0]
         if self.proj is not None:
             wp, sp, tp = self._proj(dev)
@@ -269,8 +279,12 @@ class ResBottleneckBlock(_PrepCache):
             resid = out2d = x2d
         else:
             resid, out2d = x2d, torch.relu(x2d)
-        ops.conv_rows(h_b, p["wc"], p["sc"], p["tc"], out2d, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
-                      out_rows=ix.idx3, residual2d=resid, rows_hint=n3)
+        if gate is not None:
+            ops.conv_rows_gated(h_b, p["wc"], p["sc"], p["tc"], out2d, gate, Ho * Wo, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
+                                out_rows=ix.idx3, residual2d=resid)
+        else:
+            ops.conv_rows(h_b, p["wc"], p["sc"], p["tc"], out2d, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=1,
+                          out_rows=ix.idx3, residual2d=resid, rows_hint=n3)
         f.last_spatial_mask = patch
         # (defer_stats: the caller appends the channel sparsity 1 to all blocks at once -- a fill and a cat per block otherwise)
         stats = ix.stats if defer_stats else torch.cat((ix.stats, torch.ones(1, device=dev)))

@@ -675,6 +675,69 @@ def grouped16_conv3x3_images(a2d, w_frag, scale, shift, out2d, *, m_count, image
     return out2d
 
 
+def grouped16_images_bands(Hi, Wi, Ho, stride, C):
+    """Bands of output rows per image of ldn_grouped16_conv3x3_images (1: a workgroup holds a whole image; 0: does not fit)."""
+    return int(L.load().ldn_grouped16_images_bands(int(Hi), int(Wi), int(Ho), int(stride), int(C)))
+
+
+def grouped16_conv3x3_images_gap(a2d, w_frag, scale, shift, out2d, *, m_count, images, relu=1):
+    """grouped16_conv3x3_images that also returns the channel sums of its output per kept image and band: gap [B, bands, C]
+    (ldn_grouped16_conv3x3_images_gap) -- the squeeze of the SE block that follows conv b, without a second pass over h_b."""
+    L.require_device(a2d, w_frag, out2d, m_count)
+    lib = L.load()
+    C = w_frag.shape[0] * 16
+    if w_frag.dtype != torch.bfloat16 or not w_frag.is_contiguous() or w_frag.numel() * 2 != lib.ldn_grouped16_weight_bytes(C):
+        raise L.LdnError("grouped16_conv3x3_images_gap: w_frag must be the contiguous bf16 tensor of pack_grouped16_weights")
+    B, Hi, Wi, Ho, Wo, stride = (int(v) for v in images)
+    if a2d.shape[0] < B * Hi * Wi or out2d.shape[0] < B * Ho * Wo:
+        raise L.LdnError("grouped16_conv3x3_images_gap: a / out must hold B whole images")
+    bands = grouped16_images_bands(Hi, Wi, Ho, stride, C)
+    if bands <= 0:
+        raise L.LdnError("grouped16_conv3x3_images_gap: the map does not fit the LDS (grouped16_images_fit)")
+    gap = torch.empty(B, bands, C, device=a2d.device, dtype=torch.float32)
+    L.check(lib.ldn_grouped16_conv3x3_images_gap(L.ptr(_f32c(a2d, "a")), a2d.stride(0), L.ptr(_i32c(m_count, "m_count")), B, Hi, Wi, Ho,
+                                                 Wo, stride, L.ptr(w_frag), C, L.ptr(_f32c(scale, "scale")),
+                                                 L.ptr(_f32c(shift, "shift")), relu, L.ptr(_f32c(out2d, "out")), out2d.stride(0),
+                                                 L.ptr(gap), L.stream_ptr()), "ldn_grouped16_conv3x3_images_gap")
+    return gap
+
+
+def se_gate_slots(gap, m_count, rows_per_image, w1, b1, w2, b2):
+    """SE gate of every kept image from the channel sums of grouped16_conv3x3_images_gap (ldn_se_gate_slots) -> gate [B, C]."""
+    L.require_device(gap, m_count, w1)
+    lib = L.load()
+    B, bands, C = gap.shape
+    S = w1.shape[0]
+    gate = torch.empty(B, C, device=gap.device, dtype=torch.float32)
+    L.check(lib.ldn_se_gate_slots(L.ptr(_f32c(gap, "gap")), bands, L.ptr(_i32c(m_count, "m_count")), B, int(rows_per_image), C, S,
+                                  L.ptr(_f32c(w1, "w1")), L.ptr(_f32c(b1, "b1")), L.ptr(_f32c(w2, "w2")), L.ptr(_f32c(b2, "b2")),
+                                  L.ptr(gate), L.stream_ptr()), "ldn_se_gate_slots")
+    return gate
+
+
+def conv_rows_gated(a2d, w, scale, shift, out2d, gate, gate_rows, *, m_count=None, m_cap=None, relu=1, relu_if_neg=None, out_rows=None,
+                    residual2d=None):
+    """1x1 packed-row convolution whose input row r is multiplied by gate[r // gate_rows] in flight (ldn_conv_rows_gated; bf16x3)."""
+    L.require_device(a2d, w, out2d, gate)
+    lib = L.load()
+    cout, t, cin = w.shape
+    if t != 1:
+        raise L.LdnError("conv_rows_gated: 1x1 weights expected")
+    if gate.shape[1] != cin or not gate.is_contiguous():
+        raise L.LdnError("conv_rows_gated: gate must be a contiguous [images, cin] tensor")
+    if m_cap is None:
+        m_cap = a2d.shape[0]
+    if (m_cap + gate_rows - 1) // gate_rows > gate.shape[0]:
+        raise L.LdnError("conv_rows_gated: gate has fewer rows than the images m_cap spans")
+    L.check(lib.ldn_conv_rows_gated(L.ptr(_f32rows(a2d, "a")), a2d.stride(0), L.ptr(_i32c(m_count, "m_count")), m_cap,
+                                    L.ptr(split_rows_weight(w)), cin, cout, L.ptr(_f32c(scale, "scale")), L.ptr(_f32c(shift, "shift")), relu,
+                                    L.ptr(_i32c(relu_if_neg, "relu_if_neg")), L.ptr(_i32c(out_rows, "out_rows")),
+                                    L.ptr(_f32rows(residual2d, "residual")), residual2d.stride(0) if residual2d is not None else 0,
+                                    L.ptr(_f32rows(out2d, "out")), out2d.stride(0), L.ptr(_f32c(gate, "gate")), int(gate_rows),
+                                    L.stream_ptr(out2d)), "ldn_conv_rows_gated")
+    return out2d
+
+
 def grouped_conv3x3_image(a_nhwc, w, group_width, ch_idx, ch_cnt, scale, shift, out_nhwc, *, stride=1, relu=1):
     """Grouped 3x3 conv + BN (+ReLU) on left-packed per-image channel subsets (see ldn_grouped_conv3x3_image).  w [C,9,gw]."""
     L.require_device(a_nhwc, w, out_nhwc, ch_idx)

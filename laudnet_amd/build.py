@@ -29,10 +29,8 @@ def _compile_and_link(lib: str, tag: str, extra: list, force: bool, verbose: boo
     """One object per translation unit (compiled in parallel, only when its source or a header is newer), then one link."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
-    hdr_t = max(os.path.getmtime(h) for h in HEADERS if os.path.exists(h))
-    mlp = os.path.join(CSRC, "ldn_mlp.h")
-    if os.path.exists(mlp):
-        hdr_t = max(hdr_t, os.path.getmtime(mlp))
+    hdrs = HEADERS + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]      # (every internal header: ldn_mlp.h, ldn_se_head.h ...)
+    hdr_t = max(os.path.getmtime(h) for h in hdrs if os.path.exists(h))
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

@@ -273,6 +273,9 @@ __device__ __forceinline__ void channel_mlp_body(const int b, const float* __res
         if (c < width) {
             const int j = c / gran;
             f = mask_in ? mask_in[(size_t)b * G + j] > 0.5f : s_log[j] >= s_log[G + j];
+#ifdef LDN_MASK_HASH   // tuning only (ablation builds whose activations are garbage): data-independent decisions at a fixed density (per mille)
+            f = ((unsigned)(j * 2654435761u + (unsigned)b * 40503u) >> 12) % 1000u < (unsigned)(LDN_MASK_HASH);
+#endif
         }
         int tot;
         const int r = block_rank_n<NW>(f, s_w, tot);

@@ -64,9 +64,21 @@ __device__ unsigned long long* g_head_trace = nullptr;    // k_head: [workgroup]
 #define TT_ADD(acc, a, b)
 #endif
 
+#ifndef LDN_TAIL_ABLATE
+#define LDN_TAIL_ABLATE 0   // tuning only (results are wrong; tools/trace_chain.py / trace_tail.py with -DLDN_TRACE -DLDN_MASK_HASH=607): 1 = no LDS-DMA at all, 4 = no MFMA (operands kept alive)
+#endif
+#if LDN_TAIL_ABLATE & 4
+template <typename A, typename B, typename C> __device__ __forceinline__ C t_mfma_bf16(A a, B b, C c) { asm volatile("" ::"v"(a), "v"(b)); return c; }
+#else
+#define t_mfma_bf16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+
 // LDS-DMA of 16 bytes per lane: LDS destination = lds_base (wave-uniform byte address) + lane * 16, source per lane.
 // Inline asm: the compiler neither counts it nor waits for it (cdna_hip_programming.md 5.7) -- every wait is explicit below.
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+#if LDN_TAIL_ABLATE & 1
+    return;
+#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
@@ -111,9 +123,9 @@ __device__ __forceinline__ void split2(float v, __bf16& hi, __bf16& lo) {
         _Pragma("unroll") for (int ki_ = 0; ki_ < 4; ++ki_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ka0_[ki_], kb0_[ki_], ACC_, 0, 0, 0); \
         _Pragma("unroll") for (int ki_ = 0; ki_ < 4; ++ki_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ka1_[ki_], kb1_[ki_], ACC_, 0, 0, 0); \
     } else { \
-        ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL_, BH_, ACC_, 0, 0, 0); \
-        ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH_, BL_, ACC_, 0, 0, 0); \
-        ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH_, BH_, ACC_, 0, 0, 0); \
+        ACC_ = t_mfma_bf16(AL_, BH_, ACC_); \
+        ACC_ = t_mfma_bf16(AH_, BL_, ACC_); \
+        ACC_ = t_mfma_bf16(AH_, BH_, ACC_); \
     }
 
 constexpr int T_KIDX_BYTES = 1280;        // int[W + 32] channel list (W <= 256)
@@ -661,9 +673,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
                             const u32x4 ahu = {e[t][0][0], e[t][1][0], e[t][2][0], e[t][3][0]};
                             const u32x4 alu = {e[t][0][1], e[t][1][1], e[t][2][1], e[t][3][1]};
                             const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
-                            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pjh[2 * jj + t], acc3, 0, 0, 0);
-                            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pjl[2 * jj + t], acc3, 0, 0, 0);
-                            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pjh[2 * jj + t], acc3, 0, 0, 0);
+                            acc3 = t_mfma_bf16(al, pjh[2 * jj + t], acc3);
+                            acc3 = t_mfma_bf16(ah, pjl[2 * jj + t], acc3);
+                            acc3 = t_mfma_bf16(ah, pjh[2 * jj + t], acc3);
                         }
                         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
@@ -968,6 +980,9 @@ __device__ __forceinline__ void wait_vm_rt(int n) {   // counted wait with a run
 // the caller with (3 - f) * 1024 against sbase - 3072) -> LDS lds_base + f * 1024 + lane * 16.  The instruction offset of
 // global_load_lds_dwordx4 moves the LDS destination as well as the global source (tools/experiments/dma_offset.hip).
 template <int NF> __device__ __forceinline__ void dma16_pieces(const unsigned (&vo)[4], const void* sbase, unsigned lds_base) {
+#if LDN_TAIL_ABLATE & 1
+    return;
+#endif
     unsigned keep;
     if constexpr (NF == 1)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -1429,9 +1444,9 @@ __device__ __forceinline__ void head_body2(const HeadArgs& p, const int b, const
                 if (j < nsub) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wsl + j * 4096 + ((uu ^ xsw) << 4));
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(wsl + j * 4096 + (((uu + 1) ^ xsw) << 4));
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[CUR][half], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[CUR][half], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[CUR][half], acc[j], 0, 0, 0);
+                    acc[j] = t_mfma_bf16(al, bh[CUR][half], acc[j]);
+                    acc[j] = t_mfma_bf16(ah, bl[CUR][half], acc[j]);
+                    acc[j] = t_mfma_bf16(ah, bh[CUR][half], acc[j]);
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                 }

@@ -102,6 +102,13 @@ int ldn_mask_to_index(const float* patch_mask, int B, int Sy, int Sx, int Ho, in
                       int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
                       int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work, void* stream);
 size_t ldn_mask_to_index_workspace_bytes(int B, int Ho, int Wo, int stride);
+/* The one-launch build (ldn_mask_plan, and ldn_mask_to_index where ldn_mask_plan_fits) keeps its flag words in `work`: they must be zero when the
+ * launch starts, so a zeroing launch runs in front of it -- unless the caller vouches for the buffer: ldn_plan_work_zeroed(1) says that the `work`
+ * of the NEXT such call of this thread is all zero.  Every one-launch build LEAVES its flag words zero (the last workgroup out clears them), so a
+ * buffer zeroed once and only ever handed to one-launch builds on ONE stream stays valid: 1 launch per list build instead of 2.  The word is
+ * consumed by the next ldn_mask_plan / ldn_mask_to_index call whatever path it takes; never give it for a buffer the banded / two-launch build
+ * (maps beyond ldn_mask_plan_fits, LDN_INDEX_PLAN=0) has used. */
+int ldn_plan_work_zeroed(int yes);
 
 /* ---- a1 + a4 in ONE launch (round 4): the fused spatial masker of a run of identity blocks (models/utils.py:47-65 +
  * laud_resnet.py:96-110).  The lists, counts, prefixes and statistics of ldn_mask_to_index, from

@@ -343,7 +343,8 @@ struct PlanArgs {
     int patch_major;
     const float* patch;
     const float* pool; int C; const float* w; const float* bias; float* mask_out; float* logits;
-    int32_t* sync;                 // [1 + 3 B], zeroed in front of the launch: failure word; per image count3 + 1, count1 + 1, patches + 1
+    int32_t* sync;                 // [2 + 3 B], ZERO in front of the launch and left zero by it: failure word; per image count3 + 1, count1 + 1, patches + 1;
+                                   // workgroups that have left (the last one out zeroes all of it for the next launch on this buffer)
     int32_t *idx3, *pos3, *idx1, *pos1, *nbr, *cnt, *pre3, *pre1;
     float* stats;
     long long timeout_ticks;       // bound of the prefix wait in wall_clock64() ticks (100 MHz); set by launch_plan
@@ -499,6 +500,17 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
         if (lane < 2) __hip_atomic_store(&a.cnt[lane], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane < 3) __hip_atomic_store(reinterpret_cast<int*>(a.stats) + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    // Leaving (the LAST thing a workgroup does, on every path): count out; the last workgroup out -- nobody reads a flag word any more -- zeroes
+    // them all, so that the next launch on this buffer (stream order) finds them clean without a zeroing launch in front of it.
+    auto leave = [&]() {
+        __syncthreads();
+        if (wave == 0) {
+            int last = 0;
+            if (lane == 0) last = __hip_atomic_fetch_add(&a.sync[1 + 3 * g.B], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.B - 1;
+            if (__builtin_amdgcn_readfirstlane(last))
+                for (int i = lane; i < 2 + 3 * g.B; i += 64) __hip_atomic_store(&a.sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     if (s_fail) {                   // (never observed outside the test hook: a predecessor that did not publish within the bound)
         if (wave == 0) {
             if (lane == 0) {        // flag first, then the zeroes
@@ -508,6 +520,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             poison();
         }
+        leave();
         return;
     }
     const int base3 = s_base[0], base1 = s_base[1], own3 = s_red[0];
@@ -582,6 +595,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (__hip_atomic_load(&a.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) poison();
     }
+    leave();
 }
 
 // ---- S == Sx == 1 (layer skip: one decision per image): every list is a closed form of the number of kept images in front of
@@ -1197,7 +1211,13 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
 static size_t plan_lds(int S, int Sx, int Ho, int Wo, int stride) {
     return (size_t)Ho * Wo * 9 + (size_t)Ho * stride * Wo * stride * 5 + (size_t)round_up(S * Sx, 16);
 }
-static int launch_plan(PlanArgs& a, int32_t* work, hipStream_t st) {
+// The caller's word that the `work` buffer of the NEXT one-launch list build of this thread is all zero (a buffer it zeroed once and has only
+// ever handed to such builds on one stream: every build leaves it zero) -- the zeroing launch in front of k_plan is then skipped.  Consumed by
+// the next ldn_mask_plan / ldn_mask_to_index call of the thread whatever path it takes.
+static thread_local int g_plan_work_zero = 0;
+extern "C" int ldn_plan_work_zeroed(int yes) { g_plan_work_zero = yes ? 1 : 0; return LDN_OK; }
+
+static int launch_plan(PlanArgs& a, int32_t* work, hipStream_t st, bool work_is_zero) {
     const IdxGeom& g = a.g;
     const size_t lds = plan_lds(g.S, g.Sx, g.Ho, g.Wo, g.stride);
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_plan), lds), "k_plan: cannot reserve %zu B of LDS", lds);
@@ -1208,9 +1228,11 @@ static int launch_plan(PlanArgs& a, int32_t* work, hipStream_t st) {
     a.timeout_ticks = (long long)timeout_ms * 100000ll;
     // the flag words are zeroed by a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph faulted on the second replay
     // of the graph (ROCm 7.2, measured: tools/experiments/repro_graph.py), a kernel node replays fine
-    const int nsync = 3 * g.B + 1;
-    hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)ceil_div(nsync, 256)), dim3(256), 0, st, work, nsync);
-    LDN_CHECK_LAUNCH("k_zero_i32");
+    const int nsync = 3 * g.B + 2;
+    if (!work_is_zero) {
+        hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)ceil_div(nsync, 256)), dim3(256), 0, st, work, nsync);
+        LDN_CHECK_LAUNCH("k_zero_i32");
+    }
     hipLaunchKernelGGL(k_plan, dim3((unsigned)g.B), dim3(kPlanThreads), lds, st, a);
     LDN_CHECK_LAUNCH("k_plan");
     return LDN_OK;
@@ -1224,6 +1246,8 @@ extern "C" int ldn_mask_plan(const float* patch_mask, const float* pool, int C, 
                              float* logits, int B, int S, int Sx, int Ho, int Wo, int stride, int patch_major, int32_t* idx3,
                              int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt, int32_t* img_prefix3,
                              int32_t* img_prefix1, float* stats, int32_t* work, void* stream) {
+    const bool work_zero = g_plan_work_zero != 0;     // (consumed by this call whatever happens below)
+    g_plan_work_zero = 0;
     LDN_REQUIRE(idx3 && pos3 && idx1 && pos1 && nbr && cnt && img_prefix3 && img_prefix1 && stats && work, "ldn_mask_plan: null pointer");
     LDN_REQUIRE(B > 0 && S > 0 && Sx > 0 && Ho > 0 && Wo > 0 && stride >= 1, "ldn_mask_plan: bad shape");
     LDN_REQUIRE((long)B * Ho * stride * Wo * stride < (1l << 31), "ldn_mask_plan: index space exceeds int32");
@@ -1234,7 +1258,7 @@ extern "C" int ldn_mask_plan(const float* patch_mask, const float* pool, int C, 
     LDN_REQUIRE(ldn_mask_plan_fits(S, Sx, Ho, Wo, stride), "ldn_mask_plan: the per-image tables of a %dx%d map exceed one workgroup's LDS (use ldn_mask_to_index)", Ho * stride, Wo * stride);
     PlanArgs a{IdxGeom{B, S, Sx, Ho, Wo, stride, Ho * stride, Wo * stride}, patch_major ? 1 : 0, patch_mask, pool, C, w, bias, mask_out, logits,
                nullptr, idx3, pos3, idx1, pos1, nbr, cnt, img_prefix3, img_prefix1, stats};
-    return launch_plan(a, work, static_cast<hipStream_t>(stream));
+    return launch_plan(a, work, static_cast<hipStream_t>(stream), work_zero);
 }
 
 // layer skip (one decision per image) with the kept images' pixels listed TILE BY TILE (tile_gy x tile_gx pixels; 0, 0 = row-major,
@@ -1277,6 +1301,8 @@ extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, 
                                  int32_t* pos3, int32_t* idx1, int32_t* pos1, int32_t* nbr, int32_t* cnt,
                                  int32_t* img_prefix3, int32_t* img_prefix1, float* stats, int32_t* work,
                                  void* stream) {
+    const bool work_zero = g_plan_work_zero != 0;     // (consumed by this call whatever path it takes)
+    g_plan_work_zero = 0;
     LDN_REQUIRE(patch_mask && idx3 && pos3 && idx1 && pos1 && nbr && cnt && img_prefix3 && img_prefix1 && stats && work,
                 "ldn_mask_to_index: null pointer");
     LDN_REQUIRE(B > 0 && S > 0 && Sx > 0 && Ho > 0 && Wo > 0 && stride >= 1, "ldn_mask_to_index: bad shape");
@@ -1296,7 +1322,7 @@ extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, 
     if (use_plan && !getenv("LDN_INDEX_BANDS") && ldn_mask_plan_fits(S, Sx, Ho, Wo, stride)) {   // whole image in one workgroup's LDS: one launch
         PlanArgs a{g, 0, patch_mask, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, idx3, pos3, idx1, pos1, nbr, cnt,
                    img_prefix3, img_prefix1, stats};
-        return launch_plan(a, work, st);
+        return launch_plan(a, work, st, work_zero);
     }
     const size_t lds1 = (size_t)Ho * Wo;
     const size_t lds2 = (size_t)Ho * Wo * 5 + (size_t)g.Hi * g.Wi * 4;

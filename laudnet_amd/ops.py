@@ -138,7 +138,7 @@ class IndexSet:
     patch_major: bool = False     # idx3 lists the kept pixels patch by patch (ldn_mask_plan): whole patches are consecutive packed rows
 
 
-def _empty_index(B, out_h, out_w, stride, dev):
+def _empty_index(B, out_h, out_w, stride, dev, plan_S=None):
     lib = L.load()
     cap3, cap1 = B * out_h * out_w, B * out_h * stride * out_w * stride
     i32 = dict(device=dev, dtype=torch.int32)
@@ -146,8 +146,27 @@ def _empty_index(B, out_h, out_w, stride, dev):
                   pos1=torch.empty(cap1, **i32), nbr=torch.empty(cap3 * 9, **i32), cnt=torch.empty(2, **i32),
                   pre3=torch.empty(B + 1, **i32), pre1=torch.empty(B + 1, **i32),
                   stats=torch.empty(3, device=dev, dtype=torch.float32), cap3=cap3, cap1=cap1)
-    work = torch.empty(max(lib.ldn_mask_to_index_workspace_bytes(B, out_h, out_w, stride) // 4, 1), **i32)
-    return ix, work
+    nwork = max(lib.ldn_mask_to_index_workspace_bytes(B, out_h, out_w, stride) // 4, 1)
+    if plan_S is not None and USE_CLEAN_PLAN_WORK and _plan_path(lib, plan_S[0], plan_S[1], out_h, out_w, stride):
+        # the one-launch build leaves its flag words zero: a buffer zeroed ONCE per (device, stream) serves every build (ldn_plan_work_zeroed)
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        work = _PLAN_WORK.get(key)
+        if work is None or work.numel() < nwork:
+            work = _PLAN_WORK[key] = torch.zeros(max(nwork, 4096), **i32)
+        lib.ldn_plan_work_zeroed(1)
+        return ix, work
+    return ix, torch.empty(nwork, **i32)
+
+
+_PLAN_WORK = {}
+USE_CLEAN_PLAN_WORK = os.environ.get("LDN_PLAN_CLEAN_WORK", "1") != "0"    # tuning switch (A/B): "0" = a fresh work buffer + a zeroing launch per list build
+
+
+def _plan_path(lib, S, Sx, out_h, out_w, stride):
+    """Will ldn_mask_plan / ldn_mask_to_index build these lists in ONE launch (k_plan)?  (mirrors the library's own choice)"""
+    if os.environ.get("LDN_INDEX_BANDS") or os.environ.get("LDN_INDEX_PLAN", "1") == "0":
+        return False
+    return bool(lib.ldn_mask_plan_fits(int(S), int(Sx), int(out_h), int(out_w), int(stride)))
 
 
 def plan_timeouts(reset=False, raise_on_error=False):
@@ -174,7 +193,8 @@ def mask_to_index(patch_mask, out_h, out_w, stride, patch_major=False):
     if patch_mask.dim() != 3:
         raise L.LdnError("mask_to_index: patch_mask must be [B,Sy,Sx]")
     B, S, Sx = patch_mask.shape
-    ix, work = _empty_index(B, out_h, out_w, stride, patch_mask.device)
+    # (S == Sx == 1 is the closed-form layer-skip build: it does not touch `work`)
+    ix, work = _empty_index(B, out_h, out_w, stride, patch_mask.device, plan_S=(S, Sx) if (patch_major or S > 1 or Sx > 1 or os.environ.get("LDN_INDEX_GENERIC")) else None)
     if patch_major:
         ix.patch_major = True
         L.check(lib.ldn_mask_plan(L.ptr(_f32c(patch_mask, "patch_mask")), None, 0, None, None, None, None, B, S, Sx, out_h, out_w,
@@ -226,7 +246,7 @@ def mask_plan(pool, weight, bias, out_h, out_w, stride=1, patch_major=True, want
         raise L.LdnError("mask_plan: pool must be [B,S,Sx,C], weight [2,C], bias [2] (one mask group)")
     B, S, Sx, C = pool.shape
     dev = pool.device
-    ix, work = _empty_index(B, out_h, out_w, stride, dev)
+    ix, work = _empty_index(B, out_h, out_w, stride, dev, plan_S=(S, Sx))
     ix.patch_major = bool(patch_major)
     mask = torch.empty(B, 1, S, Sx, device=dev, dtype=torch.float32)
     logits = torch.empty(B, 2, S, Sx, device=dev, dtype=torch.float32) if want_logits else None

@@ -117,6 +117,33 @@ def test_plan_equals_two_launch_build(ops, B, S, Ho, Wo, stride, p, monkeypatch)
     assert torch.equal(one.nbr[:n3 * 9], two.nbr[:n3 * 9])
 
 
+def test_plan_leaves_its_flag_words_zero_for_the_next_build(ops):
+    """ldn_plan_work_zeroed: the one-launch build clears its flag words on the way out (last workgroup out), so ONE buffer zeroed once per
+    (device, stream) serves every build without a zeroing launch in front (ops' default).  A run of builds of different shapes on that
+    buffer against builds with a fresh buffer + zeroing launch each (USE_CLEAN_PLAN_WORK = False): identical lists; the shared buffer is all
+    zero afterwards."""
+    shapes = [(260, 7, 14, 14, 1, 0.5), (3, 14, 14, 14, 1, 0.5), (5, 14, 56, 56, 1, 0.3), (2, 3, 14, 14, 2, 0.4), (64, 7, 28, 28, 1, 0.6), (260, 7, 14, 14, 1, 0.1)]
+    assert ops.USE_CLEAN_PLAN_WORK
+    got = []
+    for rep in range(2):
+        for (B, S, Ho, Wo, stride, p) in shapes:
+            got.append(ops.mask_to_index(seeded_bernoulli((B, S, S), p, 3 + B + Ho).to(DEV), Ho, Wo, stride))
+    torch.cuda.synchronize()
+    bufs = [w for k, w in ops._PLAN_WORK.items() if k[0] == str(torch.device(DEV)) or k[0] == DEV]
+    assert bufs and all(int(w.abs().sum()) == 0 for w in bufs), "the flag words must be left zero"
+    ops.USE_CLEAN_PLAN_WORK = False
+    try:
+        want = [ops.mask_to_index(seeded_bernoulli((B, S, S), p, 3 + B + Ho).to(DEV), Ho, Wo, stride) for (B, S, Ho, Wo, stride, p) in shapes]
+    finally:
+        ops.USE_CLEAN_PLAN_WORK = True
+    torch.cuda.synchronize()
+    for i, one in enumerate(got):
+        two = want[i % len(shapes)]
+        n3, n1 = int(two.cnt[0]), int(two.cnt[1])
+        assert torch.equal(one.cnt, two.cnt) and torch.equal(one.pre3, two.pre3) and torch.equal(one.pre1, two.pre1) and torch.equal(one.stats, two.stats)
+        assert torch.equal(one.idx3[:n3], two.idx3[:n3]) and torch.equal(one.idx1[:n1], two.idx1[:n1]) and torch.equal(one.nbr[:n3 * 9], two.nbr[:n3 * 9])
+
+
 @pytest.mark.parametrize("B,C,S,H", [(4, 256, 14, 56), (3, 512, 7, 28), (6, 1024, 7, 14), (2, 64, 4, 8)])
 def test_plan_decides_like_the_standalone_masker(ops, B, C, S, H):
     """Decide mode: from the pooled means the stand-alone masker stored, ldn_mask_plan takes the SAME decisions with the SAME logits

@@ -487,7 +487,8 @@ size_t ldn_se_packed_workspace_bytes(int B, int C, int max_rows_per_image);
  *   2. ldn_se_gate_slots: gate[k][:] = sigmoid(W2 relu(W1 (sum over bands / rows_per_image) + b1) + b2) for every kept image k
  *      (k * rows_per_image < *m_count), gate [images_cap][C]; w1 [S][C], w2 [C][S];
  *   3. ldn_conv_rows_gated: conv c reads h_b and multiplies row r by gate[r / gate_rows][:] in flight (bf16x3; products formed from
- *      fp32(h_b * gate): bit-identical to scaling h_b first); any cin % 8 == 0 (<= 2048), cout % 4 == 0; relu 0 / 1 / 2; residual /
+ *      fp32(h_b * gate): bit-identical to scaling h_b first); any cin % 8 == 0 (<= 2048), cout % 4 == 0; (255 / gate_rows + 2) *
+ *      roundup32(cin) * 4 <= 44 KB (the gate vectors of the images a 256-row tile touches sit in LDS); relu 0 / 1 / 2; residual /
  *      out_rows as ldn_conv_rows_split.
  * Three launches (conv b, the SE head, conv c) instead of six; h_b is read once by conv c and never rewritten. */
 int ldn_grouped16_images_bands(int Hi, int Wi, int Ho, int stride, int C);

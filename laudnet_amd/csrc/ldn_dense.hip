@@ -1011,6 +1011,10 @@ extern "C" int ldn_conv_rows_gated(const float* a, int lda, const int32_t* m_cou
                 gate, gate_rows};
     hipStream_t st = static_cast<hipStream_t>(stream);
     g_rows_hint = -1;
+    // the gate vectors of every image a 256-row tile can touch sit in LDS behind the staging buffers (98 - 114 KB): small images x wide layers do not fit
+    LDN_REQUIRE((size_t)(255 / gate_rows + 2) * round_up(cin, 32) * 4 <= 44 * 1024,
+                "ldn_conv_rows_gated: the gate vectors of the %d images a 256-row tile touches (%d channels each) exceed the 44 KB of LDS left for them "
+                "(scale the rows first and use ldn_conv_rows_split)", 255 / gate_rows + 2, cin);
     if (cout % 128 == 0 || (cout > 64 && cout <= 128)) return launch_dense2<4, false, false, false, true, true, true>(d, st);
     if (cout <= 64) return launch_dense2<2, false, false, false, true, true, true>(d, st);
     return launch_dense2<5, false, false, false, true, true, true>(d, st);

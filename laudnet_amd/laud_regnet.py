@@ -261,7 +261,7 @@ class ResBottleneckBlock(_PrepCache):
         # turns them into a gate per kept image, conv c multiplies its input rows by it in flight -- three launches instead of six
         gate = None
         if (USE_SE_FUSED and "wb_frag" in p and ops.get_math_mode() == "bf16x3" and USE_GROUPED_MFMA and USE_GROUPED_IMAGES
-                and w_b <= 2048 and ops.grouped16_images_fit(Hi, Wi, w_b) > 0):
+                and ops.conv_rows_gated_fits(w_b, Ho * Wo) and ops.grouped16_images_fit(Hi, Wi, w_b) > 0):
             gap = ops.grouped16_conv3x3_images_gap(h_a, p["wb_frag"], p["sb"], p["tb"], h_b, m_count=ix.cnt[0:1],
                                                    images=(B, Hi, Wi, Ho, Wo, self.stride), relu=1)
             gate = ops.se_gate_slots(gap, ix.cnt[0:1], Ho * Wo, p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"])

@@ -735,6 +735,11 @@ def se_gate_slots(gap, m_count, rows_per_image, w1, b1, w2, b2):
     return gate
 
 
+def conv_rows_gated_fits(cin, gate_rows):
+    """ldn_conv_rows_gated keeps the gate vectors of the images a 256-row tile touches in LDS (include/ldn_hip.h): does this shape fit?"""
+    return cin % 8 == 0 and cin <= 2048 and (255 // int(gate_rows) + 2) * ((int(cin) + 31) // 32 * 32) * 4 <= 44 * 1024
+
+
 def conv_rows_gated(a2d, w, scale, shift, out2d, gate, gate_rows, *, m_count=None, m_cap=None, relu=1, relu_if_neg=None, out_rows=None,
                     residual2d=None):
     """1x1 packed-row convolution whose input row r is multiplied by gate[r // gate_rows] in flight (ldn_conv_rows_gated; bf16x3)."""

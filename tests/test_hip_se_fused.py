@@ -107,6 +107,31 @@ def test_conv_c_with_the_gate_on_its_input_rows(ops, imgs, kept, rows, cin, cout
     assert (got.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("rows_total,gate_rows,cin,cout,count", [(1000, 7, 8, 4, 1000), (513, 2, 40, 36, 400), (300, 300, 2048, 64, 257), (257, 64, 136, 200, 1),
+                                                                 (2049, 49, 784, 320, 2049), (64, 10, 24, 160, 0)])
+def test_conv_c_gated_edge_shapes(ops, rows_total, gate_rows, cin, cout, count):
+    """Ragged everything: rows not a multiple of the tile, one gate row per input row, K tails (cin % 32 != 0), the widest K, column tails,
+    an empty and a one-row device-side count -- against fp64 and bit-identical to scaling first."""
+    imgs = (rows_total + gate_rows - 1) // gate_rows
+    h_b = seeded_randn((rows_total, cin), 71).to(DEV)
+    gate = torch.sigmoid(seeded_randn((imgs, cin), 72)).to(DEV)
+    w = (seeded_randn((cout, 1, cin), 73) * (2.0 / cin) ** 0.5).to(DEV)
+    sc, sh = _affine(cout, 74)
+    cnt = torch.tensor([count], dtype=torch.int32, device=DEV)
+    img_of_row = torch.arange(rows_total, device=DEV) // gate_rows
+    scaled = (h_b * gate[img_of_row]).contiguous()
+    want = torch.full((rows_total, cout), -3.0, device=DEV)
+    ops.conv_rows(scaled, w, sc, sh, want, taps=1, m_count=cnt, m_cap=rows_total, relu=0)
+    got = torch.full((rows_total, cout), -3.0, device=DEV)
+    ops.conv_rows_gated(h_b, w, sc, sh, got, gate, gate_rows, m_count=cnt, m_cap=rows_total, relu=0)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert bool((got[count:] == -3.0).all()), "rows past the device-side count must not be written"
+    if count:
+        ref = (scaled[:count].double() @ w[:, 0].double().t()) * sc.double() + sh.double()
+        assert (got[:count].double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_c_gated_rejects_what_it_does_not_run(ops):
     from laudnet_amd import LdnError
     h_b = torch.zeros(64, 32, device=DEV)
@@ -117,6 +142,8 @@ def test_conv_c_gated_rejects_what_it_does_not_run(ops):
         ops.conv_rows_gated(h_b, w, None, sh, out, torch.ones(1, 32, device=DEV), 32)        # gate covers one image, the rows span two
     with pytest.raises(LdnError):
         ops.conv_rows_gated(h_b, w, None, sh, out, torch.ones(2, 16, device=DEV), 32)        # gate width != cin
+    with pytest.raises(LdnError):     # one gate row per input row of a 1024-wide layer: 257 gate vectors per tile do not fit the LDS
+        ops.conv_rows_gated(torch.zeros(64, 1024, device=DEV), torch.zeros(32, 1, 1024, device=DEV), None, sh, out, torch.ones(64, 1024, device=DEV), 1)
 
 
 @pytest.mark.parametrize("stride,Hi,w_in,w_out", [(1, 14, 320, 320), (2, 28, 144, 320), (1, 7, 784, 784)])

@@ -220,14 +220,15 @@ SECONDARY = ("spatial", "layer", "regnet", "adavit")     # BASELINE.json configs
 
 def run_secondary(args):
     """The other BASELINE configs, timed in the SAME invocation as the headline: each one is this script
-    again (`--workload W --steps 10 --warmup 5 --brief`; 30 + 10 for the two short workloads, its own process on the same GPU, after the headline's timed region and legs
-    are done) -- 5 warm-up + 10 timed forwards at batch 256, masks produced by the maskers in the timed region, the oracle's dense
+    again (`--workload W --steps 30 --warmup 10 --brief`, its own process on the same GPU, after the headline's timed region and legs
+    are done) -- 10 warm-up + 30 timed forwards at batch 256, masks produced by the maskers in the timed region, the oracle's dense
     emulation on the same GPU and the same-mask parity beside it.  Values are per-workload JSON lines reduced to the judged keys."""
     import subprocess
     out = {}
     for w in SECONDARY:
-        # (short workloads get more forwards: ten 3.5 ms RegNet steps right after a cold start read 2-3x slow on some boxes -- clocks still ramping)
-        n_steps, n_warm = ("30", "10") if w in ("regnet", "adavit") else ("10", "5")
+        # (30 timed forwards behind 10 warm-up ones: windows of ten forwards right after a process start read up to 2-3x slow now and then -- RegNet 10.8 vs 3.5 ms,
+        # layer 14.1 vs 10.5 ms with every kernel at its usual duration in the event leg of the same process, i.e. a host-side stall of tens of milliseconds)
+        n_steps, n_warm = "30", "10"
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", n_steps, "--warmup", n_warm, "--batch", str(args.batch), "--brief"]
         t0 = time.perf_counter()
         try:

@@ -714,7 +714,15 @@ def main():
         out = step()
     torch.cuda.synchronize()
 
-    # ---- the timed region: exactly args.steps forwards, no HIP events, no instrumentation of any kind
+    # ---- the timed region: exactly args.steps forwards, no HIP events, no instrumentation of any kind.  The interpreter's cyclic garbage
+    # collector is parked for its duration: a rare host-side stall of tens of milliseconds was seen twice in ~60 runs of the round (a 10-forward
+    # window reading 14 ms per step instead of 10 with every kernel at its usual duration in the same process); a generation-2 pass over the
+    # model's object graph is one candidate and costs nothing to rule out (20 alternating runs with / without: 11.03-11.09 ms either way)
+    import gc
+    gc.collect()
+    if not os.environ.get("LDN_BENCH_KEEP_GC"):      # (A/B switch)
+        gc.freeze()
+        gc.disable()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -732,6 +740,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    gc.unfreeze()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

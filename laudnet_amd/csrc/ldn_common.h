@@ -100,6 +100,18 @@ __device__ __forceinline__ u32x4_t presplit_store_quad(const f32x4 x, bool odd) 
     return odd ? u32x4_t{p0, p1, lo[0], lo[1]} : u32x4_t{hi[0], hi[1], p0, p1};
 }
 
+// x[l] + x[l ^ 8] + x[l ^ 16] + ... : the sum over lane bits 3, 4, 5 (the eight row groups of a (row = lane >> 3, quad = lane & 7) epilogue layout), in every
+// lane, WITHOUT the LDS: the tree of three __shfl_xor steps (8, 16, 32 = three dependent ds_bpermute round trips) as one DPP add inside the 16-lane row
+// and the two gfx950 half / row exchanges.  Operand for operand the same additions (a + b vs b + a): bit-identical to the shuffle form.
+__device__ __forceinline__ float sum_lane_bits_345(float x) {
+    float t;
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "=&v"(t) : "v"(x));
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 // 16-byte global store, optionally WRITE-THROUGH (sc0 sc1: the line leaves the XCD's L2 at once instead of staying dirty until the
 // end-of-kernel write-back).  LDN_WT_STORES is a tuning switch (the ~5.6 us behind every large row kernel).
 template <typename V>

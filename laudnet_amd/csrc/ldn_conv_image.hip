@@ -325,13 +325,7 @@ __device__ __forceinline__ void tile_store(const ImgArgs& p, const Tile& t, floa
         }
         if (p.colsum) {   // fused global-average-pool partials for the NEXT block's channel masker
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = csum[e];
-                x += __shfl_xor(x, 8, 64);
-                x += __shfl_xor(x, 16, 64);
-                x += __shfl_xor(x, 32, 64);
-                csum[e] = x;
-            }
+            for (int e = 0; e < 4; ++e) csum[e] = sum_lane_bits_345(csum[e]);
             if (trow == 0) {
                 const size_t slot = ((size_t)t.b * ceil_div(t.HWo, 32) + (t.m0 >> 5) + mi) * p.cout + t.n0 + ccol;   // dense mode only
                 *reinterpret_cast<f32x4*>(p.colsum + slot) = csum;
@@ -443,13 +437,7 @@ __device__ __forceinline__ void tile_store_rows(const ImgArgs& p, const Tile& t,
         }
         if (p.colsum) {   // fused global-average-pool partials for the NEXT block's channel masker
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = csum[e];
-                x += __shfl_xor(x, 8, 64);
-                x += __shfl_xor(x, 16, 64);
-                x += __shfl_xor(x, 32, 64);
-                csum[e] = x;
-            }
+            for (int e = 0; e < 4; ++e) csum[e] = sum_lane_bits_345(csum[e]);
             if (trow == 0) {
                 const size_t slot = ((size_t)t.b * ceil_div(t.HWo, 32) + (t.m0 >> 5) + mi) * p.cout + t.n0 + ccol;   // dense mode only
                 *reinterpret_cast<f32x4*>(p.colsum + slot) = csum;
@@ -1654,13 +1642,7 @@ __global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const ImgArgs p) {
                     }
                     if (p.colsum) {   // fused global-average-pool partials of the 32-pixel subtile (dense image mode only)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = csum[e];
-                            x += __shfl_xor(x, 8, 64);
-                            x += __shfl_xor(x, 16, 64);
-                            x += __shfl_xor(x, 32, 64);
-                            csum[e] = x;
-                        }
+                        for (int e = 0; e < 4; ++e) csum[e] = sum_lane_bits_345(csum[e]);
                         const int sub = ((r0 + mb * ST_BM) >> 5) + mi;
                         if (trow == 0 && sub * 32 < HWo)
                             *reinterpret_cast<f32x4*>(p.colsum + ((size_t)b * ceil_div(HWo, 32) + sub) * p.cout + ccol) = csum;

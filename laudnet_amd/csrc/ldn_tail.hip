@@ -718,13 +718,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
             }
             if (p.colsum) {   // fused global-average-pool partials (the next block's channel masker): one slot per (block, wave)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = csum[e];
-                    x += __shfl_xor(x, 8, 64);
-                    x += __shfl_xor(x, 16, 64);
-                    x += __shfl_xor(x, 32, 64);
-                    csum[e] = x;
-                }
+                for (int e = 0; e < 4; ++e) csum[e] = sum_lane_bits_345(csum[e]);      // (no LDS round trips: DPP + permlane swaps, same additions)
                 if (trw == 0)
                     *reinterpret_cast<f32x4*>(p.colsum + ((size_t)b * (p.mblocks * 8) + mb * 8 + wave) * p.cout + c0 + tc * 4) = csum;
             }

@@ -1126,6 +1126,14 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
         if (cout % 128 != 0 && cout <= 64 && dense2_ok(2, 9, cin, cout)) return launch_dense2<2, true, false, false>(d, st);
         return (cout % 128 == 0 || cout > 64) ? launch_dense<4, true>(d, st) : launch_dense<2, true>(d, st);
     }
+    // ONE K chunk (a 32-wide input: LAD-RegNet's stage 1 behind its 32-channel stem): nothing to pipeline inside a workgroup -- load, multiply, store
+    // follow one another -- so the launch lives on workgroups overlapping EACH OTHER: 128-row tiles with a two-slot ring (49 KB: three per CU)
+    // instead of 256-row tiles with the 122 KB ring of the long-K form (one per CU).  LDN_DENSE_SHORTK=<widest cin> (0: off) for A/B.
+    static const int shortk = getenv("LDN_DENSE_SHORTK") ? atoi(getenv("LDN_DENSE_SHORTK")) : 32;      // widest input that takes this form (0: off; A/B)
+    if (cin <= shortk && !small_grid && !post_sub && !chan_mask && !ln_stats && relu != 3) {
+        if (cout <= 64) return cout % 64 == 0 ? launch_dense_f<2, false, true, false, 128>(d, st) : launch_dense_f<2, false, false, false, 128>(d, st);
+        if (cout % 128 == 0) return launch_dense_f<4, false, true, false, 128>(d, st);
+    }
     if (use_model && rows_known > 0 && !small_grid) {
         int best = 0;
         double best_cost = 0.0;

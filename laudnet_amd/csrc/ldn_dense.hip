@@ -1134,6 +1134,9 @@ static int conv_rows_dense_impl(const float* a, int lda, const int32_t* a_rows, 
         if (cout <= 64) return cout % 64 == 0 ? launch_dense_f<2, false, true, false, 128>(d, st) : launch_dense_f<2, false, false, false, 128>(d, st);
         if (cout % 128 == 0) return launch_dense_f<4, false, true, false, 128>(d, st);
     }
+    static const int shortk5 = getenv("LDN_DENSE_SHORTK5") ? atoi(getenv("LDN_DENSE_SHORTK5")) : 144;  // the same for 160-column tiles (ragged widths above 128; RegNet 3.25 -> 3.22 ms); 0: off
+    if (cin <= shortk5 && !small_grid && !post_sub && !chan_mask && !ln_stats && relu != 3 && (cout % 160 == 0 || (cout % 32 != 0 && cout > 128)))
+        return cout % 160 == 0 ? launch_dense_f<5, false, true, false, 128>(d, st) : launch_dense_f<5, false, false, false, 128>(d, st);
     if (use_model && rows_known > 0 && !small_grid) {
         int best = 0;
         double best_cost = 0.0;

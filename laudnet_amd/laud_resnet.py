@@ -169,13 +169,13 @@ class Masker_spatial(_PrepCache):
                                    self.conv.bias.detach().float().contiguous()))
         return self._prep
 
-    def decide_from_means(self, work, x_shape, out_hw, patch_major):
+    def decide_from_means(self, work, x_shape, out_hw, patch_major, stride=1):
         """The decision AND the packed lists of the block in one launch, from the pooled patch means the previous block's conv3
         left in `work` (ldn_mask_plan; models/utils.py:47-65 without reading x).  Returns (mask [B,1,S,S], IndexSet)."""
         B, C, H, W = x_shape
         S = self.mask_size
         w, b = self._wb()
-        mask, _, ix = ops.mask_plan(work.view(B, S, S, C), w, b, out_hw[0], out_hw[1], 1, patch_major=patch_major)
+        mask, _, ix = ops.mask_plan(work.view(B, S, S, C), w, b, out_hw[0], out_hw[1], stride, patch_major=patch_major)
         self.last_work = work
         return mask, ix
 
@@ -707,6 +707,60 @@ class Bottleneck(_PrepCache):
             return S
         return None
 
+    def _pool_grid_out(self, Ho, Wo, cout):
+        """The same for a PROJECTION block (stride 1 or 2) as the producer: its output is written whole by the projection launch (every
+        pixel, ReLU where the block is inactive) and rewritten at the active pixels by conv3 -- with the projection's rows listed patch by
+        patch both launches can leave the mean of every cell they complete, so the block behind it decides without reading x either."""
+        ms = self.masker_spatial
+        if not (self.use_fused_spatial_masker and self.use_fused_projection_means and ms.mask_channel_group == 1 and self.forced_spatial_mask is None
+                and self.downsample is not None and cout % 128 == 0 and self.width % 8 == 0 and ops.dense_kernel_ok()
+                and ops.get_math_mode() == "bf16x3"):
+            return None
+        S = ms.mask_size
+        if S == 1:
+            if Ho != Wo:
+                return None
+            return Ho // 4 if Ho % 4 == 0 else (Ho // 2 if Ho % 2 == 0 else None)
+        if 1 < S < Ho and Ho % S == 0 and Wo % S == 0 and (Ho // S) * (Wo // S) in (4, 16) and ops.mask_plan_fits(S, S, Ho, Wo, self.stride):
+            return S
+        return None
+
+    use_fused_projection_means = os.environ.get("LDN_FUSED_PROJECTION_MEANS", "1") != "0"   # class-level switch (A/B, tests)
+
+    def _patch_major_rows(self, B, Hi, Wi, Ho, Wo, s, S, dev):
+        """(source row of x, flat output pixel) of every output pixel of the batch, listed cell by cell of the S x S grid (row-major inside a
+        cell, cells row-major, images in order): the projection launch's gather / scatter lists when it leaves the cell means."""
+        key = ("pm", B, Hi, Wi, Ho, Wo, s, S, str(dev))
+        cache = self.__dict__.setdefault("_ds_cache", {})
+        if key not in cache:
+            gy, gx = Ho // S, Wo // S
+            b = torch.arange(B, device=dev).view(B, 1, 1, 1, 1)
+            py = torch.arange(S, device=dev).view(1, S, 1, 1, 1)
+            px = torch.arange(S, device=dev).view(1, 1, S, 1, 1)
+            ly = torch.arange(gy, device=dev).view(1, 1, 1, gy, 1)
+            lx = torch.arange(gx, device=dev).view(1, 1, 1, 1, gx)
+            oy, ox = py * gy + ly, px * gx + lx
+            out_pix = ((b * Ho + oy) * Wo + ox).reshape(-1)
+            src = ((b * Hi + oy * s) * Wi + ox * s).reshape(-1)
+            cache[key] = (src.to(torch.int32).contiguous(), out_pix.to(torch.int32).contiguous(), out_pix.long().contiguous())
+        return cache[key]
+
+    def _consume_grid(self, Hi, Wi, Ho, Wo):
+        """S of the S x S grid of cell means of its INPUT this block's masker can decide from (None: it reads x itself) -- the consumer side of
+        _pool_grid, without the producer's conditions: a stride-2 / projection block at the head of a stage pools the same input cells its
+        predecessor (the last identity block of the stage before) rewrote (models/utils.py:47-52: adaptive_avg_pool2d of the block INPUT)."""
+        ms = self.masker_spatial
+        if not (self.use_fused_spatial_masker and ms.mask_channel_group == 1 and self.forced_spatial_mask is None and ops.dense_kernel_ok()):
+            return None
+        S = ms.mask_size
+        if S == 1:
+            if Hi != Wi:
+                return None
+            return Hi // 4 if Hi % 4 == 0 else (Hi // 2 if Hi % 2 == 0 else None)
+        if 1 < S < Hi and Hi % S == 0 and Wi % S == 0 and (Hi // S) * (Wi // S) in (4, 16) and ops.mask_plan_fits(S, S, Ho, Wo, self.stride):
+            return S
+        return None
+
     def _run_spatial(self, x, p):
         B, Cin, Hi, Wi = x.shape
         W = self.width
@@ -720,20 +774,23 @@ class Bottleneck(_PrepCache):
         # builds its lists from those means in ONE launch (ldn_mask_plan) -- no pass over x, no count launch
         layer = ms.mask_size == 1
         pS = self._pool_grid(Hi, Wi, Ho, Wo, p["w3"].shape[0])
-        pool_out = bool(getattr(self, "_pool_next", False)) and pS is not None
+        # (a projection block as the producer: the grid lives on its OUTPUT map; its pool buffer is its own, not the masker's)
+        gS_ds = self._pool_grid_out(Ho, Wo, p["w3"].shape[0]) if self.downsample is not None else None
+        pool_out = bool(getattr(self, "_pool_next", False)) and (pS is not None or gS_ds is not None)
         self._pool_next = False
         ix = None
-        fresh = (pS is not None and carry_in is not None and len(carry_in) > 4 and carry_in[4] and carry_in[0] is not None
-                 and tuple(carry_in[2] or ()) == (B, Hi, Wi, Cin, pS))
+        cS = pS if pS is not None else self._consume_grid(Hi, Wi, Ho, Wo)
+        fresh = (cS is not None and carry_in is not None and len(carry_in) > 4 and carry_in[4] and carry_in[0] is not None
+                 and tuple(carry_in[2] or ()) == (B, Hi, Wi, Cin, cS))
         # (tests / bench audits) did this block's decision come from the pooled means the previous block's conv3 epilogue left?
         self.last_fused_decision = bool(fresh) and self.forced_spatial_mask is None
         if self.forced_spatial_mask is not None:
             patch = self.forced_spatial_mask.to(device=x.device, dtype=torch.float32).contiguous()
         elif fresh and layer:
-            patch = ms.decide_layer_from_means(carry_in[0], B, pS, Cin)
+            patch = ms.decide_layer_from_means(carry_in[0], B, cS, Cin)
         elif fresh:
-            patch, ix = ms.decide_from_means(carry_in[0], x.shape, (Ho, Wo), pool_out)
-        elif layer and pool_out:
+            patch, ix = ms.decide_from_means(carry_in[0], x.shape, (Ho, Wo), pool_out, stride=self.stride)
+        elif layer and pool_out and gS_ds is None:
             patch = ms.decide_layer_pooled(x, pS)
         else:
             patch = ms.decide(x, carry=carry_in if not (carry_in is not None and len(carry_in) > 4 and layer) else None)
@@ -744,11 +801,18 @@ class Bottleneck(_PrepCache):
         union = patch[:, 0] if G == 1 else patch.amax(dim=1)
         if ix is None:
             if layer and pool_out:     # the kept images' pixels tile by tile: conv3's epilogue owns whole tiles
-                ix = ops.layer_index(union.reshape(B), Ho, Wo, self.stride, tile=(Hi // pS, Wi // pS))
+                gS = pS if gS_ds is None else gS_ds
+                ix = ops.layer_index(union.reshape(B), Ho, Wo, self.stride, tile=(Ho // gS, Wo // gS))
             else:
                 ix = ops.mask_to_index(union.contiguous(), Ho, Wo, self.stride, patch_major=pool_out)
         pool = None
-        if self.forced_spatial_mask is None and getattr(ms, "last_work", None) is not None:
+        if gS_ds is not None and pool_out and ix.patch_major and self.forced_spatial_mask is None:
+            cout_ = p["w3"].shape[0]
+            work = torch.empty(B * gS_ds * gS_ds * cout_, device=dev, dtype=torch.float32)
+            work.ldn_shape_key = (B, Ho, Wo, cout_, gS_ds)
+            pool = work.view(B, gS_ds, gS_ds, cout_)
+            self.last_carry = (work, ix.pre3 if layer else None, work.ldn_shape_key, None if layer else union.contiguous(), True)
+        elif self.forced_spatial_mask is None and getattr(ms, "last_work", None) is not None:
             key = getattr(ms.last_work, "ldn_shape_key", None)
             if pool_out and ix.patch_major and key is not None and tuple(key) == (B, Hi, Wi, Cin, pS):
                 # [4]: conv3 below refreshes the means of the cells it rewrites -> the next block decides without reading x
@@ -791,10 +855,17 @@ class Bottleneck(_PrepCache):
                 groups.append((ig, rows.contiguous(), slice(g * (cout // G), (g + 1) * (cout // G))))
         if self.downsample is not None:
             out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
-            ds_rows = self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev)
-            for ig, _, cs in groups:   # ReLU directly where the (pixel, group) is inactive: no branch output is added there
-                ops.conv_rows(x2d, p["wd"][cs], p["sd"][cs], p["td"][cs], out2d[:, cs], a_rows=ds_rows, taps=1, m_cap=ix.cap3,
-                              relu=2, relu_if_neg=ig.pos3)
+            if pool is not None and gS_ds is not None:
+                # the projection's rows cell by cell: its epilogue leaves the mean of every cell (final for the inactive ones; conv3 below
+                # rewrites the active cells and their means)
+                src_pm, out_pm, out_pm_long = self._patch_major_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], gS_ds, dev)
+                ops.conv_rows(x2d, p["wd"], p["sd"], p["td"], out2d, a_rows=src_pm, taps=1, m_cap=ix.cap3, relu=2,
+                              relu_if_neg=ix.pos3.view(-1)[out_pm_long].contiguous(), out_rows=out_pm, pool=pool, pool_grid=(gS_ds, gS_ds, Ho, Wo))
+            else:
+                ds_rows = self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev)
+                for ig, _, cs in groups:   # ReLU directly where the (pixel, group) is inactive: no branch output is added there
+                    ops.conv_rows(x2d, p["wd"][cs], p["sd"][cs], p["td"][cs], out2d[:, cs], a_rows=ds_rows, taps=1, m_cap=ix.cap3,
+                                  relu=2, relu_if_neg=ig.pos3)
             resid = out2d
         elif self._inplace:
             resid = out2d = x2d          # x >= 0 (post-ReLU) inside the network: inactive pixels pass through
@@ -804,11 +875,11 @@ class Bottleneck(_PrepCache):
             if ps and (cs.stop - cs.start) % 64 == 0:
                 ops.conv_rows_ps(h2, p["w3"][cs], None, p["t3"][cs], out2d[:, cs], a_presplit=True, a_rows=rows, m_count=ig.cnt[0:1],
                                  m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs], rows_hint=n3 if G == 1 else None,
-                                 pool=pool, pool_grid=(pS, pS, Ho, Wo) if pool is not None else None)
+                                 pool=pool, pool_grid=((pS if gS_ds is None else gS_ds,) * 2 + (Ho, Wo)) if pool is not None else None)
                 continue
             ops.conv_rows(h2 if not ps else ops.unsplit_rows(h2), p["w3"][cs], None, p["t3"][cs], out2d[:, cs], a_rows=rows, taps=1, m_count=ig.cnt[0:1],
                           m_cap=ix.cap3, relu=1, out_rows=ig.idx3, residual2d=resid[:, cs], rows_hint=n3 if G == 1 else None, pool=pool,
-                          pool_grid=(pS, pS, Ho, Wo) if pool is not None else None)
+                          pool_grid=((pS if gS_ds is None else gS_ds,) * 2 + (Ho, Wo)) if pool is not None else None)
         self.last_spatial_mask = patch
         if G > 1:   # sparsity of conv3 = mean over ALL group masks (Masker_spatial, utils.py:61); conv2 / conv1 = the union's
             ix.stats = torch.cat((patch.mean().reshape(1), ix.stats[1:]))
@@ -1116,14 +1187,17 @@ class ResNet(nn.Module):
             # layer skip: the images the previous block skipped reach this block unchanged -> their channel sums (the masker's global
             # average pool) are carried over instead of re-read (one full read of x per block otherwise)
             prev = blocks[j - 1] if j > 0 else None
+            # (a carry of FRESH cell means -- conv3's epilogue left the mean of every cell of the block's output -- also serves the stride-2 /
+            # projection block at the head of the next stage: its masker pools its INPUT, which is that output)
+            fresh_means = prev is not None and len(getattr(prev, "last_carry", None) or ()) > 4 and bool(prev.last_carry[4])
             blk._carry_in = (prev.last_carry if (self.use_layer_carry and prev is not None and blk.dyn_mode in ("layer", "spatial") and prev.dyn_mode == blk.dyn_mode
-                                                 and blk.stride == 1 and blk.downsample is None and blk.forced_spatial_mask is None
+                                                 and ((blk.stride == 1 and blk.downsample is None) or (fresh_means and self.use_stage_carry)) and blk.forced_spatial_mask is None
                                                  # the producer must leave the images it skips UNCHANGED: a block with a projection
                                                  # shortcut / stride 2 turns them into relu(downsample(x))
-                                                 and prev.stride == 1 and prev.downsample is None
+                                                 and ((prev.stride == 1 and prev.downsample is None) or fresh_means)
                                                  and getattr(prev, "_carry_step", -1) == step_id) else None)
             blk._pool_next = (self.use_layer_carry and nxt is not None and blk.dyn_mode in ("spatial", "layer") and nxt.dyn_mode == blk.dyn_mode
-                              and nxt.stride == 1 and nxt.downsample is None and nxt.forced_spatial_mask is None
+                              and ((nxt.stride == 1 and nxt.downsample is None) or self.use_stage_carry) and nxt.forced_spatial_mask is None
                               and nxt.masker_spatial.mask_size == blk.masker_spatial.mask_size
                               and nxt.masker_spatial.mask_channel_group == 1)
             x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap, defer_stats=True, inplace=self.inplace_residual)
@@ -1133,6 +1207,8 @@ class ResNet(nn.Module):
             if stage_outs is not None and j + 1 in ends:
                 stage_outs.append(x)
         return x, stats, sizes
+
+    use_stage_carry = os.environ.get("LDN_STAGE_CARRY", "1") != "0"   # the fused masker across a stage boundary (class-level switch: A/B, tests)
 
     # ---- chained execution of a run of blocks (ldn_bottleneck_chain)
     use_chain = os.environ.get("LDN_CHAIN", "1") != "0"     # class-level switch (A/B measurements, tests): False launches every block on its own

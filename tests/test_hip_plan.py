@@ -242,6 +242,49 @@ def test_fused_spatial_masker_whole_model(ops, gran):
     assert torch.equal(outs[True][0], outs[False][0])
 
 
+@pytest.mark.parametrize("mode", ["spatial", "layer"])
+def test_fused_masker_across_projection_blocks_and_stage_boundaries(ops, mode):
+    """Round 5, late: (a) a stride-2 / projection block at the head of a stage decides from the cell means its predecessor (the last identity
+    block of the stage before) left, when the two grids coincide; (b) a projection block LEAVES cell means itself -- its projection launch
+    lists the output pixels cell by cell, so the block behind it decides without reading x either (models/utils.py:47-65 on the block INPUT).
+    Which blocks decide from means is pinned (LAUD-ResNet50 @224: every block except the one behind the stem, spatial's stage-2 head -- 14 x 14
+    cells against a 7 x 7 masker -- and the per-pixel / odd-map blocks of stage 4); decisions and logits equal the stand-alone path's."""
+    import laudnet_amd
+    from laudnet_amd import laud_resnet as LR
+    from fill import fill_state_dict
+    kw = dict(mask_spatial_granularity=[4, 4, 2, 1]) if mode == "spatial" else {}
+    m = laudnet_amd.uni_resnet50(dyn_mode=[mode] * 4, width_mult=0.5, input_size=224, num_classes=10, **kw).eval()
+    sd = fill_state_dict(m.state_dict(), 7)
+    for k in sd:
+        if k.endswith("masker_spatial.conv.bias"):
+            sd[k] = torch.zeros_like(sd[k])
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x = seeded_randn((6, 3, 224, 224), 25).to(DEV)
+    names = [f"{i + 1}.{j + 1}" for i in range(4) for j in range(len(getattr(m, f"layer{i + 1}")))]
+    blocks = [b for i in range(4) for b in getattr(m, f"layer{i + 1}")]
+    outs = {}
+    for on in (True, False):
+        LR.Bottleneck.use_fused_projection_means = on
+        LR.ResNet.use_stage_carry = on
+        try:
+            with torch.no_grad():
+                logits = m(x, 1.0)[0]
+            outs[on] = (logits.clone(), [b.last_spatial_mask.clone() for b in blocks], [n for n, b in zip(names, blocks) if b.last_fused_decision])
+        finally:
+            LR.Bottleneck.use_fused_projection_means = True
+            LR.ResNet.use_stage_carry = True
+    torch.cuda.synchronize()
+    every = set(names)
+    expect_on = every - ({"1.1", "2.1", "4.2", "4.3"} if mode == "spatial" else {"1.1", "4.2", "4.3"})
+    expect_off = every - {"1.1", "1.2", "2.1", "2.2", "3.1", "3.2", "4.1", "4.2", "4.3"}
+    assert set(outs[True][2]) == expect_on, sorted(every - set(outs[True][2]))
+    assert set(outs[False][2]) == expect_off, sorted(every - set(outs[False][2]))
+    flips = [names[i] for i, (a, b) in enumerate(zip(outs[False][1], outs[True][1])) if not torch.equal(a, b)]
+    assert not flips, f"decisions differ at blocks {flips} (a tie between the two summation orders of the pooled means?)"
+    assert torch.equal(outs[True][0], outs[False][0])
+
+
 def test_fused_spatial_masker_graph_replay(ops):
     """The fused path inside a captured hipGraph (ticket words zeroed by a kernel node, decisions and list sizes on the device): three
     replays equal the eager forward bit for bit."""

@@ -1178,7 +1178,7 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
     LDN_REQUIRE(g >= 1 && g <= 4, "ldn_spatial_masker: mask groups must be 1..4 (got %d)", g);
     LDN_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C > 0 && S > 0, "ldn_spatial_masker: bad shape");
     const bool pooled = S < Hi;
-    if (pooled && S == 1 && Hi * Wi >= 64 && C % 4 == 0) {
+    if (pooled && S == 1 && Hi * Wi >= 32 && C % 4 == 0) {       // (>= 32 pixels: 7 x 7 maps included -- one wave per image walking 49 x 2048 values took 58 us)
         // layer-skip masks (mask_size 1): the pooling window is the whole image -> two-stage deterministic GAP over
         // many workgroups (one wave per image would walk 3136 pixels serially), then one wave per image for the head
         LDN_REQUIRE(work, "ldn_spatial_masker: mask_size 1 needs the work buffer (B*splits*C floats)");

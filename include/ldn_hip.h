@@ -109,6 +109,10 @@ size_t ldn_mask_to_index_workspace_bytes(int B, int Ho, int Wo, int stride);
  * consumed by the next ldn_mask_plan / ldn_mask_to_index call whatever path it takes; never give it for a buffer the banded / two-launch build
  * (maps beyond ldn_mask_plan_fits, LDN_INDEX_PLAN=0) has used. */
 int ldn_plan_work_zeroed(int yes);
+/* Cell means on a 2S x 2S grid (pool [B][2S][2S][C], as ldn_conv_rows_pool / ldn_spatial_masker leave them) -> the means of the S x S grid of
+ * 2 x 2 groups of cells, coarse [B][S][S][C] = 0.25 * ((f00 + f01) + (f10 + f11)): for the head of a stage whose masker pools coarser cells
+ * than its predecessor wrote (models/utils.py:47-52 with a halved mask_size on the same map), in front of ldn_mask_plan's decide mode. */
+int ldn_coarsen_cell_means(const float* fine, int B, int S, int C, float* coarse, void* stream);
 
 /* ---- a1 + a4 in ONE launch (round 4): the fused spatial masker of a run of identity blocks (models/utils.py:47-65 +
  * laud_resnet.py:96-110).  The lists, counts, prefixes and statistics of ldn_mask_to_index, from

@@ -54,6 +54,7 @@ SIGNATURES = {
     "ldn_grouped16_images_fit": ([_I, _I, _I], _I),
     "ldn_grouped16_conv3x3_images": ([_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P], _I),
     "ldn_plan_work_zeroed": ([_I], _I),
+    "ldn_coarsen_cell_means": ([_P, _I, _I, _I, _P, _P], _I),
     "ldn_grouped16_images_bands": ([_I, _I, _I, _I, _I], _I),
     "ldn_grouped16_conv3x3_images_gap": ([_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], _I),
     "ldn_se_gate_slots": ([_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),

@@ -1207,6 +1207,33 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
     return LDN_OK;
 }
 
+// cell means on a 2S x 2S grid -> the means of the S x S grid of 2 x 2 groups of them (equal cells: the mean of the four means); the head of a
+// stage whose masker pools coarser cells than its predecessor's (LAUD-ResNet spatial 4-4-2-1: 7 x 7 cells of 8 x 8 pixels behind 14 x 14 of 4 x 4)
+__global__ __launch_bounds__(256) void k_coarsen_cells(const float* __restrict__ fine, int S, int C4, float* __restrict__ coarse, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long r = i / C4;
+        const int x = (int)(r % S); r /= S;
+        const int y = (int)(r % S);
+        const long b = r / S;
+        const f32x4* f = reinterpret_cast<const f32x4*>(fine) + ((b * 2 * S + 2 * y) * 2 * S + 2 * x) * C4 + c;
+        const f32x4 v = ((f[0] + f[C4]) + (f[(long)2 * S * C4] + f[(long)2 * S * C4 + C4])) * 0.25f;
+        reinterpret_cast<f32x4*>(coarse)[i] = v;
+    }
+}
+
+extern "C" int ldn_coarsen_cell_means(const float* fine, int B, int S, int C, float* coarse, void* stream) {
+    LDN_REQUIRE(fine && coarse, "ldn_coarsen_cell_means: null pointer");
+    LDN_REQUIRE(B > 0 && S > 0 && C > 0 && C % 4 == 0, "ldn_coarsen_cell_means: bad shape (C must be a multiple of 4)");
+    LDN_REQUIRE((uintptr_t)fine % 16 == 0 && (uintptr_t)coarse % 16 == 0, "ldn_coarsen_cell_means: pointers must be 16-byte aligned");
+    const long total = (long)B * S * S * (C / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_coarsen_cells, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), fine, S, C / 4, coarse, total);
+    LDN_CHECK_LAUNCH("k_coarsen_cells");
+    return LDN_OK;
+}
+
 // one launch (k_plan): patch decisions (given, or taken from pooled channel means) -> counts, prefixes, lists
 static size_t plan_lds(int S, int Sx, int Ho, int Wo, int stride) {
     return (size_t)Ho * Wo * 9 + (size_t)Ho * stride * Wo * stride * 5 + (size_t)round_up(S * Sx, 16);

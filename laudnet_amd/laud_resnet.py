@@ -757,8 +757,8 @@ class Bottleneck(_PrepCache):
             if Hi != Wi:
                 return None
             return Hi // 4 if Hi % 4 == 0 else (Hi // 2 if Hi % 2 == 0 else None)
-        if 1 < S < Hi and Hi % S == 0 and Wi % S == 0 and (Hi // S) * (Wi // S) in (4, 16) and ops.mask_plan_fits(S, S, Ho, Wo, self.stride):
-            return S
+        if 1 < S < Hi and Hi % S == 0 and Wi % S == 0 and (Hi // S) * (Wi // S) in (4, 16, 64) and ops.mask_plan_fits(S, S, Ho, Wo, self.stride):
+            return S            # (64-pixel cells: only as the 2 x 2 groups of a predecessor's 16-pixel cells, see _run_spatial)
         return None
 
     def _run_spatial(self, x, p):
@@ -782,6 +782,13 @@ class Bottleneck(_PrepCache):
         cS = pS if pS is not None else self._consume_grid(Hi, Wi, Ho, Wo)
         fresh = (cS is not None and carry_in is not None and len(carry_in) > 4 and carry_in[4] and carry_in[0] is not None
                  and tuple(carry_in[2] or ()) == (B, Hi, Wi, Cin, cS))
+        # the predecessor's cells are the quarters of this masker's (the head of stage 2 of S = 4-4-2-1: 7 x 7 cells of 8 x 8 pixels behind
+        # 14 x 14 of 4 x 4): the mean of a cell is the mean of its four quarters' means
+        coarsen = (not fresh and not layer and pS is None and cS is not None and carry_in is not None and len(carry_in) > 4 and carry_in[4]
+                   and carry_in[0] is not None and tuple(carry_in[2] or ()) == (B, Hi, Wi, Cin, 2 * cS) and Cin % 4 == 0)
+        if coarsen:
+            carry_in = (ops.coarsen_cell_means(carry_in[0].view(B, 2 * cS, 2 * cS, Cin), cS).view(-1),) + tuple(carry_in[1:])
+            fresh = True
         # (tests / bench audits) did this block's decision come from the pooled means the previous block's conv3 epilogue left?
         self.last_fused_decision = bool(fresh) and self.forced_spatial_mask is None
         if self.forced_spatial_mask is not None:
@@ -1198,7 +1205,8 @@ class ResNet(nn.Module):
                                                  and getattr(prev, "_carry_step", -1) == step_id) else None)
             blk._pool_next = (self.use_layer_carry and nxt is not None and blk.dyn_mode in ("spatial", "layer") and nxt.dyn_mode == blk.dyn_mode
                               and ((nxt.stride == 1 and nxt.downsample is None) or self.use_stage_carry) and nxt.forced_spatial_mask is None
-                              and nxt.masker_spatial.mask_size == blk.masker_spatial.mask_size
+                              and (nxt.masker_spatial.mask_size == blk.masker_spatial.mask_size
+                                   or (self.use_stage_carry and blk.masker_spatial.mask_size == 2 * nxt.masker_spatial.mask_size))
                               and nxt.masker_spatial.mask_channel_group == 1)
             x, st = blk.run_dynamic(x, gap_in=gap, want_gap=want_gap, defer_stats=True, inplace=self.inplace_residual)
             blk._carry_step = step_id if getattr(blk, "last_carry", None) is not None else -1

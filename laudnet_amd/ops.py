@@ -169,6 +169,17 @@ def _plan_path(lib, S, Sx, out_h, out_w, stride):
     return bool(lib.ldn_mask_plan_fits(int(S), int(Sx), int(out_h), int(out_w), int(stride)))
 
 
+def coarsen_cell_means(fine, S):
+    """fine [B, 2S, 2S, C] cell means -> [B, S, S, C] means of the 2 x 2 groups of cells (ldn_coarsen_cell_means)."""
+    L.require_device(fine)
+    B, S2, S2x, C = fine.shape
+    if S2 != 2 * S or S2x != 2 * S:
+        raise L.LdnError("coarsen_cell_means: fine must be [B, 2S, 2S, C]")
+    coarse = torch.empty(B, S, S, C, device=fine.device, dtype=torch.float32)
+    L.check(L.load().ldn_coarsen_cell_means(L.ptr(_f32c(fine, "fine")), B, S, C, L.ptr(coarse), L.stream_ptr()), "ldn_coarsen_cell_means")
+    return coarse
+
+
 def plan_timeouts(reset=False, raise_on_error=False):
     """Prefix waits of the one-launch list build that ran into their time bound since the last reset (ldn_plan_timeouts; 0 on a
     healthy device; such a launch leaves EMPTY lists, never uninitialised ones).  Synchronises the device."""

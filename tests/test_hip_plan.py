@@ -247,8 +247,9 @@ def test_fused_masker_across_projection_blocks_and_stage_boundaries(ops, mode):
     """Round 5, late: (a) a stride-2 / projection block at the head of a stage decides from the cell means its predecessor (the last identity
     block of the stage before) left, when the two grids coincide; (b) a projection block LEAVES cell means itself -- its projection launch
     lists the output pixels cell by cell, so the block behind it decides without reading x either (models/utils.py:47-65 on the block INPUT).
-    Which blocks decide from means is pinned (LAUD-ResNet50 @224: every block except the one behind the stem, spatial's stage-2 head -- 14 x 14
-    cells against a 7 x 7 masker -- and the per-pixel / odd-map blocks of stage 4); decisions and logits equal the stand-alone path's."""
+    Which blocks decide from means is pinned (LAUD-ResNet50 @224: every block except the one behind the stem and the per-pixel / odd-map
+    blocks of stage 4; spatial's stage-2 head averages the 2 x 2 groups of its predecessor's cells first); decisions and logits equal the
+    stand-alone path's."""
     import laudnet_amd
     from laudnet_amd import laud_resnet as LR
     from fill import fill_state_dict
@@ -276,7 +277,7 @@ def test_fused_masker_across_projection_blocks_and_stage_boundaries(ops, mode):
             LR.ResNet.use_stage_carry = True
     torch.cuda.synchronize()
     every = set(names)
-    expect_on = every - ({"1.1", "2.1", "4.2", "4.3"} if mode == "spatial" else {"1.1", "4.2", "4.3"})
+    expect_on = every - {"1.1", "4.2", "4.3"}      # (spatial 2.1: its 8 x 8-pixel cells are the 2 x 2 groups of block 1.3's -- ldn_coarsen_cell_means)
     expect_off = every - {"1.1", "1.2", "2.1", "2.2", "3.1", "3.2", "4.1", "4.2", "4.3"}
     assert set(outs[True][2]) == expect_on, sorted(every - set(outs[True][2]))
     assert set(outs[False][2]) == expect_off, sorted(every - set(outs[False][2]))

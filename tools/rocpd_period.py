@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One whole step (from a stem launch (k_stem, else the max-pool) to the next) of a rocprofv3 (rocpd sqlite) kernel trace: every kernel in start order;
-runs of kernels shorter than min_us are folded into one line (count, busy time, span).  usage: rocpd_period.py results.db [min_us]"""
+runs of kernels shorter than min_us are folded into one line (count, busy time, span).  usage: rocpd_period.py results.db [min_us] [marker kernel] [its launches per step]"""
 import sqlite3
 import sys
 
@@ -9,8 +9,14 @@ min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 15.0
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 rows = db.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
-pools = [i for i, r in enumerate(rows) if "k_stem" in r[0]] or [i for i, r in enumerate(rows) if "max_pool" in r[0]]
-a, b = pools[-2], pools[-1]
+marker = sys.argv[3] if len(sys.argv) > 3 else None          # (workloads without a stem: a kernel that runs `per` times per step, e.g. k_packed_mha 12)
+per = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+if marker:
+    pools = [i for i, r in enumerate(rows) if marker in r[0]]
+    a, b = pools[-1 - 2 * per], pools[-1 - per]
+else:
+    pools = [i for i, r in enumerate(rows) if "k_stem" in r[0]] or [i for i, r in enumerate(rows) if "max_pool" in r[0]]
+    a, b = pools[-2], pools[-1]
 rows = rows[a:b]
 t0 = rows[0][1]
 prev_end = t0

@@ -38,3 +38,16 @@ def _no_list_build_timeouts():
     except Exception:      # library not built / no device: nothing to check
         return
     assert n == 0, f"{n} list-build launches ran into their time bound during this session"
+    # ... and, when the session ran on the LDN_DEBUG build (LDN_LIB_PATH=laudnet_amd/libldn_hip_debug.so pytest -m gpu), no device-side index audit
+    # may have counted a violation (the release build reports -1: checks compiled away).  tests/test_hip_debug.py corrupts a list on purpose in
+    # its own subprocess; deselect it for such a session.
+    try:
+        import ctypes
+        from laudnet_amd import _lib
+        lib = _lib.load()
+        c, code = ctypes.c_int(0), ctypes.c_int(0)
+        if lib.ldn_debug_violations(ctypes.byref(c), ctypes.byref(code), 0) != 0:
+            return
+    except Exception:
+        return
+    assert c.value <= 0, f"{c.value} device-side index-audit violations during this session (first code {code.value})"

@@ -1,0 +1,808 @@
+// k_chain_ld -- the chained stage kernel (k_chain, csrc/ldn_tail.hip) re-decomposed as a LOADER / CONSUMER pipeline (round 6).
+//
+// What round 5's traces said about k_chain: every phase of a block runs at 2-3 x its matrix time because all eight waves walk the same
+// barrier-to-barrier chain per K chunk -- wait for the chunk's LDS-DMA, s_barrier, issue the next chunk's DMA (index look-ups, address arithmetic,
+// M0 set-ups), read fragments, multiply -- so the two waves of a SIMD multiply together and then idle the matrix pipe together.  A 14 x 14 map is 196
+// pixels = seven 32-pixel wave tiles: the EIGHTH wave of the workgroup has no pixels.  Here it becomes the workgroup's loader:
+//   * wave 7 issues ALL LDS-DMA of the operands the waves share (the image's gathered W1 rows, W2 tiles, h1 slices, W3 chunks) into rings of 3-4
+//     slots, from per-lane source offsets it computes once per block / K slice, and publishes "chunks landed" in an LDS word behind its own vmcnt;
+//   * waves 0-6 (the consumers) never issue a shared DMA, never look an index up and never meet a workgroup barrier inside a phase: they poll the
+//     landed word (normally already ahead), multiply, and post their own progress word, which the loader polls before it refills a slot.  Nothing
+//     re-synchronises the two waves of a SIMD chunk by chunk, so they drift out of phase and one wave's fragment reads / epilogue run under the
+//     other's MFMAs;
+//   * conv1's activation rows stay private to the wave that owns the pixels (its own DMA, its own vmcnt, ring of 2-3 K32 steps: DESIGN.md 4u).
+// Same products in the same order per accumulator as head_body / tail_body: results are bit-identical to k_chain and to the block-by-block kernels
+// (tests/test_hip_chain.py).  Every spin is bounded: a wait that runs into its bound is counted (ldn_plan_timeouts) and poisons nothing but the
+// values -- the launch always terminates.
+//
+// Included by ldn_tail.hip behind head_body / tail_body (their DMA / fragment helpers are used as they are).
+#pragma once
+
+namespace ldn {
+
+constexpr int LD_SYNC_OFF = T_KIDX_BYTES;         // the sync words live behind the channel list in every phase
+constexpr int LD_SYNC_BYTES = 256;
+constexpr int LD_LOADER = 7;                      // the wave without pixels
+constexpr int LD_SPIN_LIMIT = 1 << 20;            // polls (each >= ~150 cycles with its s_sleep): ~0.1 s
+
+__device__ unsigned g_ld_stalls = 0u;             // hand-off waits that ran into LD_SPIN_LIMIT since the last reset
+#ifdef LDN_TRACE   // tuning only (tools/trace_chain.py): [B][8 waves][8] cycles summed over the run -- consumers: conv1 loop, conv1 epilogue, conv2 loop,
+                   // table build + conversion, conv3 loop, waits for the loader (all phases); loader: the three streams, waits for the consumers
+__device__ unsigned long long* g_ld_trace = nullptr;
+#define LT(x) x = __builtin_amdgcn_s_memtime();
+#define LD_TIMED(slot, stmt) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); stmt; q.t[slot] += __builtin_amdgcn_s_memtime() - t0_; }
+#define LD_SPAN(slot, a, b) q.t[slot] += (b) - (a);
+#else
+#define LT(x)
+#define LD_TIMED(slot, stmt) { stmt; }
+#define LD_SPAN(slot, a, b)
+#endif
+
+struct LdSync {                                   // LDS, 256 bytes
+    unsigned landed;                              // chunks (sequence numbers < landed) whose LDS-DMA has landed; written by the loader only
+    unsigned pad0[15];
+    unsigned done[16];                            // done[w] = sequence number + 1 of the last chunk consumer wave w has finished READING
+    unsigned pad1[32];
+};
+static_assert(sizeof(LdSync) == LD_SYNC_BYTES, "LdSync layout");
+
+// per-wave state of the hand-off protocol (wave-uniform)
+struct LdSeq {
+    unsigned base;                                // sequence number of the next phase's first chunk (same arithmetic in every wave)
+    unsigned seen;                                // consumers: the last value of sync->landed this wave has read
+#ifdef LDN_TRACE
+    unsigned long long t[8];
+#endif
+};
+
+// ds_read_b32 of a sync word with its wait in ONE statement (hipcc neither counts nor waits for an asm load: cdna_hip_programming.md 5.7)
+__device__ __forceinline__ unsigned ld_lds_read(const unsigned* p) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_off(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld_lds_write(unsigned* p, unsigned v) {
+    asm volatile("ds_write_b32 %0, %1\n\ts_nop 0" ::"v"(lds_off(p)), "v"(v) : "memory");
+}
+
+// consumer: chunk `need - 1` has landed (LDS is one in-order memory: the loader's ds_write of the word sits behind its covering vmcnt, this wave's
+// fragment reads sit behind its read of the word)
+__device__ __forceinline__ void ld_wait_landed(LdSync* sy, unsigned need, unsigned& seen) {
+    if (seen >= need) return;
+    for (int spin = 0;; ++spin) {
+        seen = __builtin_amdgcn_readfirstlane(ld_lds_read(&sy->landed));
+        if (seen >= need) break;
+        if (spin >= LD_SPIN_LIMIT) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&g_ld_stalls, 1u);
+            seen = 0x7fffffffu;                   // sticky: this wave stops waiting (values are lost, the launch terminates)
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+// consumer: every read of chunk seq's slot has been ISSUED (LDS executes a wave's operations in order: the word becomes visible behind them)
+__device__ __forceinline__ void ld_post_done(LdSync* sy, int wave, unsigned seq_plus_1) {
+    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) ld_lds_write(&sy->done[wave], seq_plus_1);
+    asm volatile("" ::: "memory");
+}
+// loader: every consumer wave has finished chunk need - 1
+__device__ __forceinline__ void ld_wait_done(LdSync* sy, int ncomp, unsigned need, bool& dead) {
+    if (dead) return;
+    const int lane = threadIdx.x & 63;
+    for (int spin = 0;; ++spin) {
+        const unsigned v = ld_lds_read(&sy->done[lane & 15]);
+        if (__ballot(lane < ncomp && v < need) == 0ull) break;
+        if (spin >= LD_SPIN_LIMIT) {
+            if (lane == 0) atomicAdd(&g_ld_stalls, 1u);
+            dead = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+__device__ __forceinline__ void ld_publish(LdSync* sy, unsigned landed) {
+    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) ld_lds_write(&sy->landed, landed);
+    asm volatile("" ::: "memory");
+}
+
+// counted wait with a run-time, wave-uniform count (0 .. 63: the counter has six bits)
+__device__ __forceinline__ void wait_vm_rt63(int n) {
+#define LDN_WV(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        LDN_WV(0) LDN_WV(1) LDN_WV(2) LDN_WV(3) LDN_WV(4) LDN_WV(5) LDN_WV(6) LDN_WV(7) LDN_WV(8) LDN_WV(9) LDN_WV(10) LDN_WV(11) LDN_WV(12)
+        LDN_WV(13) LDN_WV(14) LDN_WV(15) LDN_WV(16) LDN_WV(17) LDN_WV(18) LDN_WV(19) LDN_WV(20) LDN_WV(21) LDN_WV(22) LDN_WV(23) LDN_WV(24)
+        LDN_WV(25) LDN_WV(26) LDN_WV(27) LDN_WV(28) LDN_WV(29) LDN_WV(30) LDN_WV(31) LDN_WV(32) LDN_WV(33) LDN_WV(34) LDN_WV(35) LDN_WV(36)
+        LDN_WV(37) LDN_WV(38) LDN_WV(39) LDN_WV(40) LDN_WV(41) LDN_WV(42) LDN_WV(43) LDN_WV(44) LDN_WV(45) LDN_WV(46) LDN_WV(47) LDN_WV(48)
+        LDN_WV(49) LDN_WV(50) LDN_WV(51) LDN_WV(52) LDN_WV(53) LDN_WV(54) LDN_WV(55) LDN_WV(56) LDN_WV(57) LDN_WV(58) LDN_WV(59) LDN_WV(60)
+        LDN_WV(61) LDN_WV(62)
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+#undef LDN_WV
+}
+
+// One LDS-DMA piece (1 KB: 16 bytes per lane) from sbase (wave-uniform) + vo (per-lane byte offset) to LDS lds_base + lane * 16.
+__device__ __forceinline__ void ld_dma1(unsigned vo, const void* sbase, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(sbase), "s"(lds_base) : "memory");
+}
+// n (wave-uniform, a multiple of 4, <= MAXP) consecutive 1 KB pieces of a slot: piece i from sbase + vo[i] to lds_base + i * 1024.  Groups of four
+// share one M0 set-up (dma16_pieces: the instruction offset moves source AND destination, so vo[i] carries the bias (3 - i % 4) * 1024 against
+// sbase - 3072: ld_bias()).  All indices are compile-time: the offsets stay in registers.
+__device__ __forceinline__ unsigned ld_bias(int i) { return (unsigned)(3 - (i & 3)) * 1024u; }
+template <int MAXP>
+__device__ __forceinline__ void ld_dma_run(const unsigned (&vo)[MAXP], int n, const unsigned char* sbase, unsigned lds_base) {
+    const void* sb = uniform_cptr(sbase - 3072);
+#pragma unroll
+    for (int g = 0; g < MAXP / 4; ++g) {
+        if (4 * g >= n) break;
+        const unsigned v4[4] = {vo[4 * g], vo[4 * g + 1], vo[4 * g + 2], vo[4 * g + 3]};
+        dma16_pieces<4>(v4, sb, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)g * 4096u)));
+    }
+}
+
+// ================================================================================================================ conv1
+// head_ld: conv1 of block i on the loader / consumer structure.  LDS: [channel list 1280 | sync 256 | sc1 sh1 ps1 3 W floats | weight ring RW x
+// (8 ceil(Nb / 8) rows x 128 B) | x rings: consumer wave w owns DX x 4 KB].  A weight slot holds the image's gathered rows of one K32 chunk in list
+// order (row n at n * 128, 16-byte units XOR-swizzled by (n >> 1) & 7 on the source side); an x slot the wave's 32 pixels of the chunk.
+template <int NS>
+__device__ __forceinline__ void head_ld(const HeadArgs& p, const int b, unsigned char* const smem, const int lds_total, const int tid, LdSeq& q) {
+    constexpr int W = NS * 32;
+    constexpr int MAXP = NS * 4;                                          // weight pieces of a chunk when the image keeps every channel
+    int* const s_nidx = reinterpret_cast<int*>(smem);                    // [W + 32]
+    LdSync* const sy = reinterpret_cast<LdSync*>(smem + LD_SYNC_OFF);
+    float* const s_tab = reinterpret_cast<float*>(smem + LD_SYNC_OFF + LD_SYNC_BYTES);
+    unsigned char* const s_ring = smem + LD_SYNC_OFF + LD_SYNC_BYTES + 3 * W * 4;
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int npix = p.HW;                                                // whole image (<= 224 pixels)
+    const long row0 = (long)b * p.HW;
+    const int ncomp = ceil_div(npix, 32);
+
+    const int Nb = min(p.n_cnt[b], W);
+    const int nsub = __builtin_amdgcn_readfirstlane(ceil_div(Nb, 32));
+    const int nwp = __builtin_amdgcn_readfirstlane(4 * max(nsub, 1));             // weight pieces (8 rows each) per chunk: whole n-subtiles, rows beyond the list re-read its last channel
+    const int wslot = nwp * 1024;
+    if (tid < W + 32) s_nidx[tid] = tid < Nb ? p.n_idx[(size_t)b * W + tid] : -1;
+    if (tid < LD_SYNC_BYTES / 4) reinterpret_cast<unsigned*>(sy)[tid] = 0u;       // the block's sequence numbers start at 0
+    __syncthreads();
+    for (int i = tid; i < 3 * W; i += 512) {
+        const int k = i / W, n = i - k * W;
+        const int ch = s_nidx[n];
+        const float* src = k == 0 ? p.sc1 : (k == 1 ? p.sh1 : p.ps1);
+        s_tab[i] = ch >= 0 ? src[ch] : 0.f;
+    }
+    // ring depths: three x steps per wave where the weight ring still gets three slots, else two; weight ring 2..4 slots
+    const int avail = lds_total - (LD_SYNC_OFF + LD_SYNC_BYTES + 3 * W * 4);
+    int DX = 3;
+    if ((avail - ncomp * DX * 4096) / wslot < 3) DX = 2;
+    DX = __builtin_amdgcn_readfirstlane(DX);
+    const int RW = __builtin_amdgcn_readfirstlane(min(4, (avail - ncomp * DX * 4096) / wslot));      // >= 2 for W <= 256 (ldn_bottleneck_chain_fits)
+    unsigned char* const s_x = s_ring + RW * wslot;
+    const int nchunks = p.cin / 32;
+    const unsigned base = q.base;
+    q.base = base + (unsigned)nchunks;
+#ifdef LDN_TRACE
+    unsigned long long ta, tb, tc;
+    LT(ta)
+#endif
+
+    if (wave == LD_LOADER) {
+        // ---- loader: per-lane source offsets of the image's weight pieces (fixed for the block), then the stream
+        unsigned wo[MAXP];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int rw = 8 * i + (lane >> 3);
+            const int ch = s_nidx[min(rw, max(Nb, 1) - 1)];                // rows beyond the list re-read its last channel (zero epilogue tables)
+            wo[i] = (unsigned)(max(ch, 0) * p.cin * 4 + (((lane & 7) ^ ((rw >> 1) & 7)) << 4)) + ld_bias(i);
+        }
+        const unsigned lds_w = lds_off(s_ring);
+        bool dead = false;
+        int slot = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            if (c >= RW) LD_TIMED(5, ld_wait_done(sy, ncomp, base + (unsigned)(c - RW + 1), dead))
+            ld_dma_run<MAXP>(wo, nwp, p.w1s + (long)c * 128, lds_w + (unsigned)slot * (unsigned)wslot);
+            slot = slot + 1 == RW ? 0 : slot + 1;
+            if (c > 0) { wait_vm_rt63(nwp); ld_publish(sy, base + (unsigned)c); }      // chunks < c have landed
+        }
+        wait_vm_n<0>();
+        ld_publish(sy, base + (unsigned)nchunks);
+        LT(tb)
+        LD_SPAN(0, ta, tb)
+        return;
+    }
+    if (wave >= ncomp) return;
+
+    // ---- consumer
+    const unsigned lds_x = lds_off(s_x) + (unsigned)wave * (unsigned)(DX * 4096);
+    unsigned char* const my_x = s_x + wave * DX * 4096;
+    unsigned xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rl = 8 * i + (lane >> 3);                                // row of the wave's tile
+        const int r = wave * 32 + rl;
+        xo[i] = (unsigned)((min(r, npix - 1) * p.ldx) * 4 + (((lane & 7) ^ ((rl >> 1) & 7)) << 4)) + ld_bias(i);
+    }
+    const unsigned char* const xbase = reinterpret_cast<const unsigned char*>(p.x + row0 * p.ldx) - 3072;
+    auto dma_x = [&](int c, int xs) {      // chunk c (beyond the K range: the last one again -- keeps the counted wait's arithmetic constant) into x slot xs
+        const int cc = min(c, nchunks - 1);
+        dma16_pieces<4>(xo, uniform_cptr(xbase + (long)cc * 128), (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_x + (unsigned)xs * 4096u)));
+    };
+
+    f32x16 acc[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    for (int c = 0; c < DX - 1; ++c) dma_x(c, c);
+    const unsigned xsw = ((unsigned)l31 >> 1) & 7u;
+    bf16x8 bh[2], bl[2];
+    int xs = 0, ws_i = 0;                   // x slot / weight slot of chunk c
+    for (int c = 0; c < nchunks; ++c) {
+        wait_vm_rt(4 * (DX - 2));           // this wave's x rows of chunk c have landed
+        {   // B operands of both K16 steps (the wave's 32 pixels), split once for all of the image's n-subtiles
+            const unsigned char* xsl = my_x + xs * 4096 + l31 * 128;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const unsigned sl = 4u * half + 2u * h;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xsl + ((sl ^ xsw) << 4));
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xsl + (((sl + 1) ^ xsw) << 4));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = e < 4 ? x0[e] : x1[e - 4];
+                    const __bf16 hb = (__bf16)v;
+                    bh[half][e] = hb;
+                    bl[half][e] = (__bf16)(v - (float)hb);
+                }
+            }
+        }
+        // the x slot of chunk c - 1 (read and split one iteration ago) takes chunk c + DX - 1
+        dma_x(c + DX - 1, xs == 0 ? DX - 1 : xs - 1);
+        LD_TIMED(5, ld_wait_landed(sy, base + (unsigned)c + 1u, q.seen))
+        const unsigned char* ws = s_ring + ws_i * wslot + l31 * 128;
+        // n-subtiles in DESCENDING order, software-pipelined as in head_body (weight fragment = two ds_read_b128, double-buffered in a0 / a1)
+        bf16x8 a0h, a0l, a1h, a1l;
+        const unsigned sl0 = 2u * h, sl1 = 4u + 2u * h;
+        auto frag0 = [&](int j) {
+            a0h = *reinterpret_cast<const bf16x8*>(ws + j * 4096 + ((sl0 ^ xsw) << 4));
+            a0l = *reinterpret_cast<const bf16x8*>(ws + j * 4096 + (((sl0 + 1) ^ xsw) << 4));
+        };
+        auto frag1 = [&](int j) {
+            a1h = *reinterpret_cast<const bf16x8*>(ws + j * 4096 + ((sl1 ^ xsw) << 4));
+            a1l = *reinterpret_cast<const bf16x8*>(ws + j * 4096 + (((sl1 + 1) ^ xsw) << 4));
+        };
+#define LDN_HEADLD_STEP(J)                                                                                \
+        frag1(J);                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        LDN_K16(false, acc[J], a0h, a0l, bh[0], bl[0])                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        if (J > 0) frag0(J > 0 ? J - 1 : 0);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        LDN_K16(false, acc[J], a1h, a1l, bh[1], bl[1])                                                    \
+        __builtin_amdgcn_sched_barrier(0);
+        if (nsub > 0) {
+            frag0(nsub - 1);
+            switch (nsub) {
+                default:
+                    if constexpr (NS >= 8) { LDN_HEADLD_STEP(7) }
+                    [[fallthrough]];
+                case 7:
+                    if constexpr (NS >= 8) { LDN_HEADLD_STEP(6) }
+                    [[fallthrough]];
+                case 6:
+                    if constexpr (NS >= 8) { LDN_HEADLD_STEP(5) }
+                    [[fallthrough]];
+                case 5:
+                    if constexpr (NS >= 8) { LDN_HEADLD_STEP(4) }
+                    [[fallthrough]];
+                case 4:
+                    if constexpr (NS >= 4) { LDN_HEADLD_STEP(3) }
+                    [[fallthrough]];
+                case 3:
+                    if constexpr (NS >= 4) { LDN_HEADLD_STEP(2) }
+                    [[fallthrough]];
+                case 2:
+                    LDN_HEADLD_STEP(1)
+                    [[fallthrough]];
+                case 1:
+                    LDN_HEADLD_STEP(0)
+            }
+        }
+#undef LDN_HEADLD_STEP
+        ld_post_done(sy, wave, base + (unsigned)c + 1u);
+        xs = xs + 1 == DX ? 0 : xs + 1;
+        ws_i = ws_i + 1 == RW ? 0 : ws_i + 1;
+    }
+    wait_vm_n<0>();      // no LDS-DMA of this wave may be in flight when the phase's LDS is handed on
+    LT(tb)
+    LD_SPAN(0, ta, tb)
+
+    // ---- epilogue (as head_body): bn1 + ReLU - c1, split, pair the half-waves, 16-byte stores of [8 hi] (lanes 0-31) / [8 lo] (lanes 32-63)
+    const int pm = wave * 32 + l31;
+    unsigned char* orow = p.h1 + (row0 + min(pm, npix - 1)) * p.h1_row_bytes;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        if (j >= nsub) continue;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int n0 = 32 * j + 8 * q4 + 4 * h;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_tab + n0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(s_tab + W + n0);
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(s_tab + 2 * W + n0);
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            unsigned hi2[2], lo2[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float v0 = fmaxf(acc[j][4 * q4 + 2 * d] * sc[2 * d] + sh[2 * d], 0.f) - ps[2 * d];
+                const float v1 = fmaxf(acc[j][4 * q4 + 2 * d + 1] * sc[2 * d + 1] + sh[2 * d + 1], 0.f) - ps[2 * d + 1];
+                const bf16x2 hh = {(__bf16)v0, (__bf16)v1};
+                const bf16x2 ll = {(__bf16)(v0 - (float)hh[0]), (__bf16)(v1 - (float)hh[1])};
+                hi2[d] = __builtin_bit_cast(unsigned, hh);
+                lo2[d] = __builtin_bit_cast(unsigned, ll);
+            }
+            u32x4 outv;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const auto r = __builtin_amdgcn_permlane32_swap(hi2[d], lo2[d], false, false);
+                outv[d] = r[0];
+                outv[2 + d] = r[1];
+            }
+            if (pm < npix) *reinterpret_cast<u32x4*>(orow + (4 * j + q4) * 32 + h * 16) = outv;
+        }
+    }
+    LT(tc)
+    LD_SPAN(1, tb, tc)
+}
+
+// ================================================================================================================ conv2 -> conv3
+// tail_ld: the fused tail (stride 1, whole image per workgroup) on the loader / consumer structure.
+// conv2 LDS: [channel list | sync | h1 slices 2 x slice_bytes | W2 ring R2 x (16 k-pair rows x Kp * 8 B)] -- a W2 slot is DENSE (row length = the
+//            image's Kp / 2 channel pairs x 16 B instead of the layer's W / 2): 20 DMA pieces per chunk at Kp = 160 instead of 32, four slots
+//            instead of three.
+// conv3 LDS: [channel list | sync | W3 ring R3 x (Kp / 2 k-pair rows x 32 channels x 8 B) | ... | conversion tables 18 W floats | 7 x 4 KB transpose
+//            scratch] (tables and scratch at the top of the workgroup's LDS).
+constexpr int LD_CW = 32;                         // output channels per conv3 chunk
+template <int NS>
+__device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned char* const smem, const int lds_total, const int tid, LdSeq& q) {
+    constexpr int W = NS * 32;
+    constexpr int MAXP = NS * 4;                      // pieces of a W2 / W3 chunk when the image keeps every channel (Kp / 8)
+    constexpr int MAXH = 28;                          // pieces of an h1 slice (<= 224 pixels, 8 per piece)
+    constexpr int NP = W;
+    constexpr int W3_ROW = LD_CW * 8;
+    int* const s_kidx = reinterpret_cast<int*>(smem);
+    LdSync* const sy = reinterpret_cast<LdSync*>(smem + LD_SYNC_OFF);
+    unsigned char* const s_lo = smem + LD_SYNC_OFF + LD_SYNC_BYTES;
+    unsigned char* const s_h1 = s_lo;                                     // conv2: 2 slice slots ...
+    unsigned char* const s_w2 = s_h1 + 2 * p.slice_bytes;                 // ... and the W2 ring
+    unsigned char* const s_w3 = s_lo;                                     // conv3: the W3 ring ...
+    unsigned char* const s_scr = smem + lds_total - 7 * 4096;             // ... the transpose scratch and the conversion tables at the top
+    float* const s_tab = reinterpret_cast<float*>(s_scr - 18 * NP * 4);
+
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int l31 = lane & 31, h = lane >> 5;
+    const int npix = p.Ho * p.Wo;                                         // stride 1, whole image: <= 224
+    const int ncomp = ceil_div(npix, 32);
+    const int NR = npix, NRp = round_up(NR, 8);
+    const int ZR = NRp;
+    const long pix0 = (long)b * npix;
+
+    const int Kb = min(p.k_cnt[b], W);
+    const int nsub = __builtin_amdgcn_readfirstlane(ceil_div(Kb, 32));
+    const int Kp = nsub * 32;
+    const int P2 = __builtin_amdgcn_readfirstlane(Kp / 8);                // DMA pieces of a W2 chunk == of a W3 chunk
+    const int slot2 = Kp * 128, slot3 = Kp * 128;
+    if (tid < W + 32) s_kidx[tid] = tid < Kb ? p.k_idx[(size_t)b * W + tid] : -1;
+    if (tid < 64) reinterpret_cast<float*>(s_h1 + (tid >> 5) * p.slice_bytes + ZR * 128)[tid & 31] = 0.f;      // the slices' zero rows
+    __syncthreads();
+
+    const int avail2 = lds_total - (LD_SYNC_OFF + LD_SYNC_BYTES) - 2 * p.slice_bytes;
+    const int R2 = __builtin_amdgcn_readfirstlane(nsub > 0 ? min(4, avail2 / slot2) : 4);          // >= 3 for a 224-pixel map of width 256
+    const int avail3 = lds_total - (LD_SYNC_OFF + LD_SYNC_BYTES) - 18 * NP * 4 - 7 * 4096;
+    const int R3 = __builtin_amdgcn_readfirstlane(nsub > 0 ? min(4, avail3 / slot3) : 4);
+    const int nchunks = nsub * 9;
+    const int nchunk3 = p.cout / LD_CW;
+    const int nq = NRp / 8;
+    const unsigned base2 = q.base, base3 = base2 + (unsigned)nchunks;
+    q.base = base3 + (unsigned)nchunk3;
+    constexpr int TMIN = 3;                           // the pieces of slice s + 1 go out with taps TMIN .. 8 of slice s (every reader has left slice s - 1 by then: R2 <= 4)
+    static_assert(TMIN == 3 && MAXH == 28, "the slice schedule below is written out for taps 3 .. 8 and <= 28 pieces");
+
+    const bool loader = wave == LD_LOADER;
+    const bool consumer = wave < ncomp;
+#ifdef LDN_TRACE
+    unsigned long long ta, tb, tc, td;
+    LT(ta)
+#endif
+    unsigned w3o[MAXP];                               // loader: per-lane source offsets of the W3 pieces (set behind conv2)
+    bool dead = false;
+
+    // ======================================================================================================== conv2 (3x3)
+    f32x16 acc[NS];
+    if (loader) {
+        unsigned ho[MAXH];                            // h1 slice piece i: rows 8 i + (lane >> 3), physical 16-byte slot lane & 7
+#pragma unroll
+        for (int i = 0; i < MAXH; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            ho[i] = (unsigned)(min(r, NR - 1) * (int)p.h1_row_bytes + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+        }
+        // W2 piece i covers bytes [1024 i, 1024 i + 1024) of the dense slot: k-pair row u = e / (Kp / 2), packed n-pair v = e % (Kp / 2), e = 64 i + lane
+        unsigned un[MAXP];                            // u of the lane's piece-i element
+        unsigned no[MAXP];                            // its n-pair's source offset (+ the group bias)
+        const int hp = max(Kp / 2, 1);
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int e = 64 * i + lane;
+            const int u = min(e / hp, 15), v = e - (e / hp) * hp;
+            const int ch = 2 * v < Kb ? s_kidx[2 * v] : 0;               // columns beyond the list fetch pair 0 (their accumulator columns meet zero tables)
+            un[i] = (unsigned)u;
+            no[i] = (unsigned)((ch >> 1) * 16) + ld_bias(i);
+        }
+        const unsigned lds_h1 = lds_off(s_h1), lds_w2 = lds_off(s_w2);
+        const unsigned char* const h1b = p.h1 + pix0 * p.h1_row_bytes;
+        if (nchunks > 0) {
+#pragma unroll
+            for (int i = 0; i < MAXH; ++i)
+                if (i < nq) ld_dma1(ho[i], uniform_cptr(h1b), (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_h1 + (unsigned)i * 1024u)));      // slice 0 -> slot 0
+        }
+        int slot = 0;
+        for (int s = 0; s < nsub; ++s) {
+            unsigned vo[MAXP];                        // this slice's pieces: k-pair rows through the channel list (rows beyond it meet zero h1 columns)
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int kch = s_kidx[32 * s + 2 * (int)un[i]];
+                vo[i] = (unsigned)((max(kch, 0) >> 1) * (W / 2) * 16) + no[i];
+            }
+            const unsigned char* const hsrc = h1b + (long)(s + 1) * 128;
+            const unsigned hdst = lds_h1 + (unsigned)((s + 1) & 1) * (unsigned)p.slice_bytes;
+            const bool more = s + 1 < nsub;
+            for (int t = 0; t < 9; ++t) {             // (a run-time loop: the loader's code stays small)
+                const int c = 9 * s + t;
+                if (c >= R2) LD_TIMED(5, ld_wait_done(sy, ncomp, base2 + (unsigned)(c - R2 + 1), dead))
+                ld_dma_run<MAXP>(vo, P2, p.w2p + (long)t * ((W / 2) * (W / 2) * 16), lds_w2 + (unsigned)slot * (unsigned)slot2);
+                slot = slot + 1 == R2 ? 0 : slot + 1;
+                int pieces = P2;
+                if (t >= TMIN && more) {
+                    const void* hsb = uniform_cptr(hsrc);
+#define LDN_LD_H1(I) if ((I) < nq) { ld_dma1(ho[(I)], hsb, (unsigned)__builtin_amdgcn_readfirstlane((int)(hdst + (unsigned)(I) * 1024u))); ++pieces; }
+                    switch (t) {      // piece i goes out with tap TMIN + i % NT
+                        case 3: LDN_LD_H1(0) LDN_LD_H1(6) LDN_LD_H1(12) LDN_LD_H1(18) LDN_LD_H1(24) break;
+                        case 4: LDN_LD_H1(1) LDN_LD_H1(7) LDN_LD_H1(13) LDN_LD_H1(19) LDN_LD_H1(25) break;
+                        case 5: LDN_LD_H1(2) LDN_LD_H1(8) LDN_LD_H1(14) LDN_LD_H1(20) LDN_LD_H1(26) break;
+                        case 6: LDN_LD_H1(3) LDN_LD_H1(9) LDN_LD_H1(15) LDN_LD_H1(21) LDN_LD_H1(27) break;
+                        case 7: LDN_LD_H1(4) LDN_LD_H1(10) LDN_LD_H1(16) LDN_LD_H1(22) break;
+                        default: LDN_LD_H1(5) LDN_LD_H1(11) LDN_LD_H1(17) LDN_LD_H1(23) break;
+                    }
+#undef LDN_LD_H1
+                }
+                if (c > 0) { wait_vm_rt63(pieces); ld_publish(sy, base2 + (unsigned)c); }      // chunks < c (and every slice piece issued with them) have landed
+            }
+        }
+        wait_vm_n<0>();
+        ld_publish(sy, base2 + (unsigned)nchunks);
+    }
+
+    // ---- consumers: this lane's output pixel and its nine tap rows in a slice (ZR = zero row); border class for the shift table
+    const int pm = wave * 32 + l31;
+    const bool pvalid = pm < npix;
+    const int oy = pm / p.Wo, ox = pm % p.Wo;
+    const int cls = (((oy - 1 < 0) | ((oy + 1 >= p.Hi) << 1)) * 4 + ((ox - 1 < 0) | ((ox + 1 >= p.Wi) << 1)));
+    if (consumer) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        int trow[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+            const bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            trow[t] = ok ? iy * p.Wi + ix : ZR;
+        }
+        // A (weights): k-pair rows 4 h + q (K16 half 0) / 4 h + 8 + q (half 1) of the dense slot, entry l31 of n-subtile j at + j * 256
+        const unsigned RL = (unsigned)Kp * 8u;
+        unsigned arow[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) arow[i] = (unsigned)(4 * h + (i & 3) + 8 * (i >> 2)) * RL + (unsigned)l31 * 8u;
+        int slot = 0;
+        for (int s = 0; s < nsub; ++s) {
+            const unsigned char* hs = s_h1 + (s & 1) * p.slice_bytes;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int c = 9 * s + t;
+                LD_TIMED(5, ld_wait_landed(sy, base2 + (unsigned)c + 1u, q.seen))
+                const unsigned char* ws = s_w2 + slot * slot2;
+                slot = slot + 1 == R2 ? 0 : slot + 1;
+                {
+                    const unsigned rbase = (unsigned)trow[t] * 128u, rx = ((unsigned)trow[t] >> 1) & 7u;
+                    bf16x8 bh[2], bl[2];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const unsigned sl = 2u * (2u * half + h);
+                        bh[half] = *reinterpret_cast<const bf16x8*>(hs + rbase + ((sl ^ rx) << 4));
+                        bl[half] = *reinterpret_cast<const bf16x8*>(hs + rbase + (((sl + 1) ^ rx) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) {
+                        if (j < nsub) {
+                            u32x2 e0[4], e1[4];
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) e0[qq] = *reinterpret_cast<const u32x2*>(ws + arow[qq] + j * 256);
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) e1[qq] = *reinterpret_cast<const u32x2*>(ws + arow[4 + qq] + j * 256);
+                            {
+                                const u32x4 ahu = {e0[0][0], e0[1][0], e0[2][0], e0[3][0]};
+                                const u32x4 alu = {e0[0][1], e0[1][1], e0[2][1], e0[3][1]};
+                                const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
+                                LDN_K16(false, acc[j], ah, al, bh[0], bl[0])
+                            }
+                            {
+                                const u32x4 ahu = {e1[0][0], e1[1][0], e1[2][0], e1[3][0]};
+                                const u32x4 alu = {e1[0][1], e1[1][1], e1[2][1], e1[3][1]};
+                                const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
+                                LDN_K16(false, acc[j], ah, al, bh[1], bl[1])
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                        }
+                    }
+                }
+                ld_post_done(sy, wave, base2 + (unsigned)c + 1u);
+            }
+        }
+    }
+    LT(tb)
+    LD_SPAN(2, ta, tb)
+    __syncthreads();       // every wave is out of conv2: the slice / W2 regions are free
+    // (as in tail_body: the lane index behind an optimisation barrier, or hipcc keeps the conv3 phase's per-lane addresses alive through conv2)
+    asm volatile("" : "+v"(lane));
+    l31 = lane & 31;
+    h = lane >> 5;
+
+    // ======================================================================================================== conv3 (1x1)
+    const unsigned lds_w3 = lds_off(s_w3);
+    if (loader) {
+        // W3 piece i = k-pair rows 4 i .. 4 i + 3 (256 B each: 32 channels x 8 B): lane = (row 4 i + lane / 16, channel pair lane % 16)
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int u = 4 * i + (lane >> 4);
+            const int kch = 2 * u < Kp ? s_kidx[2 * u] : -1;              // rows beyond the list meet zero h2 values
+            w3o[i] = (unsigned)(((long)(max(kch, 0) >> 1) * p.cout + 2 * (lane & 15)) * 8) + ld_bias(i);
+        }
+        if (nchunk3 > 0 && nsub > 0) ld_dma_run<MAXP>(w3o, P2, p.w3p, lds_w3);      // chunk 0 flies through the table build
+    } else {
+        // conversion tables (gathered through the channel list) by the seven other waves
+        const int t7 = tid;                                               // threads 0 .. 447
+        for (int i = t7; i < NP; i += 448) {
+            const int ch = i < Kb ? s_kidx[i] : -1;
+            s_tab[i] = ch >= 0 ? p.sc2[ch] : 0.f;
+            s_tab[NP + i] = ch >= 0 ? p.ps2[ch] : 0.f;
+        }
+        for (int i = t7; i < 16 * NP; i += 448) {
+            const int k = i / NP, n = i - k * NP;
+            const int ch = n < Kb ? s_kidx[n] : -1;
+            s_tab[2 * NP + i] = ch >= 0 ? p.sh2[k * W + ch] : 0.f;
+        }
+    }
+    __syncthreads();       // the tables are in LDS
+
+    if (loader) {
+        if (nsub > 0) {
+            int slot = 1 == R3 ? 0 : 1;
+            for (int cc = 1; cc < nchunk3; ++cc) {
+                if (cc >= R3) LD_TIMED(5, ld_wait_done(sy, ncomp, base3 + (unsigned)(cc - R3 + 1), dead))
+                ld_dma_run<MAXP>(w3o, P2, p.w3p + (long)cc * (LD_CW * 8), lds_w3 + (unsigned)slot * (unsigned)slot3);
+                slot = slot + 1 == R3 ? 0 : slot + 1;
+                wait_vm_rt63(P2);
+                ld_publish(sy, base3 + (unsigned)cc);
+            }
+            wait_vm_n<0>();
+        }
+        ld_publish(sy, base3 + (unsigned)nchunk3);
+        LT(tc)
+        LD_SPAN(4, tb, tc)
+        return;
+    }
+    if (!consumer) return;
+
+    // In place: the 16 fp32 accumulators of n-subtile j become 16 dwords of bf16 pairs (tail_body's conversion, same values)
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        float v[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int n0 = 32 * j + 8 * q4 + 4 * h;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_tab + n0);
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(s_tab + NP + n0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(s_tab + 2 * NP + cls * NP + n0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[4 * q4 + e] = fmaxf(acc[j][4 * q4 + e] * sc[e] + sh[e], 0.f) - ps[e];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float x0 = v[8 * t + 2 * d], x1 = v[8 * t + 2 * d + 1];
+                const bf16x2 hi = {(__bf16)x0, (__bf16)x1};
+                const bf16x2 lo = {(__bf16)(x0 - (float)hi[0]), (__bf16)(x1 - (float)hi[1])};
+                acc[j][8 * t + d] = __builtin_bit_cast(float, hi);
+                acc[j][8 * t + 4 + d] = __builtin_bit_cast(float, lo);
+            }
+        asm volatile("" : "+v"(acc[j]) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto frag_hi = [&](int j, int t) -> bf16x8 {
+        const f32x4 x = {acc[j][8 * t], acc[j][8 * t + 1], acc[j][8 * t + 2], acc[j][8 * t + 3]};
+        return __builtin_bit_cast(bf16x8, x);
+    };
+    auto frag_lo = [&](int j, int t) -> bf16x8 {
+        const f32x4 x = {acc[j][8 * t + 4], acc[j][8 * t + 5], acc[j][8 * t + 6], acc[j][8 * t + 7]};
+        return __builtin_bit_cast(bf16x8, x);
+    };
+
+    LT(tc)
+    LD_SPAN(3, tb, tc)
+    const int trw = lane >> 3, tcq = lane & 7;                 // epilogue layout: lane = (row trw + 8 it, 4 channels at 4 tcq)
+    const unsigned a3_lane = (unsigned)(2 * h * W3_ROW + l31 * 8);
+    float* const scr = reinterpret_cast<float*>(s_scr + wave * 4096);   // this wave's 32 x 32 transpose scratch
+    int slot = 0;
+    for (int cc = 0; cc < nchunk3; ++cc) {
+        const int c0 = cc * LD_CW;
+        // residual tile in the layout the epilogue stores in, requested before the K loop that hides its latency
+        f32x4 res[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int prow = wave * 32 + trw + 8 * it;
+            const float* src = (p.residual && prow < npix) ? p.residual + (size_t)(pix0 + prow) * p.ldr + c0 + tcq * 4 : g_tail_zero;
+            res[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+        }
+        f32x4 sh = *reinterpret_cast<const f32x4*>(p.sh3 + c0 + tcq * 4);
+        f32x16 acc3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+        LD_TIMED(5, ld_wait_landed(sy, base3 + (unsigned)cc + 1u, q.seen))
+        const unsigned char* ws = s_w3 + slot * slot3;
+        slot = slot + 1 == R3 ? 0 : slot + 1;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if (j < nsub) {
+                u32x2 e[2][4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        e[t][qq] = *reinterpret_cast<const u32x2*>(ws + a3_lane + (16 * j + 8 * t + (qq & 1) + 4 * (qq >> 1)) * W3_ROW);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const u32x4 ahu = {e[t][0][0], e[t][1][0], e[t][2][0], e[t][3][0]};
+                    const u32x4 alu = {e[t][0][1], e[t][1][1], e[t][2][1], e[t][3][1]};
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
+                    const bf16x8 hb = frag_hi(j, t), lb = frag_lo(j, t);
+                    LDN_K16(false, acc3, ah, al, hb, lb)
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+        }
+        ld_post_done(sy, wave, base3 + (unsigned)cc + 1u);
+        // the residual (and this wave's earlier stores) before this chunk's stores, which then fly through the next chunk (tail_body: gfx9 counts
+        // loads and stores in one vmcnt and completes them out of order with each other)
+        wait_vm<0>();
+        asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sh));
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = {acc3[4 * q4], acc3[4 * q4 + 1], acc3[4 * q4 + 2], acc3[4 * q4 + 3]};
+            *reinterpret_cast<f32x4*>(scr + l31 * 32 + (((2 * q4 + h) ^ (l31 & 7)) << 2)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = trw + 8 * it, prow = wave * 32 + row;
+            f32x4 x = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tcq ^ (row & 7)) << 2));
+            x = x + sh + res[it];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+            if (prow < npix) {
+                __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p.out + (size_t)(pix0 + prow) * p.ldo + c0 + tcq * 4));
+                csum += x;
+            }
+        }
+        if (p.colsum) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[e] = sum_lane_bits_345(csum[e]);
+            if (trw == 0) *reinterpret_cast<f32x4*>(p.colsum + ((size_t)b * 8 + wave) * p.cout + c0 + tcq * 4) = csum;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    LT(td)
+    LD_SPAN(4, tc, td)
+}
+
+// Whole-image maps of at most 224 pixels leave the workgroup's eighth wave without pixels: the loader / consumer form applies.
+template <int NS>
+__global__ __launch_bounds__(512, 2) void k_chain_ld(const ChainArgs p) {
+    constexpr int W = NS * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int HW = p.H * p.Wd;
+    {   // GAP partial slots of the waves without pixels (the loader, and consumers beyond the map): zero, once -- nobody else writes them
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (wave >= ceil_div(HW, 32))
+            for (int c = lane * 4; c < p.C; c += 256)
+                *reinterpret_cast<f32x4*>(p.colsum + ((size_t)b * 8 + wave) * p.C + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    LdSeq q;
+#ifdef LDN_TRACE
+    for (int k = 0; k < 8; ++k) q.t[k] = 0;
+    unsigned long long c0, c1, c2, c3, c4, c5, c6, am = 0, ah = 0, at = 0, af = 0;
+#endif
+    for (int i = 0; i < p.nblocks; ++i) {
+        CT(c0)
+        const ChainBlock* cb = p.blocks + i;
+        float* const mask_i = p.masks + (size_t)i * p.B * p.G;
+        int32_t* const idx_i = p.ch_idx + (size_t)i * p.B * W;
+        int32_t* const cnt_i = p.ch_cnt + (size_t)i * p.B;
+        const float* const xin = i == 0 ? p.x_in : p.x_work;
+        {   // ---- channel masker of block i on the GAP of its input
+            float* const s_f = reinterpret_cast<float*>(smem);
+            int* const s_w = reinterpret_cast<int*>(s_f + p.C + (p.hidden > 0 ? p.hidden : 1) + 2 * p.G);
+            channel_mlp_body<512>(b, i == 0 ? p.gap_in : p.colsum, HW, p.C, i == 0 ? p.gap_splits : 8, uniform_ptr(cb->mw1),
+                                  uniform_ptr(cb->mb1), uniform_ptr(cb->mw2), uniform_ptr(cb->mb2), p.hidden, p.G, p.gran, nullptr,
+                                  mask_i, nullptr, idx_i, cnt_i, s_f, s_w);
+        }
+        CT(c1)
+        phase_fence();
+        CT(c2)
+        q.base = 0u;
+        q.seen = 0u;
+        {   // ---- conv1 -> h1 (pre-split)
+            HeadArgs ha;
+            ha.x = xin; ha.ldx = p.ldx; ha.B = p.B; ha.HW = HW; ha.cin = p.C; ha.W = W;
+            ha.w1s = uniform_ptr(cb->w1s); ha.n_idx = idx_i; ha.n_cnt = cnt_i;
+            ha.sc1 = uniform_ptr(cb->sc1); ha.sh1 = uniform_ptr(cb->sh1); ha.ps1 = uniform_ptr(cb->ps1);
+            ha.h1 = p.h1; ha.h1_row_bytes = p.h1_row_bytes; ha.pix_per_blk = HW; ha.mblocks = 1; ha.xs = nullptr;
+            head_ld<NS>(ha, b, smem, p.lds_total, opaque_tid(), q);
+        }
+        CT(c3)
+        phase_fence();
+        CT(c4)
+        {   // ---- conv2 -> conv3 + residual, GAP partials of the output
+            TailArgs ta;
+            ta.h1 = p.h1; ta.h1_row_bytes = p.h1_row_bytes;
+            ta.B = p.B; ta.Hi = p.H; ta.Wi = p.Wd; ta.Ho = p.H; ta.Wo = p.Wd; ta.W = W; ta.cout = p.C;
+            ta.w2p = uniform_ptr(cb->w2p); ta.w3p = uniform_ptr(cb->w3p); ta.k_idx = idx_i; ta.k_cnt = cnt_i;
+            ta.sc2 = uniform_ptr(cb->sc2); ta.sh2 = uniform_ptr(cb->sh2); ta.ps2 = uniform_ptr(cb->ps2); ta.sh3 = uniform_ptr(cb->sh3);
+            ta.residual = xin; ta.ldr = p.ldx; ta.out = p.x_work; ta.ldo = p.ldx; ta.colsum = p.colsum;
+            ta.rows_per_blk = p.H; ta.mblocks = 1; ta.slice_bytes = p.slice_bytes; ta.pxs = nullptr; ta.pw = nullptr;
+            tail_ld<NS>(ta, b, smem, p.lds_total, opaque_tid(), q);
+        }
+        CT(c5)
+        phase_fence();
+        CT(c6)
+#ifdef LDN_TRACE
+        am += c1 - c0; ah += c3 - c2; at += c5 - c4; af += (c2 - c1) + (c4 - c3) + (c6 - c5);
+#endif
+    }
+#ifdef LDN_TRACE
+    if (g_chain_trace && threadIdx.x == 0) {
+        unsigned long long* r = g_chain_trace + (size_t)b * 4;
+        r[0] = am; r[1] = ah; r[2] = at; r[3] = af;
+    }
+    if (g_ld_trace && (threadIdx.x & 63) == 0) {
+        unsigned long long* r = g_ld_trace + ((size_t)b * 8 + (threadIdx.x >> 6)) * 8;
+        for (int k = 0; k < 8; ++k) r[k] = q.t[k];
+    }
+#endif
+}
+
+}  // namespace ldn

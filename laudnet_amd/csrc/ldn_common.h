@@ -62,6 +62,7 @@ int tu_violations_tail(unsigned* count, unsigned* code, int reset);
 int tu_violations_dense(unsigned* count, unsigned* code, int reset);
 int tu_violations_small(unsigned* count, unsigned* code, int reset);
 int tu_violations_rows3(unsigned* count, unsigned* code, int reset);
+int tu_chain_stalls(unsigned* count, int reset);      // csrc/ldn_tail.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1109,7 +1109,9 @@ extern "C" int ldn_plan_timeouts(int* count, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) { set_error("ldn_plan_timeouts: device error"); return LDN_EHIP; }
     unsigned v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_plan_timeouts), sizeof(v)) != hipSuccess) { set_error("ldn_plan_timeouts: cannot read the counter"); return LDN_EHIP; }
-    *count = (int)v;
+    unsigned stalls = 0;      // + the loader / consumer hand-off waits of the chained kernel that ran into their bound (csrc/ldn_chain_ld.h)
+    if (tu_chain_stalls(&stalls, reset) != LDN_OK) { set_error("ldn_plan_timeouts: cannot read the chained kernel's counter"); return LDN_EHIP; }
+    *count = (int)(v + stalls);
     if (reset && v) {
         const unsigned z = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_plan_timeouts), &z, sizeof(z)) != hipSuccess) { set_error("ldn_plan_timeouts: cannot reset the counter"); return LDN_EHIP; }

@@ -22,6 +22,7 @@
 #include "ldn_common.h"
 #include "ldn_mlp.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace ldn {
 
@@ -817,6 +818,7 @@ extern "C" int ldn_debug_set_chain_trace(void* buf) {
     unsigned long long* q = static_cast<unsigned long long*>(buf);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
 }
+extern "C" int ldn_debug_set_ld_trace(void* buf);
 extern "C" int ldn_debug_set_head_trace(void* buf) {
     unsigned long long* q = static_cast<unsigned long long*>(buf);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_head_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
@@ -1704,6 +1706,10 @@ __global__ __launch_bounds__(512, (NS == 2 ? 4 : 2)) void k_chain(const ChainArg
 #endif
 }
 
+}  // namespace ldn
+#include "ldn_chain_ld.h"
+namespace ldn {
+
 // LDS of the three phases of a chained block (masker, conv2, conv3; conv1's ring takes whatever is left): do they fit 160 KiB?
 static bool chain_fits(int H, int Wd, int width, int C, int hidden, int G) {
     const int NS = width / 32;
@@ -1726,12 +1732,43 @@ static int launch_chain(ChainArgs& a, hipStream_t st) {
     const size_t lds = 160 * 1024;
     LDN_REQUIRE(chain_fits(a.H, a.Wd, W, a.C, a.hidden, a.G), "ldn_bottleneck_chain: the phases need more than 160 KiB of LDS (map %dx%d, width %d; ldn_bottleneck_chain_fits == 0)", a.H, a.Wd, W);
     a.lds_total = (int)lds;
+    if constexpr (!F32 && NS >= 4) {
+        // A map of at most 224 pixels leaves the workgroup's eighth wave without pixels: the loader / consumer form (ldn_chain_ld.h; round 6).
+        // LDN_CHAIN_LD=0 keeps round 5's kernel (A/B measurements).
+        static const bool use_ld = [] { const char* e = getenv("LDN_CHAIN_LD"); return !(e && atoi(e) == 0); }();
+        if (use_ld && nr <= 224) {
+            LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_chain_ld<NS>), lds), "k_chain_ld: cannot reserve %zu B of LDS", lds);
+            hipLaunchKernelGGL((k_chain_ld<NS>), dim3((unsigned)a.B), dim3(512), lds, st, a);
+            LDN_CHECK_LAUNCH("k_chain_ld");
+            return LDN_OK;
+        }
+    }
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_chain<NS, F32>), lds), "k_chain: cannot reserve %zu B of LDS", lds);
     hipLaunchKernelGGL((k_chain<NS, F32>), dim3((unsigned)a.B), dim3(512), lds, st, a);
     LDN_CHECK_LAUNCH("k_chain");
     return LDN_OK;
 }
 
+}  // namespace ldn
+
+#ifdef LDN_TRACE
+extern "C" int ldn_debug_set_ld_trace(void* buf) {
+    unsigned long long* q = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(ldn::g_ld_trace), &q, sizeof(q)) == hipSuccess ? 0 : -2;
+}
+#endif
+namespace ldn {
+// hand-off waits of k_chain_ld that ran into their bound (summed into ldn_plan_timeouts)
+int tu_chain_stalls(unsigned* count, int reset) {
+    unsigned v = 0u;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ld_stalls), sizeof(v)) != hipSuccess) return LDN_EHIP;
+    *count += v;
+    if (reset && v) {
+        const unsigned z = 0u;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ld_stalls), &z, sizeof(z)) != hipSuccess) return LDN_EHIP;
+    }
+    return LDN_OK;
+}
 }  // namespace ldn
 
 extern "C" int ldn_bottleneck_chain_fits(int H, int Wd, int C, int width, int hidden, int G) {

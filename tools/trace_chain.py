@@ -25,6 +25,10 @@ lib = _lib.load()
 trace = torch.zeros(256 * 4, dtype=torch.int64, device=dev)
 lib.ldn_debug_set_chain_trace.argtypes = [ctypes.c_void_p]
 assert lib.ldn_debug_set_chain_trace(ctypes.c_void_p(trace.data_ptr())) == 0
+ld = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+if hasattr(lib, "ldn_debug_set_ld_trace"):
+    lib.ldn_debug_set_ld_trace.argtypes = [ctypes.c_void_p]
+    assert lib.ldn_debug_set_ld_trace(ctypes.c_void_p(ld.data_ptr())) == 0
 with torch.no_grad():
     for _ in range(3):
         model(x, 1.0)
@@ -34,3 +38,11 @@ tot = t.sum(1)
 for i, n in enumerate(["masker", "conv1 (head)", "conv2+conv3 (tail)", "fences"]):
     print(f"{n:20s} mean {t[:, i].mean():9.0f} cycles/block  ({100 * t[:, i].mean() / tot.mean():4.1f} %)   max {t[:, i].max():9.0f}")
 print(f"total per block      mean {tot.mean():9.0f}   max image {tot.max():9.0f}  min image {tot.min():9.0f}   (shader-clock cycles, ~2.2 GHz)")
+
+l = ld.cpu().numpy().reshape(256, 8, 8).astype(np.float64) / 22.0
+if l.sum() > 0:      # the loader / consumer form (k_chain_ld): cycles per block and wave
+    names = ["conv1 loop", "conv1 epilogue", "conv2 loop", "tables+convert", "conv3 loop", "waits for the other side"]
+    for w in (0, 3, 4, 6):
+        print(f"consumer wave {w}: " + "  ".join(f"{n} {l[:, w, i].mean():8.0f}" for i, n in enumerate(names)))
+    print("loader wave 7:   " + "  ".join(f"{n} {l[:, 7, i].mean():8.0f}" for i, n in ((0, "conv1 stream"), (2, "conv2 stream"), (4, "conv3 stream"), (5, "waits for the consumers"))))
+print("plan_timeouts (incl. chain hand-off stalls):", ops.plan_timeouts())

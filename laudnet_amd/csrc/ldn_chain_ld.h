@@ -193,6 +193,7 @@ __device__ __forceinline__ void head_ld(const HeadArgs& p, const int b, unsigned
 
     if (wave == LD_LOADER) {
         // ---- loader: per-lane source offsets of the image's weight pieces (fixed for the block), then the stream
+        if (nsub == 0) return;
         unsigned wo[MAXP];
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
@@ -239,6 +240,7 @@ __device__ __forceinline__ void head_ld(const HeadArgs& p, const int b, unsigned
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    if (nsub == 0) return;                  // (wave-uniform per image; the loader returned as well) no active channel: no h1 column is read downstream
     for (int c = 0; c < DX - 1; ++c) dma_x(c, c);
     const unsigned xsw = ((unsigned)l31 >> 1) & 7u;
     bf16x8 bh[2], bl[2];
@@ -419,7 +421,6 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
     unsigned long long ta, tb, tc, td;
     LT(ta)
 #endif
-    unsigned w3o[MAXP];                               // loader: per-lane source offsets of the W3 pieces (set behind conv2)
     bool dead = false;
 
     // ======================================================================================================== conv2 (3x3)
@@ -463,7 +464,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
             const bool more = s + 1 < nsub;
             for (int t = 0; t < 9; ++t) {             // (a run-time loop: the loader's code stays small)
                 const int c = 9 * s + t;
-                if (c >= R2) LD_TIMED(5, ld_wait_done(sy, ncomp, base2 + (unsigned)(c - R2 + 1), dead))
+                if (c >= R2) LD_TIMED(6, ld_wait_done(sy, ncomp, base2 + (unsigned)(c - R2 + 1), dead))
                 ld_dma_run<MAXP>(vo, P2, p.w2p + (long)t * ((W / 2) * (W / 2) * 16), lds_w2 + (unsigned)slot * (unsigned)slot2);
                 slot = slot + 1 == R2 ? 0 : slot + 1;
                 int pieces = P2;
@@ -485,6 +486,37 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
         }
         wait_vm_n<0>();
         ld_publish(sy, base2 + (unsigned)nchunks);
+        LT(tb)
+        LD_SPAN(2, ta, tb)
+        // The loader's path stays apart from the consumers' to its end (its own instances of the two workgroup barriers below): merged at the
+        // barriers, its offsets and the consumers' 128 accumulator registers would be live together and hipcc spills the offsets -- scratch reloads
+        // inside the stream loop, whose s_waitcnt vmcnt(0) then drains the ring every chunk.
+        __syncthreads();       // (1) every wave is out of conv2: the slice / W2 regions are free
+        const unsigned lds_w3 = lds_off(s_w3);
+        unsigned w3o[MAXP];    // W3 piece i = k-pair rows 4 i .. 4 i + 3 (256 B each: 32 channels x 8 B): lane = (row 4 i + lane / 16, channel pair lane % 16)
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int u = 4 * i + (lane >> 4);
+            const int kch = 2 * u < Kp ? s_kidx[2 * u] : -1;              // rows beyond the list meet zero h2 values
+            w3o[i] = (unsigned)(((long)(max(kch, 0) >> 1) * p.cout + 2 * (lane & 15)) * 8) + ld_bias(i);
+        }
+        if (nchunk3 > 0 && nsub > 0) ld_dma_run<MAXP>(w3o, P2, p.w3p, lds_w3);      // chunk 0 flies through the table build
+        __syncthreads();       // (2) the tables are in LDS
+        if (nsub > 0) {
+            int slot3i = 1 == R3 ? 0 : 1;
+            for (int cc = 1; cc < nchunk3; ++cc) {
+                if (cc >= R3) LD_TIMED(7, ld_wait_done(sy, ncomp, base3 + (unsigned)(cc - R3 + 1), dead))
+                ld_dma_run<MAXP>(w3o, P2, p.w3p + (long)cc * (LD_CW * 8), lds_w3 + (unsigned)slot3i * (unsigned)slot3);
+                slot3i = slot3i + 1 == R3 ? 0 : slot3i + 1;
+                wait_vm_rt63(P2);
+                ld_publish(sy, base3 + (unsigned)cc);
+            }
+            wait_vm_n<0>();
+        }
+        ld_publish(sy, base3 + (unsigned)nchunk3);
+        LT(tc)
+        LD_SPAN(4, tb, tc)
+        return;
     }
 
     // ---- consumers: this lane's output pixel and its nine tap rows in a slice (ZR = zero row); border class for the shift table
@@ -509,13 +541,37 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
         unsigned arow[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) arow[i] = (unsigned)(4 * h + (i & 3) + 8 * (i >> 2)) * RL + (unsigned)l31 * 8u;
+#ifndef LDN_LD2_STYLE
+#define LDN_LD2_STYLE 1     // 1 = per n-subtile eight entry reads, then six MFMAs, scheduled by hipcc; 3 = a hand-pipelined sequence (entries of subtile j - 1 requested in front of the MFMAs of subtile j, the next chunk's first operands in front of the last ones): measured SLOWER (conv2 151 k vs 143 k cycles per block) -- the loop is not bound by LDS latency
+#endif
+#ifndef LDN_LD_ABLATE
+#define LDN_LD_ABLATE 0     // tuning only, style 1 (results are wrong): 1 = entries are not shuffled into hi / lo quads, 2 = entries are not read from LDS, 4 = no MFMA
+#endif
+#if LDN_LD_ABLATE & 2
+#define LD_ABL_RD(PTR_, I_) (u32x2{(unsigned)(I_) + (unsigned)l31, (unsigned)(I_) * 3u + (unsigned)h})
+#else
+#define LD_ABL_RD(PTR_, I_) (*reinterpret_cast<const u32x2*>(PTR_))
+#endif
+#if LDN_LD_ABLATE & 1
+#define LD_ABL_HI(E_) (u32x4{E_[0][0], E_[0][1], E_[1][0], E_[1][1]})
+#define LD_ABL_LO(E_) (u32x4{E_[2][0], E_[2][1], E_[3][0], E_[3][1]})
+#else
+#define LD_ABL_HI(E_) (u32x4{E_[0][0], E_[1][0], E_[2][0], E_[3][0]})
+#define LD_ABL_LO(E_) (u32x4{E_[0][1], E_[1][1], E_[2][1], E_[3][1]})
+#endif
+#if LDN_LD_ABLATE & 4
+#define LD_ABL_K16(ACC_, AH_, AL_, BH_, BL_) asm volatile("" ::"v"(AH_), "v"(AL_), "v"(BH_), "v"(BL_));
+#else
+#define LD_ABL_K16(ACC_, AH_, AL_, BH_, BL_) LDN_K16(false, ACC_, AH_, AL_, BH_, BL_)
+#endif
+#if LDN_LD2_STYLE == 1
         int slot = 0;
         for (int s = 0; s < nsub; ++s) {
             const unsigned char* hs = s_h1 + (s & 1) * p.slice_bytes;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int c = 9 * s + t;
-                LD_TIMED(5, ld_wait_landed(sy, base2 + (unsigned)c + 1u, q.seen))
+                LD_TIMED(6, ld_wait_landed(sy, base2 + (unsigned)c + 1u, q.seen))
                 const unsigned char* ws = s_w2 + slot * slot2;
                 slot = slot + 1 == R2 ? 0 : slot + 1;
                 {
@@ -532,20 +588,20 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
                         if (j < nsub) {
                             u32x2 e0[4], e1[4];
 #pragma unroll
-                            for (int qq = 0; qq < 4; ++qq) e0[qq] = *reinterpret_cast<const u32x2*>(ws + arow[qq] + j * 256);
+                            for (int qq = 0; qq < 4; ++qq) e0[qq] = LD_ABL_RD(ws + arow[qq] + j * 256, qq);
 #pragma unroll
-                            for (int qq = 0; qq < 4; ++qq) e1[qq] = *reinterpret_cast<const u32x2*>(ws + arow[4 + qq] + j * 256);
+                            for (int qq = 0; qq < 4; ++qq) e1[qq] = LD_ABL_RD(ws + arow[4 + qq] + j * 256, 4 + qq);
                             {
-                                const u32x4 ahu = {e0[0][0], e0[1][0], e0[2][0], e0[3][0]};
-                                const u32x4 alu = {e0[0][1], e0[1][1], e0[2][1], e0[3][1]};
+                                const u32x4 ahu = LD_ABL_HI(e0);
+                                const u32x4 alu = LD_ABL_LO(e0);
                                 const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
-                                LDN_K16(false, acc[j], ah, al, bh[0], bl[0])
+                                LD_ABL_K16(acc[j], ah, al, bh[0], bl[0])
                             }
                             {
-                                const u32x4 ahu = {e1[0][0], e1[1][0], e1[2][0], e1[3][0]};
-                                const u32x4 alu = {e1[0][1], e1[1][1], e1[2][1], e1[3][1]};
+                                const u32x4 ahu = LD_ABL_HI(e1);
+                                const u32x4 alu = LD_ABL_LO(e1);
                                 const bf16x8 ah = __builtin_bit_cast(bf16x8, ahu), al = __builtin_bit_cast(bf16x8, alu);
-                                LDN_K16(false, acc[j], ah, al, bh[1], bl[1])
+                                LD_ABL_K16(acc[j], ah, al, bh[1], bl[1])
                             }
                             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
                             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
@@ -555,28 +611,130 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
                 ld_post_done(sy, wave, base2 + (unsigned)c + 1u);
             }
         }
+#else
+        // One chunk = tap t of K slice s: B fragment = the tap's h1 row (per-lane LDS address), A = the staged W2 rows.  The image's n-subtiles in
+        // DESCENDING order as ONE linear, software-pipelined sequence with an entry point per subtile count (a switch that falls through): the
+        // eight weight entries of subtile j - 1 are requested in front of the six MFMAs of subtile j (a full step of matrix time covers their LDS
+        // latency -- half a step did not: measured), and the NEXT chunk's B fragment and first entries in front of the last six MFMAs of this one
+        // when that chunk has already landed (a non-blocking look at the landed word; otherwise at the top of the next chunk).  Per accumulator the
+        // products keep tail_body's order (half 0, then half 1, chunk after chunk).
+        struct Ent { u32x2 e0[4], e1[4]; };
+        bf16x8 bh[2], bl[2];
+        Ent cur;
+        // (the tap row behind an optimisation barrier: left alone, hipcc hoists the nine taps' four fragment addresses out of the slice loop --
+        // 36 registers that it then spills and reloads inside the chunk)
+        auto rdB = [&](const unsigned char* hs_, int tr, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
+            asm volatile("" : "+v"(tr));
+            const unsigned rbase = (unsigned)tr * 128u, rx = ((unsigned)tr >> 1) & 7u;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const unsigned sl = 2u * (2u * half + h);
+                dh[half] = *reinterpret_cast<const bf16x8*>(hs_ + rbase + ((sl ^ rx) << 4));
+                dl[half] = *reinterpret_cast<const bf16x8*>(hs_ + rbase + (((sl + 1) ^ rx) << 4));
+            }
+        };
+        auto rdBh = [&](const unsigned char* hs_, int tr, int half, bf16x8& dh, bf16x8& dl) {
+            asm volatile("" : "+v"(tr));
+            const unsigned rbase = (unsigned)tr * 128u, rx = ((unsigned)tr >> 1) & 7u;
+            const unsigned sl = 2u * (2u * half + h);
+            dh = *reinterpret_cast<const bf16x8*>(hs_ + rbase + ((sl ^ rx) << 4));
+            dl = *reinterpret_cast<const bf16x8*>(hs_ + rbase + (((sl + 1) ^ rx) << 4));
+        };
+        auto rdE = [&](const unsigned char* ws_, int j, Ent& d) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) d.e0[qq] = *reinterpret_cast<const u32x2*>(ws_ + arow[qq] + j * 256);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) d.e1[qq] = *reinterpret_cast<const u32x2*>(ws_ + arow[4 + qq] + j * 256);
+        };
+#define LDN_LD2_ASM(E_, AH_, AL_)                                                                         \
+            const bf16x8 AH_ = __builtin_bit_cast(bf16x8, (u32x4{E_[0][0], E_[1][0], E_[2][0], E_[3][0]})); \
+            const bf16x8 AL_ = __builtin_bit_cast(bf16x8, (u32x4{E_[0][1], E_[1][1], E_[2][1], E_[3][1]}));
+#define LDN_LD2_STEP(J) {                                                                                 \
+            Ent nxt;                                                                                      \
+            rdE(ws, J - 1, nxt);                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            { LDN_LD2_ASM(cur.e0, ah0, al0) LDN_LD2_ASM(cur.e1, ah1, al1)                                 \
+              LDN_K16(false, acc[J], ah0, al0, bh[0], bl[0])                                              \
+              LDN_K16(false, acc[J], ah1, al1, bh[1], bl[1]) }                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            cur = nxt; }
+        int slot = 0;
+        const unsigned char* ws = s_w2;
+        bool pre = false;                  // this chunk's B fragment and first entries were requested during the previous chunk
+        for (int s = 0; s < nsub; ++s) {
+            const unsigned char* hs = s_h1 + (s & 1) * p.slice_bytes;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int c = 9 * s + t;
+                if (!pre) {
+                    LD_TIMED(6, ld_wait_landed(sy, base2 + (unsigned)c + 1u, q.seen))
+                    rdB(hs, trow[t], bh, bl);
+                    rdE(ws, nsub - 1, cur);
+                }
+                slot = slot + 1 == R2 ? 0 : slot + 1;
+                const unsigned char* wsn = s_w2 + slot * slot2;                                    // the next chunk's slot,
+                const unsigned char* hsn = t == 8 ? s_h1 + ((s + 1) & 1) * p.slice_bytes : hs;     // slice
+                const int trn = trow[(t + 1) % 9];                                                 // and tap row
+                switch (nsub) {
+                    default:
+                        if constexpr (NS >= 8) LDN_LD2_STEP(7)
+                        [[fallthrough]];
+                    case 7:
+                        if constexpr (NS >= 8) LDN_LD2_STEP(6)
+                        [[fallthrough]];
+                    case 6:
+                        if constexpr (NS >= 8) LDN_LD2_STEP(5)
+                        [[fallthrough]];
+                    case 5:
+                        if constexpr (NS >= 8) LDN_LD2_STEP(4)
+                        [[fallthrough]];
+                    case 4:
+                        if constexpr (NS >= 4) LDN_LD2_STEP(3)
+                        [[fallthrough]];
+                    case 3:
+                        if constexpr (NS >= 4) LDN_LD2_STEP(2)
+                        [[fallthrough]];
+                    case 2:
+                        LDN_LD2_STEP(1)
+                        [[fallthrough]];
+                    case 1: {
+                        LDN_LD2_ASM(cur.e0, ah0, al0) LDN_LD2_ASM(cur.e1, ah1, al1)
+                        __builtin_amdgcn_sched_barrier(0);
+                        pre = false;
+                        if (c + 1 < nchunks) {      // (wave-uniform)
+                            const unsigned need = base2 + (unsigned)c + 2u;
+                            if (q.seen < need) q.seen = __builtin_amdgcn_readfirstlane(ld_lds_read(&sy->landed));      // one look, no spin
+                            pre = q.seen >= need;
+                        }
+                        if (pre) rdE(wsn, nsub - 1, cur);
+                        __builtin_amdgcn_sched_barrier(0);
+                        LDN_K16(false, acc[0], ah0, al0, bh[0], bl[0])
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (pre) rdBh(hsn, trn, 0, bh[0], bl[0]);      // (in place: the MFMAs that read this half have been issued)
+                        __builtin_amdgcn_sched_barrier(0);
+                        LDN_K16(false, acc[0], ah1, al1, bh[1], bl[1])
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (pre) rdBh(hsn, trn, 1, bh[1], bl[1]);
+                    }
+                }
+                ld_post_done(sy, wave, base2 + (unsigned)c + 1u);
+                ws = wsn;
+            }
+        }
+#undef LDN_LD2_ASM
+#undef LDN_LD2_STEP
+#endif
     }
     LT(tb)
     LD_SPAN(2, ta, tb)
-    __syncthreads();       // every wave is out of conv2: the slice / W2 regions are free
+    __syncthreads();       // (1) every wave is out of conv2: the slice / W2 regions are free
     // (as in tail_body: the lane index behind an optimisation barrier, or hipcc keeps the conv3 phase's per-lane addresses alive through conv2)
     asm volatile("" : "+v"(lane));
     l31 = lane & 31;
     h = lane >> 5;
 
     // ======================================================================================================== conv3 (1x1)
-    const unsigned lds_w3 = lds_off(s_w3);
-    if (loader) {
-        // W3 piece i = k-pair rows 4 i .. 4 i + 3 (256 B each: 32 channels x 8 B): lane = (row 4 i + lane / 16, channel pair lane % 16)
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            const int u = 4 * i + (lane >> 4);
-            const int kch = 2 * u < Kp ? s_kidx[2 * u] : -1;              // rows beyond the list meet zero h2 values
-            w3o[i] = (unsigned)(((long)(max(kch, 0) >> 1) * p.cout + 2 * (lane & 15)) * 8) + ld_bias(i);
-        }
-        if (nchunk3 > 0 && nsub > 0) ld_dma_run<MAXP>(w3o, P2, p.w3p, lds_w3);      // chunk 0 flies through the table build
-    } else {
-        // conversion tables (gathered through the channel list) by the seven other waves
+    {   // conversion tables (gathered through the channel list) by the seven waves that are not the loader
         const int t7 = tid;                                               // threads 0 .. 447
         for (int i = t7; i < NP; i += 448) {
             const int ch = i < Kb ? s_kidx[i] : -1;
@@ -589,25 +747,8 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
             s_tab[2 * NP + i] = ch >= 0 ? p.sh2[k * W + ch] : 0.f;
         }
     }
-    __syncthreads();       // the tables are in LDS
+    __syncthreads();       // (2) the tables are in LDS
 
-    if (loader) {
-        if (nsub > 0) {
-            int slot = 1 == R3 ? 0 : 1;
-            for (int cc = 1; cc < nchunk3; ++cc) {
-                if (cc >= R3) LD_TIMED(5, ld_wait_done(sy, ncomp, base3 + (unsigned)(cc - R3 + 1), dead))
-                ld_dma_run<MAXP>(w3o, P2, p.w3p + (long)cc * (LD_CW * 8), lds_w3 + (unsigned)slot * (unsigned)slot3);
-                slot = slot + 1 == R3 ? 0 : slot + 1;
-                wait_vm_rt63(P2);
-                ld_publish(sy, base3 + (unsigned)cc);
-            }
-            wait_vm_n<0>();
-        }
-        ld_publish(sy, base3 + (unsigned)nchunk3);
-        LT(tc)
-        LD_SPAN(4, tb, tc)
-        return;
-    }
     if (!consumer) return;
 
     // In place: the 16 fp32 accumulators of n-subtile j become 16 dwords of bf16 pairs (tail_body's conversion, same values)
@@ -667,7 +808,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
         f32x16 acc3;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
-        LD_TIMED(5, ld_wait_landed(sy, base3 + (unsigned)cc + 1u, q.seen))
+        LD_TIMED(7, ld_wait_landed(sy, base3 + (unsigned)cc + 1u, q.seen))
         const unsigned char* ws = s_w3 + slot * slot3;
         slot = slot + 1 == R3 ? 0 : slot + 1;
 #pragma unroll
@@ -758,7 +899,7 @@ __global__ __launch_bounds__(512, 2) void k_chain_ld(const ChainArgs p) {
             int* const s_w = reinterpret_cast<int*>(s_f + p.C + (p.hidden > 0 ? p.hidden : 1) + 2 * p.G);
             channel_mlp_body<512>(b, i == 0 ? p.gap_in : p.colsum, HW, p.C, i == 0 ? p.gap_splits : 8, uniform_ptr(cb->mw1),
                                   uniform_ptr(cb->mb1), uniform_ptr(cb->mw2), uniform_ptr(cb->mb2), p.hidden, p.G, p.gran, nullptr,
-                                  mask_i, nullptr, idx_i, cnt_i, s_f, s_w);
+                                  mask_i, nullptr, idx_i, cnt_i, s_f, s_w, nullptr, true);
         }
         CT(c1)
         phase_fence();

@@ -49,7 +49,8 @@ __device__ __forceinline__ void channel_mlp_body(const int b, const float* __res
                                                       int hidden, int G, int gran, const float* __restrict__ mask_in,
                                                       float* __restrict__ mask, float* __restrict__ logits,
                                                       int32_t* __restrict__ ch_idx, int32_t* __restrict__ ch_cnt,
-                                                      float* s_f, int* s_w, float* s_part = nullptr) {   // s_part: optional NT * 4 floats
+                                                      float* s_f, int* s_w, float* s_part = nullptr,     // s_part: optional NT * 4 floats
+                                                      bool wide_latency = false) {                       // the latency form for hidden <= 8 NW (k_chain_ld)
     float* s_gap = s_f;                 // [C]
     float* s_hid = s_gap + C;           // [max(hidden,1)]
     float* s_log = s_hid + (hidden > 0 ? hidden : 1);  // [2G]
@@ -67,6 +68,84 @@ __device__ __forceinline__ void channel_mlp_body(const int b, const float* __res
         const bool lat = hidden > 0 && hidden <= 2 * NW && (C & 255) == 0 && C <= 2048 && (hidden & 3) == 0 && hidden <= 16 &&
                          (reinterpret_cast<uintptr_t>(w1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w2) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
+        // LATENCY form for the wider hidden layer of stage 3 (hidden = 64 = 8 outputs per wave; round 6, inside k_chain_ld the masker is a serial
+        // gap between two blocks' matrix phases: 28 k cycles per block as three dependent rounds of global reads): every global load of the phase --
+        // the wave's eight layer-1 rows (four quads per lane each), the thread's layer-2 row, the GAP partials -- is issued before the first is
+        // waited for.  Per output the summation order (and every expression) is the general form's below: identical decisions.
+        const bool lat2 = wide_latency && !lat && hidden > 0 && hidden <= 8 * NW && (C & 255) == 0 && C <= 1024 && (hidden & 3) == 0 && hidden <= 64 &&
+                          G2 <= NT && splits <= 8 && (reinterpret_cast<uintptr_t>(w1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w2) & 15) == 0 &&
+                          (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
+        if (lat2) {
+            const int nq = C >> 8;                                   // quads of a weight row per lane (<= 4)
+            f32x4 wq[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int o = wave + NW * k;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    wq[k][q] = (o < n1 && q < nq) ? *reinterpret_cast<const f32x4*>(w1 + (size_t)o * C + lane * 4 + 256 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            f32x4 w2q[16];
+            const int o2 = tid;                                      // layer-2 output of this thread
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                w2q[q] = (o2 < G2 && 4 * q < hidden) ? *reinterpret_cast<const f32x4*>(w2 + (size_t)o2 * hidden + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float b2v = o2 < G2 ? b2[o2] : 0.f;
+            float b1v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b1v[k] = wave + NW * k < n1 ? b1[wave + NW * k] : 0.f;
+            // GAP: four channels per thread, the partials of the (<= 8) splits in flight together, added in split order
+            for (int c = tid * 4; c < C; c += NT * 4) {
+                f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+                f32x4 pv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    pv[k] = k < splits ? *reinterpret_cast<const f32x4*>(partial + ((size_t)b * splits + k) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < splits) sacc += pv[k];
+                *reinterpret_cast<f32x4*>(s_gap + c) = sacc * inv;
+            }
+            __syncthreads();
+            float a1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a1[k] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nq) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(s_gap + lane * 4 + 256 * q);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (wave + NW * k < n1) a1[k] += wq[k][q][0] * g[0] + wq[k][q][1] * g[1] + wq[k][q][2] * g[2] + wq[k][q][3] * g[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a1[k] = wave_sum(a1[k]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int o = wave + NW * k;
+                    if (o < n1) dst1[o] = fmaxf(a1[k] + b1v[k], 0.f);
+                }
+            }
+            __syncthreads();
+            if (o2 < G2) {
+                float a = b2v;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (4 * q < hidden) {
+                        const int j = 4 * q;
+                        a += w2q[q][0] * s_hid[j];
+                        a += w2q[q][1] * s_hid[j + 1];
+                        a += w2q[q][2] * s_hid[j + 2];
+                        a += w2q[q][3] * s_hid[j + 3];
+                    }
+                }
+                s_log[o2] = a;
+            }
+            __syncthreads();
+        } else
         if (lat) {
             const int nq = C >> 8;                                   // quads of a weight row per lane (<= 8)
             f32x4 wq[2][8];

@@ -41,8 +41,8 @@ print(f"total per block      mean {tot.mean():9.0f}   max image {tot.max():9.0f}
 
 l = ld.cpu().numpy().reshape(256, 8, 8).astype(np.float64) / 22.0
 if l.sum() > 0:      # the loader / consumer form (k_chain_ld): cycles per block and wave
-    names = ["conv1 loop", "conv1 epilogue", "conv2 loop", "tables+convert", "conv3 loop", "waits for the other side"]
+    names = ["conv1 loop", "conv1 epilogue", "conv2 loop", "tables+convert", "conv3 loop", "waits: conv1", "conv2", "conv3"]
     for w in (0, 3, 4, 6):
         print(f"consumer wave {w}: " + "  ".join(f"{n} {l[:, w, i].mean():8.0f}" for i, n in enumerate(names)))
-    print("loader wave 7:   " + "  ".join(f"{n} {l[:, 7, i].mean():8.0f}" for i, n in ((0, "conv1 stream"), (2, "conv2 stream"), (4, "conv3 stream"), (5, "waits for the consumers"))))
+    print("loader wave 7:   " + "  ".join(f"{n} {l[:, 7, i].mean():8.0f}" for i, n in ((0, "conv1 stream"), (2, "conv2 stream"), (4, "conv3 stream"), (5, "waits: conv1"), (6, "conv2"), (7, "conv3"))))
 print("plan_timeouts (incl. chain hand-off stalls):", ops.plan_timeouts())

@@ -20,6 +20,10 @@
 
 namespace ldn {
 
+#ifndef LDN_LD3_STAGED
+#define LDN_LD3_STAGED 1     // conv3's weights through the loader's registers, shuffled once into fragment order (0 = LDS-DMA + per-wave shuffles: A/B measurements)
+#endif
+
 constexpr int LD_SYNC_OFF = T_KIDX_BYTES;         // the sync words live behind the channel list in every phase
 constexpr int LD_SYNC_BYTES = 256;
 constexpr int LD_LOADER = 7;                      // the wave without pixels
@@ -492,6 +496,55 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
         // barriers, its offsets and the consumers' 128 accumulator registers would be live together and hipcc spills the offsets -- scratch reloads
         // inside the stream loop, whose s_waitcnt vmcnt(0) then drains the ring every chunk.
         __syncthreads();       // (1) every wave is out of conv2: the slice / W2 regions are free
+#if LDN_LD3_STAGED
+        // conv3's weights through the loader's REGISTERS (it idles ~100 k cycles per block in this phase): a W3 piece (16 B) holds one k-pair of two
+        // channels as {hi k0k1, lo k0k1} x 2, a consumer's A fragment the hi (or lo) halves of FOUR k-pairs of ONE channel -- staged by DMA, every one of
+        // the seven consumer waves rebuilt it with eight ds_read_b64 + sixteen v_mov per n-subtile.  Here the loader shuffles ONCE: item i of a lane =
+        // group g = 4 i + (lane >> 4) (K16 step (j = i, t = (lane >> 5) & 1) of lane half hh = (lane >> 4) & 1: k-pair rows 16 j + 8 t + 2 hh + {0, 1,
+        // 4, 5}) x channel pair lane & 15; four 16-byte loads, four ds_write_b128 into [group][hi | lo plane][channel][16 B].  A consumer fragment is
+        // then ONE conflict-free ds_read_b128 and no VALU.
+        unsigned so[NS][4];
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int u = 16 * i + 8 * ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + (qq & 1) + 4 * (qq >> 1);
+                const int kch = 2 * u < Kp ? s_kidx[2 * u] : -1;          // rows beyond the list meet zero h2 values
+                so[i][qq] = (unsigned)(((long)(max(kch, 0) >> 1) * p.cout + 2 * (lane & 15)) * 8);
+            }
+        u32x4 L[NS][4];
+        auto load_chunk = [&](int cc) {
+            const unsigned char* src = p.w3p + (long)cc * (LD_CW * 8);
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                if (i < nsub)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) L[i][qq] = *reinterpret_cast<const u32x4*>(src + so[i][qq]);
+        };
+        auto store_chunk = [&](unsigned char* slotp) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                if (i < nsub) {
+                    unsigned char* d = slotp + (4 * i + (lane >> 4)) * 1024 + (lane & 15) * 32;
+                    *reinterpret_cast<u32x4*>(d) = u32x4{L[i][0][0], L[i][1][0], L[i][2][0], L[i][3][0]};               // channel 2 np: hi quad
+                    *reinterpret_cast<u32x4*>(d + 512) = u32x4{L[i][0][1], L[i][1][1], L[i][2][1], L[i][3][1]};         //               lo quad
+                    *reinterpret_cast<u32x4*>(d + 16) = u32x4{L[i][0][2], L[i][1][2], L[i][2][2], L[i][3][2]};          // channel 2 np + 1
+                    *reinterpret_cast<u32x4*>(d + 528) = u32x4{L[i][0][3], L[i][1][3], L[i][2][3], L[i][3][3]};
+                }
+        };
+        if (nchunk3 > 0 && nsub > 0) load_chunk(0);                       // chunk 0's pieces fly through the table build
+        __syncthreads();       // (2) the tables are in LDS
+        if (nsub > 0) {
+            int slot3i = 0;
+            for (int cc = 0; cc < nchunk3; ++cc) {
+                if (cc >= R3) LD_TIMED(7, ld_wait_done(sy, ncomp, base3 + (unsigned)(cc - R3 + 1), dead))
+                store_chunk(s_w3 + slot3i * slot3);
+                slot3i = slot3i + 1 == R3 ? 0 : slot3i + 1;
+                ld_publish(sy, base3 + (unsigned)cc + 1u);                // (LDS executes this wave's writes in order: the word lands behind the quads)
+                if (cc + 1 < nchunk3) load_chunk(cc + 1);                 // ... and fly through the wait for the next free slot
+            }
+        }
+#else
         const unsigned lds_w3 = lds_off(s_w3);
         unsigned w3o[MAXP];    // W3 piece i = k-pair rows 4 i .. 4 i + 3 (256 B each: 32 channels x 8 B): lane = (row 4 i + lane / 16, channel pair lane % 16)
 #pragma unroll
@@ -513,6 +566,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
             }
             wait_vm_n<0>();
         }
+#endif
         ld_publish(sy, base3 + (unsigned)nchunk3);
         LT(tc)
         LD_SPAN(4, tb, tc)
@@ -792,6 +846,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
     LD_SPAN(3, tb, tc)
     const int trw = lane >> 3, tcq = lane & 7;                 // epilogue layout: lane = (row trw + 8 it, 4 channels at 4 tcq)
     const unsigned a3_lane = (unsigned)(2 * h * W3_ROW + l31 * 8);
+    const unsigned a3q = (unsigned)(h * 1024 + l31 * 16);      // staged form: the lane's channel in the hi plane of lane half h's group
     float* const scr = reinterpret_cast<float*>(s_scr + wave * 4096);   // this wave's 32 x 32 transpose scratch
     int slot = 0;
     for (int cc = 0; cc < nchunk3; ++cc) {
@@ -811,6 +866,26 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
         LD_TIMED(7, ld_wait_landed(sy, base3 + (unsigned)cc + 1u, q.seen))
         const unsigned char* ws = s_w3 + slot * slot3;
         slot = slot + 1 == R3 ? 0 : slot + 1;
+#if LDN_LD3_STAGED
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if (j < nsub) {
+                bf16x8 ah[2], al[2];      // group 4 j + 2 t + h of the slot: [hi plane 32 channels x 16 B | lo plane]
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ah[t] = *reinterpret_cast<const bf16x8*>(ws + a3q + (4 * j + 2 * t) * 1024);
+                    al[t] = *reinterpret_cast<const bf16x8*>(ws + a3q + (4 * j + 2 * t) * 1024 + 512);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 hb = frag_hi(j, t), lb = frag_lo(j, t);
+                    LDN_K16(false, acc3, ah[t], al[t], hb, lb)
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+        }
+#else
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             if (j < nsub) {
@@ -832,6 +907,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             }
         }
+#endif
         ld_post_done(sy, wave, base3 + (unsigned)cc + 1u);
         // the residual (and this wave's earlier stores) before this chunk's stores, which then fly through the next chunk (tail_body: gfx9 counts
         // loads and stores in one vmcnt and completes them out of order with each other)

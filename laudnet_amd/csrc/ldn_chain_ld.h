@@ -20,6 +20,15 @@
 
 namespace ldn {
 
+#ifndef LDN_LD_PRIO
+#define LDN_LD_PRIO 0        // tuning: s_setprio of the younger consumer waves (4-6); the loader gets 3
+#endif
+#ifndef LDN_LD_R2MAX
+#define LDN_LD_R2MAX 4       // tuning: deepest W2 ring
+#endif
+#ifndef LDN_LD2_STAGED
+#define LDN_LD2_STAGED 0     // conv2's weight tiles through the loader's registers as well: measured SLOWER -- 45 tiles of 20 KB per block are more than one wave can shuffle (4.3 k cycles per tile against the consumers' 2.8 k: conv2 149 k -> 195 k cycles per block); conv2 keeps LDS-DMA into the dense pair layout + per-wave shuffles
+#endif
 #ifndef LDN_LD3_STAGED
 #define LDN_LD3_STAGED 1     // conv3's weights through the loader's registers, shuffled once into fragment order (0 = LDS-DMA + per-wave shuffles: A/B measurements)
 #endif
@@ -124,6 +133,13 @@ __device__ __forceinline__ void wait_vm_rt63(int n) {
         default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
     }
 #undef LDN_WV
+}
+
+// 16 bytes from sbase (wave-uniform) + off (per lane): a GLOBAL load in the saddr + 32-bit offset form (left as a generic pointer, hipcc emits
+// flat loads behind 64-bit address arithmetic -- two address registers per load, 64 of them in a staged tile)
+__device__ __forceinline__ u32x4 ld_global16(const unsigned char* sbase, unsigned off) {
+    typedef const __attribute__((address_space(1))) u32x4* gptr;
+    return *(gptr)(sbase + off);
 }
 
 // One LDS-DMA piece (1 KB: 16 bytes per lane) from sbase (wave-uniform) + vo (per-lane byte offset) to LDS lds_base + lane * 16.
@@ -408,7 +424,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
     __syncthreads();
 
     const int avail2 = lds_total - (LD_SYNC_OFF + LD_SYNC_BYTES) - 2 * p.slice_bytes;
-    const int R2 = __builtin_amdgcn_readfirstlane(nsub > 0 ? min(4, avail2 / slot2) : 4);          // >= 3 for a 224-pixel map of width 256
+    const int R2 = __builtin_amdgcn_readfirstlane(nsub > 0 ? min(LDN_LD_R2MAX, avail2 / slot2) : LDN_LD_R2MAX);          // >= 3 for a 224-pixel map of width 256
     const int avail3 = lds_total - (LD_SYNC_OFF + LD_SYNC_BYTES) - 18 * NP * 4 - 7 * 4096;
     const int R3 = __builtin_amdgcn_readfirstlane(nsub > 0 ? min(4, avail3 / slot3) : 4);
     const int nchunks = nsub * 9;
@@ -430,6 +446,102 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
     // ======================================================================================================== conv2 (3x3)
     f32x16 acc[NS];
     if (loader) {
+#if LDN_LD2_STAGED
+        // W2 tiles through the loader's registers (as conv3's chunks below: the shuffle into fragment order happens ONCE, not in seven waves).  A tile =
+        // 16 k-pair rows x Kp / 2 channel pairs of 16 B = 2 Kp pieces = nsub per lane, staged in HALVES of two groups each: item i (< nsub / 2
+        // rounded up) of a lane = e = lane + 64 i over (group-in-half gh = e / (Kp / 2), packed channel pair v = e % (Kp / 2)); half hf holds groups
+        // 2 hf + gh (K16 half hf of lane half gh: rows 8 hf + 4 gh + {0 .. 3}).  One register buffer per half: while a half is shuffled and written,
+        // the other half's sixteen-byte loads are in flight -- a whole tile of loads is always outstanding.  Slot layout
+        // [group][hi | lo plane][Kp channels][16 B]: a consumer fragment is one conflict-free ds_read_b128.
+        constexpr int NH = NS / 2;                    // items per lane and half (all channels kept)
+        const int nhi = (nsub + 1) / 2;               // ... for this image
+        unsigned colo[NH];                            // source offset of the item's channel pair
+        unsigned dsto[NH];                            // destination offset in the slot's half (a multiple of 32) | gh;  ~0u = no such item (odd nsub)
+        const int hp = max(Kp / 2, 1);
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int e = 64 * i + lane;
+            const int gh = e / hp, v = e - gh * hp;
+            const int ch = 2 * v < Kb ? s_kidx[2 * v] : 0;               // columns beyond the list fetch pair 0 (their accumulator columns meet zero tables)
+            colo[i] = (unsigned)((ch >> 1) * 16);
+            dsto[i] = gh < 2 ? ((unsigned)(gh * Kp * 32 + v * 32) | (unsigned)gh) : ~0u;
+        }
+        unsigned ro[2][NH][4];                        // this slice's source offsets per half: rows through the channel list (rows beyond it meet zero h1 columns)
+        auto slice_rows = [&](int s_) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    const int gh = (int)(dsto[i] & 1u);
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int kch = s_kidx[32 * s_ + 2 * (8 * hf + 4 * gh + qq)];
+                        ro[hf][i][qq] = (unsigned)((max(kch, 0) >> 1) * (W / 2) * 16) + colo[i];
+                    }
+                }
+        };
+        u32x4 LA[NH][4], LB[NH][4];                   // the two halves' pieces
+        auto load_half = [&](int t_, int hf, u32x4 (&L_)[NH][4]) {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(uniform_cptr(p.w2p + (long)t_ * ((W / 2) * (W / 2) * 16)));
+#pragma unroll
+            for (int i = 0; i < NH; ++i)
+                if (i < nhi)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) L_[i][qq] = ld_global16(src, ro[hf][i][qq]);
+        };
+        auto store_half = [&](unsigned char* slotp, int hf, const u32x4 (&L_)[NH][4]) {
+            const int lo = Kp * 16;
+            unsigned char* hb = slotp + hf * (Kp * 64);
+#pragma unroll
+            for (int i = 0; i < NH; ++i)
+                if (i < nhi && dsto[i] != ~0u) {
+                    unsigned char* d = hb + (dsto[i] & ~31u);
+                    *reinterpret_cast<u32x4*>(d) = u32x4{L_[i][0][0], L_[i][1][0], L_[i][2][0], L_[i][3][0]};             // channel 2 v: hi quad
+                    *reinterpret_cast<u32x4*>(d + lo) = u32x4{L_[i][0][1], L_[i][1][1], L_[i][2][1], L_[i][3][1]};        //              lo quad
+                    *reinterpret_cast<u32x4*>(d + 16) = u32x4{L_[i][0][2], L_[i][1][2], L_[i][2][2], L_[i][3][2]};        // channel 2 v + 1
+                    *reinterpret_cast<u32x4*>(d + lo + 16) = u32x4{L_[i][0][3], L_[i][1][3], L_[i][2][3], L_[i][3][3]};
+                }
+        };
+        const unsigned lds_h1 = lds_off(s_h1);
+        const unsigned char* const h1b = p.h1 + pix0 * p.h1_row_bytes;
+        // h1 slice piece i: rows 8 i + (lane >> 3), physical 16-byte slot lane & 7 (XOR swizzle on the source side)
+        auto h1_piece = [&](int i, const void* sb, unsigned dst) {
+            const int r = 8 * i + (lane >> 3);
+            const unsigned o = (unsigned)(min(r, NR - 1) * (int)p.h1_row_bytes + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+            ld_dma1(o, sb, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)i * 1024u)));
+        };
+        if (nchunks > 0) {
+            const void* sb0 = uniform_cptr(h1b);
+            for (int i = 0; i < nq; ++i) h1_piece(i, sb0, lds_h1);       // slice 0 -> slot 0
+            slice_rows(0);
+            load_half(0, 0, LA);
+            load_half(0, 1, LB);
+        }
+        int slot = 0;
+        int sn = 0, tn = 1;                           // slice / tap of chunk c + 1
+        for (int c = 0; c < nchunks; ++c) {
+            const int sc = c / 9, tc = c - 9 * sc;
+            const bool nxt = c + 1 < nchunks;
+            if (c >= R2) LD_TIMED(6, ld_wait_done(sy, ncomp, base2 + (unsigned)(c - R2 + 1), dead))
+            if (tc == 0) wait_vm_n<0>();              // slice sc has landed (its pieces went out with taps TMIN .. 8 of the slice before)
+            unsigned char* const slotp = s_w2 + slot * slot2;
+            slot = slot + 1 == R2 ? 0 : slot + 1;
+            store_half(slotp, 0, LA);                 // (waits for half 0's pieces only: half 1's and nothing younger may still fly)
+            if (nxt) {
+                if (tn == 0) slice_rows(sn);          // (both halves' rows of the next slice: ro[1] of THIS chunk has been consumed by its loads)
+                load_half(tn, 0, LA);
+            }
+            store_half(slotp, 1, LB);
+            ld_publish(sy, base2 + (unsigned)c + 1u);                  // (LDS executes this wave's writes in order: the word lands behind the quads)
+            if (nxt) load_half(tn, 1, LB);
+            if (tc >= TMIN && sc + 1 < nsub) {        // slice sc + 1: piece i goes out with tap TMIN + i % 6 (every reader has left slice sc - 1 by then: R2 <= 4)
+                const void* hsb = uniform_cptr(h1b + (long)(sc + 1) * 128);
+                const unsigned hdst = lds_h1 + (unsigned)((sc + 1) & 1) * (unsigned)p.slice_bytes;
+                for (int i = tc - TMIN; i < nq; i += 6) h1_piece(i, hsb, hdst);
+            }
+            if (++tn == 9) { tn = 0; ++sn; }
+        }
+#else
         unsigned ho[MAXH];                            // h1 slice piece i: rows 8 i + (lane >> 3), physical 16-byte slot lane & 7
 #pragma unroll
         for (int i = 0; i < MAXH; ++i) {
@@ -488,6 +600,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
                 if (c > 0) { wait_vm_rt63(pieces); ld_publish(sy, base2 + (unsigned)c); }      // chunks < c (and every slice piece issued with them) have landed
             }
         }
+#endif
         wait_vm_n<0>();
         ld_publish(sy, base2 + (unsigned)nchunks);
         LT(tb)
@@ -514,12 +627,12 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
             }
         u32x4 L[NS][4];
         auto load_chunk = [&](int cc) {
-            const unsigned char* src = p.w3p + (long)cc * (LD_CW * 8);
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(uniform_cptr(p.w3p + (long)cc * (LD_CW * 8)));
 #pragma unroll
             for (int i = 0; i < NS; ++i)
                 if (i < nsub)
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) L[i][qq] = *reinterpret_cast<const u32x4*>(src + so[i][qq]);
+                    for (int qq = 0; qq < 4; ++qq) L[i][qq] = ld_global16(src, so[i][qq]);
         };
         auto store_chunk = [&](unsigned char* slotp) {
 #pragma unroll
@@ -595,6 +708,10 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
         unsigned arow[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) arow[i] = (unsigned)(4 * h + (i & 3) + 8 * (i >> 2)) * RL + (unsigned)l31 * 8u;
+        // staged form: slot = [group 2 half + h][hi | lo plane][Kp channels][16 B]; bq[2 half + plane]
+        unsigned bq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bq[i] = (unsigned)((2 * (i >> 1) + h) * Kp * 32 + (i & 1) * Kp * 16 + l31 * 16);
 #ifndef LDN_LD2_STYLE
 #define LDN_LD2_STYLE 1     // 1 = per n-subtile eight entry reads, then six MFMAs, scheduled by hipcc; 3 = a hand-pipelined sequence (entries of subtile j - 1 requested in front of the MFMAs of subtile j, the next chunk's first operands in front of the last ones): measured SLOWER (conv2 151 k vs 143 k cycles per block) -- the loop is not bound by LDS latency
 #endif
@@ -637,6 +754,22 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
                         bh[half] = *reinterpret_cast<const bf16x8*>(hs + rbase + ((sl ^ rx) << 4));
                         bl[half] = *reinterpret_cast<const bf16x8*>(hs + rbase + (((sl + 1) ^ rx) << 4));
                     }
+#if LDN_LD2_STAGED
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) {
+                        if (j < nsub) {      // fragment (j, K16 half, hi | lo) = one ds_read_b128: group 2 half + h, plane, channel 32 j + l31
+                            const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(ws + bq[0] + j * 512);
+                            const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(ws + bq[1] + j * 512);
+                            const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(ws + bq[2] + j * 512);
+                            const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(ws + bq[3] + j * 512);
+                            LDN_K16(false, acc[j], ah0, al0, bh[0], bl[0])
+                            LDN_K16(false, acc[j], ah1, al1, bh[1], bl[1])
+                            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                        }
+                    }
+                }
+#else
 #pragma unroll
                     for (int j = 0; j < NS; ++j) {
                         if (j < nsub) {
@@ -662,6 +795,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
                         }
                     }
                 }
+#endif
                 ld_post_done(sy, wave, base2 + (unsigned)c + 1u);
             }
         }
@@ -958,6 +1092,16 @@ __global__ __launch_bounds__(512, 2) void k_chain_ld(const ChainArgs p) {
             for (int c = lane * 4; c < p.C; c += 256)
                 *reinterpret_cast<f32x4*>(p.colsum + ((size_t)b * 8 + wave) * p.C + c) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#if LDN_LD_PRIO
+    // Static priorities (MI355X_MICROARCH.md, two waves per SIMD): the second-dispatched half of the workgroup (waves 4-6) loses every VALU / issue
+    // arbitration against its older SIMD partner and finishes every phase last -- and a phase ends with its LAST wave.  The loader's few instructions
+    // sit on every hand-off's critical path.
+    {
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (w == LD_LOADER) __builtin_amdgcn_s_setprio(3);
+        else if (w >= 4) __builtin_amdgcn_s_setprio(LDN_LD_PRIO);
+    }
+#endif
     LdSeq q;
 #ifdef LDN_TRACE
     for (int k = 0; k < 8; ++k) q.t[k] = 0;

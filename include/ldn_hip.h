@@ -30,6 +30,15 @@ extern "C" {
 #define LDN_EINVAL (-1)   /* bad argument (shape/alignment/unsupported combination) */
 #define LDN_EHIP (-2)     /* HIP runtime error at launch */
 
+/* PER-THREAD STATE.  The entry points take everything they compute from their arguments; what the library keeps between calls is exactly this,
+ * all of it thread-local (two threads never see each other's):
+ *   - the text behind ldn_last_error();
+ *   - ldn_hint_rows(n): an ADVISORY row count consumed by the thread's next ldn_conv_rows_split / ldn_conv_rows_pool call (tile shape only;
+ *     results are bit-identical with any hint or none) -- ldn_conv3x3_rows_ps takes the same hint as an argument;
+ *   - ldn_plan_work_zeroed(1): the caller's PROMISE that the `work` buffer of the thread's next list-build call is zero, consumed by that call
+ *     (which hands the buffer back zeroed whatever path it takes).
+ * Process-wide and read-only after the first use: the environment switches named in this header and the default arithmetic mode.  Device-side
+ * counters (ldn_debug_violations, ldn_plan_timeouts) and the fault word (ldn_fault_flag) are diagnostics, not inputs of any computation. */
 const char* ldn_last_error(void);
 int ldn_version(void);
 /* Index-bounds audit ("race detection / sanitizers").  In the LDN_DEBUG build of the library (python -m
@@ -45,6 +54,11 @@ int ldn_debug_violations(int* count, int* first_code, int reset);
  * workgroups -- never uninitialised rows, and is counted here: *count = such events since the last reset (0 on a healthy device).
  * Synchronises the device: call it at a point where the caller synchronises anyway (end of a batch, health check). */
 int ldn_plan_timeouts(int* count, int reset);
+/* The LOUD side of the same events (and of the hand-off waits of the chained stage kernel, which are bounded the same way and counted in
+ * ldn_plan_timeouts as well): one int of pinned host memory per process that a kernel sets to 1 the moment one of its bounded waits fails.  The
+ * caller reads it WITHOUT synchronising -- laudnet_amd._lib.check() does after every library call and raises LdnError -- so a forward that ran
+ * on empty lists cannot hand its logits on silently.  Sticky until ldn_plan_timeouts(.., reset = 1).  NULL when no pinned memory could be had. */
+const int* ldn_fault_flag(void);
 /* number of compute units of the current device (used by callers to size persistent grids) */
 int ldn_device_cus(int* cus);
 /* Arithmetic of the MFMA convolutions -- the `math_mode` ARGUMENT of ldn_conv_image / ldn_conv_packed / ldn_conv_rows /
@@ -226,7 +240,8 @@ int ldn_conv_rows_pool(const float* a, int lda, const int32_t* a_rows, const int
  * ldn_conv3x3_rows_ps: out[m, :] = act(scale * sum_{tap, k} a[nbr[m][tap], k] * w[:, tap, k] + shift) over the first min(*m_count, m_cap)
  *   packed rows (m_count NULL: m_cap): `a_presplit` pre-split rows, nbr [m_cap][9] (row of `a` per tap, -1 = zero), w_split the pre-split
  *   [cout][9][cin] weights, relu 0 | 1, out fp32 or pre-split rows (out_presplit).  rows_hint >= 0: about how many rows *m_count will hold
- *   (tile shapes only; -1 = unknown).  cin % 64 == 0, cout % 64 == 0.  Bit-identical to ldn_conv_rows_split(taps = 9) on the same values. */
+ *   (tile shapes only; -1 = unknown).  cin % 64 == 0, cin <= 2048 (the zero row a missing neighbour is read from), cout % 64 == 0.  Bit-identical to
+ *   ldn_conv_rows_split(taps = 9) on the same values. */
 int ldn_conv_rows_ps(const float* a, int lda, int a_presplit, const int32_t* a_rows, const int32_t* m_count, int m_cap,
                      const void* w_split, int cin, int cout, const float* scale, const float* shift, int relu,
                      const int32_t* relu_if_neg, const int32_t* out_rows, const float* residual, int ldr, float* out, int ldo,

@@ -6,10 +6,12 @@ nn.Module surface).  There is no CPU or PyTorch fallback for the hot path.
 """
 import os as _os
 
-# Kernel arguments in device memory (ROCm runtime switch, read when HIP initialises -- i.e. it takes effect if laudnet_amd is imported
-# before the first HIP call of the process): the ~150-250 launches of a forward each start without an argument fetch over PCIe.
-# An explicit HIP_FORCE_DEV_KERNARG in the environment wins.
-_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Kernel arguments in device memory (ROCm runtime switch HIP_FORCE_DEV_KERNARG, read when HIP initialises): the ~150-250 launches of a forward
+# each start without an argument fetch over PCIe.  OPT-IN since round 6 (importing a library must not change the process environment behind its
+# host's back): LDN_DEV_KERNARG=1 sets it here -- effective only when laudnet_amd is imported before the process's first HIP call -- and an
+# explicit HIP_FORCE_DEV_KERNARG always wins.  bench.py sets the runtime switch itself, for every leg of its process alike.
+if _os.environ.get("LDN_DEV_KERNARG", "0") not in ("", "0"):
+    _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from ._lib import LdnError, load as load_library  # noqa: F401,E402
 from .laud_resnet import (Bottleneck, ExpandMask, Masker_channel_conv_linear, Masker_channel_MLP,  # noqa: F401

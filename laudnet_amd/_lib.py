@@ -19,6 +19,7 @@ SIGNATURES = {
     "ldn_version": ([], _I),
     "ldn_debug_violations": ([C.POINTER(_I), C.POINTER(_I), _I], _I),
     "ldn_plan_timeouts": ([C.POINTER(_I), _I], _I),
+    "ldn_fault_flag": ([], C.POINTER(_I)),
     "ldn_device_cus": ([C.POINTER(_I)], _I),
     "ldn_default_math_mode": ([], _I),
     "ldn_spatial_masker": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P], _I),
@@ -129,10 +130,24 @@ _SYNC_CALLS = os.environ.get("LDN_SYNC_CALLS", "0") != "0"    # debugging: synch
 _n_calls = 0
 
 
-def check(status: int, what: str):
+_fault = None          # the library's fault word (ldn_fault_flag), fetched with the first device tensor (require_device)
+
+
+def _arm_fault_flag():
+    global _fault
+    if _fault is None:
+        p = load().ldn_fault_flag()
+        _fault = p if p else False
+
+
+def check(status: int, what: str, fault_ok: bool = False):
     if status != 0:
         msg = load().ldn_last_error()
         raise LdnError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
+    if _fault and not fault_ok and _fault[0] != 0:
+        # a kernel's bounded wait (one-launch list build, chained stage hand-off) ran into its bound: it left EMPTY lists / lost values
+        raise LdnError(f"{what}: a device-side bounded wait ran into its time bound since the last reset -- results computed since are "
+                       "invalid (ops.plan_timeouts() counts the events, ops.plan_timeouts(reset=True) re-arms)")
     if _SYNC_CALLS:
         global _n_calls
         import sys
@@ -157,6 +172,8 @@ def require_device(*tensors):
             raise LdnError("laudnet_amd ops need tensors on a HIP device (cuda:N); there is no CPU path")
         if cur is None:
             cur = torch.cuda.current_device()
+            if _fault is None:
+                _arm_fault_flag()
         if t.device.index != cur:
             raise LdnError(f"tensor on {t.device} but the current device is cuda:{cur}: wrap the call in "
                            f"torch.cuda.device({t.device.index}) (kernels are launched on the current device's stream)")

@@ -39,6 +39,7 @@ constexpr int LD_LOADER = 7;                      // the wave without pixels
 constexpr int LD_SPIN_LIMIT = 1 << 20;            // polls (each >= ~150 cycles with its s_sleep): ~0.1 s
 
 __device__ unsigned g_ld_stalls = 0u;             // hand-off waits that ran into LD_SPIN_LIMIT since the last reset
+__device__ int* g_ld_fault_dev = nullptr;         // the process's host-visible fault word (ldn_fault_flag), set by launch_chain once per device
 #ifdef LDN_TRACE   // tuning only (tools/trace_chain.py): [B][8 waves][8] cycles summed over the run -- consumers: conv1 loop, conv1 epilogue, conv2 loop,
                    // table build + conversion, conv3 loop, waits for the loader (all phases); loader: the three streams, waits for the consumers
 __device__ unsigned long long* g_ld_trace = nullptr;
@@ -86,7 +87,10 @@ __device__ __forceinline__ void ld_wait_landed(LdSync* sy, unsigned need, unsign
         seen = __builtin_amdgcn_readfirstlane(ld_lds_read(&sy->landed));
         if (seen >= need) break;
         if (spin >= LD_SPIN_LIMIT) {
-            if ((threadIdx.x & 63) == 0) atomicAdd(&g_ld_stalls, 1u);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&g_ld_stalls, 1u);
+                if (g_ld_fault_dev) __hip_atomic_store(g_ld_fault_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             seen = 0x7fffffffu;                   // sticky: this wave stops waiting (values are lost, the launch terminates)
             break;
         }
@@ -107,7 +111,10 @@ __device__ __forceinline__ void ld_wait_done(LdSync* sy, int ncomp, unsigned nee
         const unsigned v = ld_lds_read(&sy->done[lane & 15]);
         if (__ballot(lane < ncomp && v < need) == 0ull) break;
         if (spin >= LD_SPIN_LIMIT) {
-            if (lane == 0) atomicAdd(&g_ld_stalls, 1u);
+            if (lane == 0) {
+                atomicAdd(&g_ld_stalls, 1u);
+                if (g_ld_fault_dev) __hip_atomic_store(g_ld_fault_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             dead = true;
             break;
         }

@@ -63,6 +63,10 @@ int tu_violations_dense(unsigned* count, unsigned* code, int reset);
 int tu_violations_small(unsigned* count, unsigned* code, int reset);
 int tu_violations_rows3(unsigned* count, unsigned* code, int reset);
 int tu_chain_stalls(unsigned* count, int reset);      // csrc/ldn_tail.hip
+// The process's fault word: pinned host memory that a kernel sets when one of its bounded waits runs into its bound (ldn_fault_flag; csrc/ldn_index.hip).
+// fault_word_dev(): its device-side address (nullptr if the allocation failed).
+int* fault_word_host();
+int* fault_word_dev();
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

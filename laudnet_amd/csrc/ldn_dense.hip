@@ -1015,7 +1015,10 @@ extern "C" int ldn_conv_rows_gated(const float* a, int lda, const int32_t* m_cou
     LDN_REQUIRE((size_t)(255 / gate_rows + 2) * round_up(cin, 32) * 4 <= 44 * 1024,
                 "ldn_conv_rows_gated: the gate vectors of the %d images a 256-row tile touches (%d channels each) exceed the 44 KB of LDS left for them "
                 "(scale the rows first and use ldn_conv_rows_split)", 255 / gate_rows + 2, cin);
-    if (cout % 128 == 0 || (cout > 64 && cout <= 128)) return launch_dense2<4, false, false, false, true, true, true>(d, st);
+    //  the 128-column tiles stage 130 KB: only 30 KB are left for the gate vectors there -- wider gates take the 160-column
+    // tiles (114 KB of staging, ragged last tile), whose 46 KB cover the 44 KB bound above
+    const size_t gate_bytes = (size_t)(255 / gate_rows + 2) * round_up(cin, 32) * 4;
+    if ((cout % 128 == 0 || (cout > 64 && cout <= 128)) && gate_bytes <= 30 * 1024) return launch_dense2<4, false, false, false, true, true, true>(d, st);
     if (cout <= 64) return launch_dense2<2, false, false, false, true, true, true>(d, st);
     return launch_dense2<5, false, false, false, true, true, true>(d, st);
 }

@@ -226,18 +226,23 @@ __global__ __launch_bounds__(512, 2) void k_grouped16_img(const GiArgs p) {
 }
 
 // groups per workgroup and output rows per workgroup for an Hi x Wi input map (false: not even three input rows of one group fit)
-static bool gi_plan(int Hi, int Wi, int Ho, int stride, int G, int* ng_out, int* R_out) {
-    auto bytes = [&](int ng, int in_rows) { return (size_t)ng * GM_FRAG + ((size_t)in_rows * Wi + 1) * (16 * ng + 4) * 4; };
-    if (bytes(1, Hi) <= 150 * 1024) {          // whole images: as many groups per workgroup as leave room for two workgroups per CU
+// gap: the launch also leaves channel sums -- [group][16-pixel tile][16] floats of scratch behind the staged rows count against the same budgets
+// (they did not, and a map near the whole-image limit made the gap form's launch fail instead of answering "does not fit")
+static bool gi_plan(int Hi, int Wi, int Ho, int stride, int G, int* ng_out, int* R_out, bool gap = false) {
+    const int Wo = (Wi - 1) / stride + 1;
+    auto bytes = [&](int ng, int in_rows, int out_rows) {
+        return (size_t)ng * GM_FRAG + ((size_t)in_rows * Wi + 1) * (16 * ng + 4) * 4 + (gap ? (size_t)ng * ceil_div(out_rows * Wo, 16) * 64 : 0);
+    };
+    if (bytes(1, Hi, Ho) <= 150 * 1024) {          // whole images: as many groups per workgroup as leave room for two workgroups per CU
         int ng = 1;
-        while (ng < G && ng < GM_MAXG && bytes(ng + 1, Hi) <= 80 * 1024) ++ng;
+        while (ng < G && ng < GM_MAXG && bytes(ng + 1, Hi, Ho) <= 80 * 1024) ++ng;
         const int nchunks = ceil_div(G, ng);
         *ng_out = ceil_div(G, nchunks);
         *R_out = Ho;
         return true;
     }
     int R = 0;                                 // bands of output rows, one group per workgroup
-    while (R < Ho && bytes(1, R * stride + 3) <= 80 * 1024) ++R;          // (R + 1 - 1) stride + 3 input rows for R + 1 output rows
+    while (R < Ho && bytes(1, R * stride + 3, R + 1) <= 80 * 1024) ++R;          // (R + 1 - 1) stride + 3 input rows for R + 1 output rows
     if (R < 1) return false;
     const int nb = ceil_div(Ho, R);
     *ng_out = 1;
@@ -281,7 +286,9 @@ extern "C" int ldn_grouped16_conv3x3_rows(const float* a, int lda, const int32_t
 
 extern "C" int ldn_grouped16_images_fit(int Hi, int Wi, int C) {
     int ng = 0, R = 0;   // (stride 2 is the worst case for the banded form: three input rows for one output row)
-    return (Hi > 0 && Wi > 0 && C > 0 && C % 16 == 0 && gi_plan(Hi, Wi, (Hi - 1) / 2 + 1, 2, C / 16, &ng, &R)) ? ng : 0;
+    // (with the channel-sum scratch of the gap form: the module gates its fused SE path on this answer)
+    return (Hi > 0 && Wi > 0 && C > 0 && C % 16 == 0 && gi_plan(Hi, Wi, (Hi - 1) / 2 + 1, 2, C / 16, &ng, &R, true) &&
+            gi_plan(Hi, Wi, Hi, 1, C / 16, &ng, &R, true)) ? ng : 0;
 }
 
 static int grouped16_images(const float* a, int lda, const int32_t* m_count, int images_cap, int Hi, int Wi, int Ho,
@@ -300,7 +307,7 @@ static int grouped16_images(const float* a, int lda, const int32_t* m_count, int
     g.scale = scale; g.shift = shift; g.relu = relu; g.out = out; g.ldo = ldo;
     g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.gap = gap;
     const int G = C / 16;
-    LDN_REQUIRE(gi_plan(Hi, Wi, Ho, stride, G, &g.gchunk, &g.R),
+    LDN_REQUIRE(gi_plan(Hi, Wi, Ho, stride, G, &g.gchunk, &g.R, gap != nullptr),
                 "ldn_grouped16_conv3x3_images: three rows of a %d-wide map do not fit the LDS (ldn_grouped16_images_fit)", Wi);
     g.nbands = ceil_div(Ho, g.R);
     g.in_ld = 16 * g.gchunk + 4;
@@ -322,7 +329,7 @@ extern "C" int ldn_grouped16_conv3x3_images(const float* a, int lda, const int32
 
 extern "C" int ldn_grouped16_images_bands(int Hi, int Wi, int Ho, int stride, int C) {
     int ng = 0, R = 0;
-    if (!(Hi > 0 && Wi > 0 && Ho > 0 && stride >= 1 && C > 0 && C % 16 == 0 && gi_plan(Hi, Wi, Ho, stride, C / 16, &ng, &R))) return 0;
+    if (!(Hi > 0 && Wi > 0 && Ho > 0 && stride >= 1 && C > 0 && C % 16 == 0 && gi_plan(Hi, Wi, Ho, stride, C / 16, &ng, &R, true))) return 0;      // (the gap form's bands: it sizes that form's buffer)
     return ceil_div(Ho, R);
 }
 

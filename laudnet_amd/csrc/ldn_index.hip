@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256) void k_mask_index(const float* __restrict__ pa
 //     that the rows of one patch are contiguous in the packed tensors (conv3's epilogue then owns whole patches).  Same SET of
 //     pixels, same counts / prefixes / statistics; pos3 / nbr follow the order.  Even grids only (Ho % S == 0, Wo % Sx == 0).
 __device__ unsigned g_plan_timeouts = 0u;      // launches' failed prefix waits since the last reset (release builds too)
+__device__ int* g_fault_dev = nullptr;          // the process's host-visible fault word (ldn_fault_flag), set by launch_plan once per device
 #ifdef LDN_DEBUG
 __device__ int g_plan_stall = -1;              // test hook (ldn_debug_plan_stall): this image never publishes its counts
 #endif
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
             if (lane == 0) {        // flag first, then the zeroes
                 __hip_atomic_store(&a.sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 atomicAdd(&g_plan_timeouts, 1u);
+                if (g_fault_dev) __hip_atomic_store(g_fault_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // loud: the caller's next check() raises
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             poison();
@@ -1101,6 +1103,39 @@ extern "C" int ldn_debug_violations(int* count, int* first_code, int reset) {
 #endif
 }
 
+namespace ldn {
+// One pinned, device-mapped int per process.  Kernels write 1 into it when a bounded wait fails; the host reads it without synchronising.
+int* fault_word_host() {
+    static int* word = [] {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return static_cast<int*>(nullptr); }
+        *static_cast<volatile int*>(q) = 0;
+        return static_cast<int*>(q);
+    }();
+    return word;
+}
+int* fault_word_dev() {
+    int* h = fault_word_host();
+    void* d = nullptr;
+    if (!h || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return static_cast<int*>(d);
+}
+// once per device: the kernels of this translation unit learn the word's address
+static void arm_fault_word_index(hipStream_t st) {
+    static bool armed[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || armed[dev]) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;       // (not inside a graph capture: the symbol copy is a synchronous call)
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    int* d = fault_word_dev();
+    if (d && hipMemcpyToSymbol(HIP_SYMBOL(g_fault_dev), &d, sizeof(d)) == hipSuccess) armed[dev] = true;
+    else (void)hipGetLastError();
+}
+}  // namespace ldn
+
+// The fault word (see include/ldn_hip.h): NULL when pinned memory could not be had (no device).
+extern "C" const int* ldn_fault_flag(void) { return ldn::fault_word_host(); }
+
 // Prefix waits of ldn_mask_plan / ldn_mask_to_index launches that ran into their time bound since the last reset (0 on a healthy
 // device).  Such a launch leaves EMPTY lists (counts, prefixes and statistics zero), never uninitialised ones; this counter is how a
 // caller finds out.  Synchronises the device.
@@ -1112,6 +1147,9 @@ extern "C" int ldn_plan_timeouts(int* count, int reset) {
     unsigned stalls = 0;      // + the loader / consumer hand-off waits of the chained kernel that ran into their bound (csrc/ldn_chain_ld.h)
     if (tu_chain_stalls(&stalls, reset) != LDN_OK) { set_error("ldn_plan_timeouts: cannot read the chained kernel's counter"); return LDN_EHIP; }
     *count = (int)(v + stalls);
+    if (reset) {
+        if (int* fw = fault_word_host()) *static_cast<volatile int*>(fw) = 0;      // re-arm the loud path
+    }
     if (reset && v) {
         const unsigned z = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_plan_timeouts), &z, sizeof(z)) != hipSuccess) { set_error("ldn_plan_timeouts: cannot reset the counter"); return LDN_EHIP; }
@@ -1245,12 +1283,23 @@ static size_t plan_lds(int S, int Sx, int Ho, int Wo, int stride) {
 // the next ldn_mask_plan / ldn_mask_to_index call of the thread whatever path it takes.
 static thread_local int g_plan_work_zero = 0;
 extern "C" int ldn_plan_work_zeroed(int yes) { g_plan_work_zero = yes ? 1 : 0; return LDN_OK; }
+//  A caller that vouched for a zeroed `work` gets it back zeroed WHATEVER path the call took: the two-launch and banded builds
+// leave their counts in it, so they clear it behind themselves -- the caller's mirror of the library's path choice (environment switches included)
+// no longer has to be exact for a shared, zeroed-once buffer to stay valid.
+static int rezero_vouched_work(bool vouched, int32_t* work, int B, int Ho, int Wo, int stride, hipStream_t st) {
+    if (!vouched) return LDN_OK;
+    const int n = (int)(ldn_mask_to_index_workspace_bytes(B, Ho, Wo, stride) / sizeof(int32_t));
+    hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, work, n);
+    LDN_CHECK_LAUNCH("k_zero_i32");
+    return LDN_OK;
+}
 
 static int launch_plan(PlanArgs& a, int32_t* work, hipStream_t st, bool work_is_zero) {
     const IdxGeom& g = a.g;
     const size_t lds = plan_lds(g.S, g.Sx, g.Ho, g.Wo, g.stride);
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_plan), lds), "k_plan: cannot reserve %zu B of LDS", lds);
     a.sync = work;
+    arm_fault_word_index(st);
     // bound of the prefix wait: 2 s by default (a predecessor workgroup of the SAME launch publishes within microseconds of its start;
     // only a queue pre-empted for that long could exceed it); LDN_PLAN_TIMEOUT_MS overrides (tests)
     static const long timeout_ms = getenv("LDN_PLAN_TIMEOUT_MS") ? atol(getenv("LDN_PLAN_TIMEOUT_MS")) : 2000;
@@ -1362,7 +1411,7 @@ extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, 
         hipLaunchKernelGGL(k_mask_index, dim3(B), dim3(256), lds2, st, patch_mask, g, work, idx3, pos3, idx1, pos1, nbr,
                            cnt, img_prefix3, img_prefix1, stats);
         LDN_CHECK_LAUNCH("k_mask_index");
-        return LDN_OK;
+        return rezero_vouched_work(work_zero, work, B, Ho, Wo, stride, st);
     }
     // bands of output rows (large / detection-size maps)
     BandGeom bg{};
@@ -1375,7 +1424,7 @@ extern "C" int ldn_mask_to_index(const float* patch_mask, int B, int S, int Sx, 
     hipLaunchKernelGGL(k_mask_index_band, dim3((unsigned)B * bg.nb), dim3(256), ldsb, st, patch_mask, g, bg, work, idx3, pos3, idx1,
                        pos1, nbr, cnt, img_prefix3, img_prefix1, stats);
     LDN_CHECK_LAUNCH("k_mask_index_band");
-    return LDN_OK;
+    return rezero_vouched_work(work_zero, work, B, Ho, Wo, stride, st);
 }
 
 static unsigned stream_grid(long work_items) {

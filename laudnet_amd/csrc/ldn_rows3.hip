@@ -30,7 +30,8 @@ struct Rows3Args {
     int mtn, ntn;
 };
 
-__device__ __attribute__((aligned(16))) float g_rows3_zero[1024] = {0.f};      // a whole zero ROW (cin <= 1024): a missing neighbour is a row base like any other
+constexpr int ROWS3_MAX_CIN = 2048;      // widest input the zero row covers (ldn_conv3x3_rows_ps requires cin <= ROWS3_MAX_CIN; ops.rows_ps_ok mirrors it)
+__device__ __attribute__((aligned(16))) float g_rows3_zero[ROWS3_MAX_CIN] = {0.f};      // a whole zero ROW: a missing neighbour is a row base like any other
 #ifdef LDN_TRACE   // tuning only: per-wave cycle split of the K loop (tools/trace_rows3.py)
 __device__ unsigned long long* g_rows3_trace = nullptr;
 #define RT(x) x = __builtin_amdgcn_s_memtime();
@@ -333,15 +334,13 @@ extern "C" int ldn_debug_set_rows3_trace(void* buf) {
 }
 #endif
 
-static thread_local long g_rows3_hint = -1;
-
 // The packed 3x3 of the spatial / layer path on pre-split rows (see the header of this file and include/ldn_hip.h).
 extern "C" int ldn_conv3x3_rows_ps(const void* a_presplit, int lda, const int32_t* nbr, const int32_t* m_count, int m_cap, const void* w_split,
                                    int cin, int cout, const float* scale, const float* shift, int relu, void* out, int ldo, int out_presplit,
                                    int rows_hint, void* stream) {
-    (void)g_rows3_hint;
     LDN_REQUIRE(a_presplit && nbr && w_split && shift && out, "ldn_conv3x3_rows_ps: null pointer");
     LDN_REQUIRE(cin > 0 && cin % 64 == 0 && cout > 0 && cout % 64 == 0, "ldn_conv3x3_rows_ps: cin and cout must be multiples of 64 (got %d, %d)", cin, cout);
+    LDN_REQUIRE(cin <= ldn::ROWS3_MAX_CIN, "ldn_conv3x3_rows_ps: cin must be <= %d (a missing neighbour is sourced from a zero row of that width; got %d -- use ldn_conv_rows_split(taps = 9))", ldn::ROWS3_MAX_CIN, cin);
     LDN_REQUIRE(lda >= cin && lda % 4 == 0 && ldo >= cout && ldo % 4 == 0, "ldn_conv3x3_rows_ps: strides (in 4-byte elements) must be multiples of 4 and cover the row");
     LDN_REQUIRE((uintptr_t)a_presplit % 16 == 0 && (uintptr_t)w_split % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)shift % 16 == 0 &&
                 (uintptr_t)scale % 16 == 0, "ldn_conv3x3_rows_ps: pointers must be 16-byte aligned");

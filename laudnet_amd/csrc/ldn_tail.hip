@@ -1737,6 +1737,17 @@ static int launch_chain(ChainArgs& a, hipStream_t st) {
         // LDN_CHAIN_LD=0 keeps round 5's kernel (A/B measurements).
         static const bool use_ld = [] { const char* e = getenv("LDN_CHAIN_LD"); return !(e && atoi(e) == 0); }();
         if (use_ld && nr <= 224) {
+            {   // once per device (and never inside a graph capture): the kernel learns the address of the process's fault word
+                static bool armed[64] = {};
+                int dev = 0;
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !armed[dev] && hipStreamIsCapturing(st, &cs) == hipSuccess &&
+                    cs == hipStreamCaptureStatusNone) {
+                    int* d = fault_word_dev();
+                    if (d && hipMemcpyToSymbol(HIP_SYMBOL(g_ld_fault_dev), &d, sizeof(d)) == hipSuccess) armed[dev] = true;
+                    else (void)hipGetLastError();
+                }
+            }
             LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_chain_ld<NS>), lds), "k_chain_ld: cannot reserve %zu B of LDS", lds);
             hipLaunchKernelGGL((k_chain_ld<NS>), dim3((unsigned)a.B), dim3(512), lds, st, a);
             LDN_CHECK_LAUNCH("k_chain_ld");

@@ -142,11 +142,30 @@ def ranks_seen(device=None, group=None) -> int:
 
 
 def gpu_numa_node(local_rank: int):
-    """NUMA node of the local_rank-th visible AMD GPU from sysfs (/sys/class/drm/card*/device/numa_node), or None when the platform
-    does not say (single-node hosts report -1)."""
+    """NUMA node of the GPU this rank computes on, or None when the platform does not say (single-node hosts report -1).  Resolved from the
+    device's PCI bus id as the HIP runtime reports it (torch.cuda.get_device_properties(i).pci_bus_id -> /sys/bus/pci/devices/<bdf>/numa_node):
+    the order of /sys/class/drm/card* is neither numeric under sorted() (card10 < card2) nor guaranteed to be HIP's device order.
+    Without a visible device (CPU tests) the DRM cards are walked in NUMERIC order as a best effort."""
+    try:
+        if torch.cuda.is_available() and local_rank < torch.cuda.device_count():
+            pr = torch.cuda.get_device_properties(local_rank)       # (HIP_VISIBLE_DEVICES is already applied: ordinal local_rank IS this rank's GPU)
+            bdf = getattr(pr, "pci_bus_id", None)
+            dom = getattr(pr, "pci_domain_id", 0) or 0
+            dev_id = getattr(pr, "pci_device_id", 0) or 0
+            if isinstance(bdf, int):
+                bdf = f"{dom:04x}:{bdf:02x}:{dev_id:02x}.0"
+            if isinstance(bdf, str) and bdf:
+                if bdf.count(":") == 1:
+                    bdf = "0000:" + bdf
+                node = int(open(f"/sys/bus/pci/devices/{bdf.lower()}/numa_node").read().strip())
+                return node if node >= 0 else None
+    except (OSError, ValueError, RuntimeError, AttributeError):
+        pass
     import glob
+    import re
     cards = []
-    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+    paths = glob.glob("/sys/class/drm/card[0-9]*/device")
+    for d in sorted(paths, key=lambda q: int(re.search(r"card(\d+)", q).group(1))):
         try:
             if open(os.path.join(d, "vendor")).read().strip() != "0x1002":      # AMD
                 continue

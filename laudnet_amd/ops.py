@@ -136,6 +136,7 @@ class IndexSet:
     cap3: int
     cap1: int
     patch_major: bool = False     # idx3 lists the kept pixels patch by patch (ldn_mask_plan): whole patches are consecutive packed rows
+    work_vouched: bool = False    # the list build's work buffer is the shared zeroed one (_vouched_call)
 
 
 def _empty_index(B, out_h, out_w, stride, dev, plan_S=None):
@@ -153,18 +154,41 @@ def _empty_index(B, out_h, out_w, stride, dev, plan_S=None):
         work = _PLAN_WORK.get(key)
         if work is None or work.numel() < nwork:
             work = _PLAN_WORK[key] = torch.zeros(max(nwork, 4096), **i32)
-        lib.ldn_plan_work_zeroed(1)
+        ix.work_vouched = True      # the caller arms ldn_plan_work_zeroed right in front of its library call (_vouched_call)
         return ix, work
     return ix, torch.empty(nwork, **i32)
+
+
+def _vouched_call(ix, fn):
+    """Run fn() -- ONE list-build call of the library -- with `ldn_plan_work_zeroed(1)` armed when ix's work buffer is the shared zeroed one.  The
+    flag is per-thread state that the call consumes; an exception raised before the call happens must not leave it armed for an unrelated later
+    call, hence the finally."""
+    vouched = getattr(ix, "work_vouched", False)
+    lib = L.load()
+    if vouched:
+        lib.ldn_plan_work_zeroed(1)
+    try:
+        return fn()
+    finally:
+        if vouched:
+            lib.ldn_plan_work_zeroed(0)
 
 
 _PLAN_WORK = {}
 USE_CLEAN_PLAN_WORK = os.environ.get("LDN_PLAN_CLEAN_WORK", "1") != "0"    # tuning switch (A/B): "0" = a fresh work buffer + a zeroing launch per list build
 
 
+def _atoi(text):
+    """C's atoi: leading blanks, an optional sign, digits; 0 when there are none."""
+    import re
+    m = re.match(r"\s*([+-]?\d+)", text)
+    return int(m.group(1)) if m else 0
+
+
 def _plan_path(lib, S, Sx, out_h, out_w, stride):
     """Will ldn_mask_plan / ldn_mask_to_index build these lists in ONE launch (k_plan)?  (mirrors the library's own choice)"""
-    if os.environ.get("LDN_INDEX_BANDS") or os.environ.get("LDN_INDEX_PLAN", "1") == "0":
+    plan_env = os.environ.get("LDN_INDEX_PLAN")
+    if "LDN_INDEX_BANDS" in os.environ or (plan_env is not None and _atoi(plan_env) == 0):      # (the library's own tests: getenv != NULL, atoi == 0)
         return False
     return bool(lib.ldn_mask_plan_fits(int(S), int(Sx), int(out_h), int(out_w), int(stride)))
 
@@ -185,7 +209,7 @@ def plan_timeouts(reset=False, raise_on_error=False):
     healthy device; such a launch leaves EMPTY lists, never uninitialised ones).  Synchronises the device."""
     import ctypes
     n = ctypes.c_int(0)
-    L.check(L.load().ldn_plan_timeouts(ctypes.byref(n), 1 if reset else 0), "ldn_plan_timeouts")
+    L.check(L.load().ldn_plan_timeouts(ctypes.byref(n), 1 if reset else 0), "ldn_plan_timeouts", fault_ok=True)
     if raise_on_error and n.value:
         raise L.LdnError(f"{n.value} list-build launches ran into their time bound: their blocks saw empty pixel lists (results invalid)")
     return n.value
@@ -208,14 +232,16 @@ def mask_to_index(patch_mask, out_h, out_w, stride, patch_major=False):
     ix, work = _empty_index(B, out_h, out_w, stride, patch_mask.device, plan_S=(S, Sx) if (patch_major or S > 1 or Sx > 1 or os.environ.get("LDN_INDEX_GENERIC")) else None)
     if patch_major:
         ix.patch_major = True
-        L.check(lib.ldn_mask_plan(L.ptr(_f32c(patch_mask, "patch_mask")), None, 0, None, None, None, None, B, S, Sx, out_h, out_w,
+        pm = _f32c(patch_mask, "patch_mask")
+        L.check(_vouched_call(ix, lambda: lib.ldn_mask_plan(L.ptr(pm), None, 0, None, None, None, None, B, S, Sx, out_h, out_w,
                                   stride, 1, L.ptr(ix.idx3), L.ptr(ix.pos3), L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr),
-                                  L.ptr(ix.cnt), L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr()),
+                                  L.ptr(ix.cnt), L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr())),
                 "ldn_mask_plan")
         return ix
-    L.check(lib.ldn_mask_to_index(L.ptr(_f32c(patch_mask, "patch_mask")), B, S, Sx, out_h, out_w, stride, L.ptr(ix.idx3),
+    pm = _f32c(patch_mask, "patch_mask")
+    L.check(_vouched_call(ix, lambda: lib.ldn_mask_to_index(L.ptr(pm), B, S, Sx, out_h, out_w, stride, L.ptr(ix.idx3),
                                   L.ptr(ix.pos3), L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr), L.ptr(ix.cnt),
-                                  L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr()),
+                                  L.ptr(ix.pre3), L.ptr(ix.pre1), L.ptr(ix.stats), L.ptr(work), L.stream_ptr())),
             "ldn_mask_to_index")
     return ix
 
@@ -261,10 +287,11 @@ def mask_plan(pool, weight, bias, out_h, out_w, stride=1, patch_major=True, want
     ix.patch_major = bool(patch_major)
     mask = torch.empty(B, 1, S, Sx, device=dev, dtype=torch.float32)
     logits = torch.empty(B, 2, S, Sx, device=dev, dtype=torch.float32) if want_logits else None
-    L.check(lib.ldn_mask_plan(None, L.ptr(_f32c(pool, "pool")), C, L.ptr(_f32c(weight, "w")), L.ptr(_f32c(bias, "bias")), L.ptr(mask),
+    pl, wt, bs = _f32c(pool, "pool"), _f32c(weight, "w"), _f32c(bias, "bias")
+    L.check(_vouched_call(ix, lambda: lib.ldn_mask_plan(None, L.ptr(pl), C, L.ptr(wt), L.ptr(bs), L.ptr(mask),
                               L.ptr(logits), B, S, Sx, out_h, out_w, stride, 1 if patch_major else 0, L.ptr(ix.idx3), L.ptr(ix.pos3),
                               L.ptr(ix.idx1), L.ptr(ix.pos1), L.ptr(ix.nbr), L.ptr(ix.cnt), L.ptr(ix.pre3), L.ptr(ix.pre1),
-                              L.ptr(ix.stats), L.ptr(work), L.stream_ptr()), "ldn_mask_plan")
+                              L.ptr(ix.stats), L.ptr(work), L.stream_ptr())), "ldn_mask_plan")
     return mask, logits, ix
 
 
@@ -482,10 +509,15 @@ def conv_rows(a2d, w, scale, shift, out2d, *, a_rows=None, taps=1, m_count=None,
 USE_ROWS_PS = os.environ.get("LDN_ROWS_PS", "1") != "0"      # the pre-split packed path (k_dense<PS / OF> + k_rows3); 0 = round 4's three launches
 
 
+ROWS_PS_MAX_WIDTH = 2048     # = ROWS3_MAX_CIN of csrc/ldn_rows3.hip
+
+
 def rows_ps_ok(cin, width, cout):
     """Can a spatial / layer block keep h1 / h2 pre-split between its launches (ldn_conv_rows_ps + ldn_conv3x3_rows_ps)?  bf16x3 mode on
-    the k_dense path, widths the kernels tile (conv1: cin % 32, width % 64; 3x3: width % 64; conv3: cout % 64)."""
-    return (USE_ROWS_PS and USE_DENSE_KERNEL and get_math_mode() == "bf16x3" and cin % 32 == 0 and width % 64 == 0 and cout % 64 == 0)
+    the k_dense path, widths the kernels tile (conv1: cin % 32, width % 64; 3x3: width % 64 and width <= 2048 -- ldn_conv3x3_rows_ps reads a
+    missing neighbour from a zero row of that width; conv3: cout % 64).  Wider blocks take conv_rows(taps=9)."""
+    return (USE_ROWS_PS and USE_DENSE_KERNEL and get_math_mode() == "bf16x3" and cin % 32 == 0 and width % 64 == 0 and width <= ROWS_PS_MAX_WIDTH
+            and cout % 64 == 0)
 
 
 def conv_rows_ps(a2d, w, scale, shift, out2d, *, a_presplit=False, out_presplit=False, a_rows=None, m_count=None, m_cap=None, relu=1,

@@ -135,7 +135,7 @@ def _header_prototypes():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     protos = {}
-    for m in re.finditer(r"\b(?:int|size_t|const\s+char\s*\*)\s+(ldn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t|const\s+char\s*\*|const\s+int\s*\*)\s*(ldn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text, flags=re.S):
         name, args = m.group(1), m.group(2).strip()
         kinds = []
         if args and args != "void":

@@ -247,6 +247,9 @@ def run_secondary(args):
                       "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches")} if roof else None,
                       "parity": d["config"].get("parity", "pinned (reference-generated fixtures, tests/golden)"),
                       "wall_s": round(time.perf_counter() - t0, 1)}
+            for k in ("same_kernels_keep_1.0", "alternating_batches"):
+                if k in d:
+                    out[w][k] = d[k]
             for k in ("roofline_rows_3x3", "mi355x_model", "predicted_speedup"):
                 if k in d:
                     v = d[k]
@@ -962,9 +965,38 @@ def main():
         ops.set_math_mode(args.math)
         out = step()   # leave the modules' last_*_mask in the headline mode for the same-mask parity leg below
         torch.cuda.synchronize()
-    if (rank == 0 and world == 1 and not args.no_legs and not args.graph and not args.brief
+    if (rank == 0 and world == 1 and not args.no_legs and not args.graph and wl["p_spatial"] is not None):
+        # Two DIFFERENT batches alternating: the timed region replays one resident batch, so the row-count hints the
+        # packed-row kernels size their tiles with (ops.RowsHint = the PREVIOUS forward's device-side counts) are exact there.  Here every forward
+        # sees the counts of the other batch: the hint is stale by one forward, as on a stream of real batches.  Results are hint-independent
+        # (tests); this leg measures what the staleness costs.
+        try:
+            x_other = seeded_randn((args.batch, 3, 224, 224), 2000 + rank).to(dev).contiguous(memory_format=torch.channels_last)
+            pair = (x, x_other)
+            with torch.no_grad():
+                for i in range(4):
+                    model(pair[i & 1], 1.0)
+                torch.cuda.synchronize()
+                n_alt = max(6, min(args.steps, 20)) & ~1
+                t0 = time.perf_counter()
+                for i in range(n_alt):
+                    o_alt = model(pair[i & 1], 1.0)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n_alt
+                ratios = [float(model(pair[i], 1.0)[5].float().mean().item()) for i in range(2)]
+            result["alternating_batches"] = {"ms_per_step": 1e3 * dt, "value": args.batch / dt, "unit": "images/sec", "steps": n_alt,
+                                             "mean_block_flops_ratio_of_the_two_batches": [round(r, 4) for r in ratios],
+                                             "vs_resident_batch": 1e3 * dt / result["ms_per_step"],
+                                             "note": "two seeded batches alternate: every forward's row-count hints are the other batch's counts"}
+            del x_other, o_alt
+            out = step()     # the resident batch's masks again (the parity leg below replays them)
+            torch.cuda.synchronize()
+        except Exception as e:   # informative only
+            result["alternating_batches"] = {"error": repr(e)[:200]}
+    if (rank == 0 and world == 1 and not args.no_legs and not args.graph
             and (wl["p_channel"] is not None or wl["p_spatial"] is not None)):
         # the SAME kernels with every unit kept (maskers recalibrated to keep 1.0): what the dynamic masks buy on this implementation
+        # (in --brief runs too since round 6: the secondary legs report it as `mi355x_model.realised_speedup_of_the_masks`)
         try:
             calibrate_maskers(model, x, 1.0 if wl["p_channel"] is not None else None, 1.0 if wl["p_spatial"] is not None else None)
             for _ in range(2):

@@ -215,6 +215,54 @@ def measure_chain_traffic(keep, batch):
                       "--warmup 1 --no-legs` right after the timed region; FETCH_SIZE doubled per MI355X_MICROARCH.md"}
 
 
+KIND_KERNELS = {"rows_1x1": ("k_dense",), "rows_3x3": ("k_rows3",), "tail_fused": ("k_tail",), "grouped16_img": ("k_grouped16_img",),
+                "conv2_3x3": ("k_conv_bf3", "k_conv_image"), "conv3_1x1": ("k_conv1x1_stream",)}
+
+
+def measure_kind_traffic(workload, kind, keep, batch):
+    """Mean HBM traffic PER LAUNCH of the kernels behind one roofline kind (KIND_KERNELS) on this box: the two PMC passes of measure_chain_traffic
+    over `bench.py --workload W --no-legs`, averaged over every dispatch of those kernels in the profiled run (the roofline object of an
+    aggregated kind -- "all shared-weight 1x1 launches of a step" -- averages its algorithmic bytes over the same launches)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    pats = KIND_KERNELS.get(kind)
+    if not os.path.exists(exe) or not pats:
+        return None
+    vals, n_disp = {}, 0
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ldn_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--workload", workload,
+                   "--steps", "2", "--warmup", "1", "--no-legs", "--batch", str(batch), "--keep", repr(float(keep))]
+            subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", LDN_BENCH_NO_EVENTS="1"))
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None
+            where = " or ".join("kernel_name like ?" for _ in pats)
+            rows = sqlite3.connect(dbs[0]).execute(f"select dispatch_id, value from counters_collection where counter_name = ? and ({where})",
+                                                   (ctr,) + tuple(f"%{q}%" for q in pats)).fetchall()
+            per = {}
+            for disp, v in rows:
+                per[disp] = per.get(disp, 0.0) + v
+            if not per:
+                return None
+            vals[ctr] = sum(per.values()) / len(per)     # KiB per dispatch, mean over the run's launches of these kernels
+            n_disp = len(per)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"traffic_bytes_per_launch": int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "fetch_kib_raw": vals["FETCH_SIZE"],
+            "write_kib": vals["WRITE_SIZE"], "dispatches_averaged": n_disp, "kernels": list(pats),
+            "scope": f"mean over the {n_disp} launches of {' / '.join(pats)} in a profiled `bench.py --workload {workload} --steps 2 --warmup 1 --no-legs` "
+                     "(calibration pass + three forwards); counted at the L2-fabric boundary (Infinity-Cache hits included)",
+            "source": "two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE), FETCH_SIZE doubled per MI355X_MICROARCH.md"}
+
+
 SECONDARY = ("spatial", "layer", "regnet", "adavit")     # BASELINE.json configs[2], the layer-skip ResNet, configs[3] (per-GPU shard), configs[4]
 
 
@@ -244,7 +292,8 @@ def run_secondary(args):
                       "realised_speedup_vs_dense_emulation": d.get("realised_speedup_vs_dense_emulation"),
                       "max_abs_diff_vs_oracle_same_masks": de.get("max_abs_logit_diff_vs_hip_same_masks", de.get("max_abs_diff_vs_hip_same_masks")),
                       "output_scale": de.get("logit_scale", de.get("output_scale")),
-                      "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches")} if roof else None,
+                      "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches", "traffic", "traffic_over_algorithmic",
+                                                                 "traffic_source", "algorithmic_mbytes_per_launch")} if roof else None,
                       "parity": d["config"].get("parity", "pinned (reference-generated fixtures, tests/golden)"),
                       "wall_s": round(time.perf_counter() - t0, 1)}
             for k in ("same_kernels_keep_1.0", "alternating_batches"):
@@ -613,6 +662,8 @@ def main():
                     "keep-1.0 / hipGraph legs, no decision audits, no CPU baseline): what the headline run uses for its `secondary` workloads")
     ap.add_argument("--no-pmc", action="store_true", help="headline run: quote the committed PMC pass of profiles/ for `roofline.traffic` instead of "
                     "measuring it in this run (two rocprofv3 --pmc passes, ~1.5 min)")
+    ap.add_argument("--pmc-legs", action="store_true", help="measure `roofline.traffic` of the dominant kernel kind of a non-headline workload live "
+                    "(two rocprofv3 --pmc passes, ~1.5 min); default: the committed pass of profiles/rNN_traffic.json is quoted")
     ap.add_argument("--no-secondary", action="store_true", help="headline run: do not append the `secondary` dict (BASELINE configs 3-5 "
                     "timed in the same invocation)")
     ap.add_argument("--graph", action="store_true", help="time the forward replayed as one hipGraph (same kernels, no launch "
@@ -913,6 +964,27 @@ def main():
                                   event_leg_ms_per_step=ev_ms)
         for k in order[1:]:
             result["roofline_" + k] = dict(objs[k], timed_ms_per_step=per_step(k), steps_bracketed=len(timer.steps_of.get(k, ())))
+        if result["roofline"].get("traffic") is None and order[0] != "chain_fused":
+            #  the wasted-traffic ratio of the dominant kind of the other workloads: measured here with --pmc-legs,
+            # else quoted from the latest committed pass (profiles/rNN_traffic.json, key "<workload>:<kind>")
+            import glob as _glob
+            key = f"{args.workload}:{order[0]}"
+            tr = measure_kind_traffic(args.workload, order[0], keep_used, args.batch) if (args.pmc_legs and world == 1) else None
+            if tr is not None:
+                tr["source"] = "MEASURED IN THIS RUN: " + tr["source"]
+            else:
+                tjs_ = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+                tr = (json.load(open(tjs_[-1])).get(key) if tjs_ and args.batch == 256 else None)
+                if tr is not None:
+                    tr = dict(tr, source="committed PMC pass (" + os.path.basename(tjs_[-1]) + "), NOT measured in this run: " + tr.get("source", ""))
+            if tr is not None:
+                result["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                result["roofline"]["traffic_scope"] = tr.get("scope")
+                result["roofline"]["traffic_source"] = tr.get("source")
+                alg = result["roofline"].get("algorithmic_mbytes_per_launch")
+                if alg:
+                    result["roofline"]["traffic_over_algorithmic"] = tr["traffic_bytes_per_launch"] / (alg * 1e6)
+                result["roofline"]["traffic_detail"] = {k_: tr.get(k_) for k_ in ("fetch_kib_raw", "write_kib", "dispatches_averaged", "kernels")}
 
     result["block_densities"] = block_densities
     result.setdefault("roofline", None)   # workloads whose hot kernels are not timed per launch (RegNet grouped conv, --graph)

@@ -55,26 +55,33 @@ def transposed_neighbour_table(ix, B, H, W, stride=1, Ho=None, Wo=None):
     rem = pix - b * (H * W)
     iy, ixx = rem // W, rem - (rem // W) * W
     pos3 = ix.pos3.view(-1).long()
-    out = torch.full((cap1, 9), -1, dtype=torch.int32, device=dev)
-    for t in range(9):
-        ny, nx = iy - (t // 3 - 1), ixx - (t % 3 - 1)       # = stride * oy, stride * ox
-        oy, ox = torch.div(ny, stride, rounding_mode="floor"), torch.div(nx, stride, rounding_mode="floor")
-        ok = (ny >= 0) & (nx >= 0) & (oy * stride == ny) & (ox * stride == nx) & (oy < Ho) & (ox < Wo)
-        q = (b * (Ho * Wo) + oy.clamp(0, Ho - 1) * Wo + ox.clamp(0, Wo - 1)).clamp(0, pos3.numel() - 1)
-        out[:, t] = torch.where(ok, pos3[q], torch.full_like(pos3[q], -1)).to(torch.int32)
+    taps = torch.arange(9, device=dev)
+    dy, dx = taps // 3 - 1, taps % 3 - 1                     # all nine taps at once: [cap1, 9] tensors, a dozen launches instead of a hundred
+    ny, nx = iy[:, None] - dy[None, :], ixx[:, None] - dx[None, :]      # = stride * oy, stride * ox
+    oy, ox = torch.div(ny, stride, rounding_mode="floor"), torch.div(nx, stride, rounding_mode="floor")
+    ok = (ny >= 0) & (nx >= 0) & (oy * stride == ny) & (ox * stride == nx) & (oy < Ho) & (ox < Wo)
+    q = (b[:, None] * (Ho * Wo) + oy.clamp(0, Ho - 1) * Wo + ox.clamp(0, Wo - 1)).clamp(0, pos3.numel() - 1)
+    out = torch.where(ok, pos3[q], torch.full_like(q, -1)).to(torch.int32)
     valid = torch.arange(cap1, device=dev) < ix.cnt[1]
     return torch.where(valid[:, None], out, torch.full_like(out, -1)).contiguous()
+
+
+_DENSE_IX = {}
+
+
+def _dense_lists(B, Ho, Wo, stride, dev):
+    """Index lists of an all-active batch, cached per shape (Bottleneck._dense_ix)."""
+    key = (B, Ho, Wo, stride, str(dev))
+    if key not in _DENSE_IX:
+        if len(_DENSE_IX) > 64:
+            _DENSE_IX.clear()
+        _DENSE_IX[key] = ops.mask_to_index(torch.ones(B, 1, 1, device=dev), Ho, Wo, stride)
+    return _DENSE_IX[key]
 
 
 def _rows_valid(n_cap, count, dev):
     """[n_cap, 1] float mask of the rows in front of a device-side count (no host read)."""
     return (torch.arange(n_cap, device=dev) < count).to(torch.float32).unsqueeze(1)
-
-
-def _gathered(src, nbr_col, zero_row_index):
-    """rows of `src` (with a zero row appended at zero_row_index) through one column of a neighbour table (-1 = the zero row)."""
-    idx = nbr_col.long()
-    return src[torch.where(idx >= 0, idx, torch.full_like(idx, zero_row_index))]
 
 
 def _weight_grad_3x3(du2, h1, nbr, cap1, count3=None):
@@ -85,12 +92,10 @@ def _weight_grad_3x3(du2, h1, nbr, cap1, count3=None):
     nb = nbr.view(-1, 9)
     if count3 is not None:
         nb = torch.where((torch.arange(nb.shape[0], device=nb.device) < count3).unsqueeze(1), nb, torch.full_like(nb, -1))
-    nb = torch.where(nb < cap1, nb, torch.full_like(nb, -1))
-    gw2 = torch.empty(W, h1.shape[1], 3, 3, device=du2.device)
-    du2t = du2.t().contiguous()
-    for t in range(9):
-        gw2[:, :, t // 3, t % 3] = du2t @ _gathered(h1z, nb[:, t], cap1)
-    return gw2
+    nb = torch.where(nb < cap1, nb, torch.full_like(nb, -1)).long()
+    nb = torch.where(nb >= 0, nb, torch.full_like(nb, cap1))
+    cols = h1z[nb.reshape(-1)].view(nb.shape[0], 9 * h1.shape[1])          # [rows, 9 K]: the nine taps' rows side by side -- ONE GEMM
+    return (du2.t() @ cols).view(W, 9, h1.shape[1]).permute(0, 2, 1).reshape(W, h1.shape[1], 3, 3)
 
 
 # ------------------------------------------------------------------------------------------------------------------ pixel masks
@@ -118,13 +123,13 @@ class _PixelBranchFn(torch.autograd.Function):
         ops.conv_rows(h1, w2r, s2, t2, h2, a_rows=ix.nbr, taps=9, m_count=ix.cnt[0:1], m_cap=ix.cap3)
         br = torch.zeros(B * Ho * Wo, cout, device=dev)
         ops.conv_rows(h2, w3s, None, t3, br, taps=1, m_count=ix.cnt[0:1], m_cap=ix.cap3, relu=0, out_rows=ix.idx3)
-        ctx.save_for_backward(x2d, h1, h2, br, w1r, w2r, w3r, s1, t1, s2, t2, s3, t3)
+        ctx.save_for_backward(x2d, h1, h2, br, w1r, w2r, w3r, s1, t1, s2, t2, s3, t3, m3.detach().float())
         ctx.ix, ctx.shape, ctx.stride = ix, (B, Cin, Hi, Wi, Ho, Wo, W, cout), stride
         return ops.from_nhwc(br.view(B, Ho, Wo, cout))
 
     @staticmethod
     def backward(ctx, g):
-        x2d, h1, h2, br, w1r, w2r, w3r, s1, t1, s2, t2, s3, t3 = ctx.saved_tensors
+        x2d, h1, h2, br, w1r, w2r, w3r, s1, t1, s2, t2, s3, t3, m3d = ctx.saved_tensors
         ix, stride = ctx.ix, ctx.stride
         B, Cin, Hi, Wi, Ho, Wo, W, cout = ctx.shape
         dev = g.device
@@ -171,14 +176,16 @@ class _PixelBranchFn(torch.autograd.Function):
         gt3 = g3.sum(0) if need[10] else None
         gm = None
         if need[4]:
-            # straight-through term of the hard mask: the branch at EVERY pixel, by the library's dense execution of the block (all pixels listed)
-            dix = ops.mask_to_index(torch.ones(B, 1, 1, device=dev), Ho, Wo, stride)
-            d1 = torch.empty(dix.cap1, W, device=dev)
-            ops.conv_rows(x2d, w1r, s1, t1, d1, a_rows=dix.idx1, taps=1, m_cap=dix.cap1)
-            d2 = torch.empty(dix.cap3, W, device=dev)
-            ops.conv_rows(d1, w2r, s2, t2, d2, a_rows=dix.nbr, taps=9, m_cap=dix.cap3)
-            full = torch.zeros(B * Ho * Wo, cout, device=dev)
-            ops.conv_rows(d2, w3s.reshape(cout, 1, W).contiguous(), None, t3, full, taps=1, m_cap=dix.cap3, relu=0, out_rows=dix.idx3)
+            # straight-through term of the hard mask: d L / d m3[p] = sum_c g[p, c] * (s3 conv3(..) + t3)[p, c] needs the branch at the DROPPED pixels
+            # too (that term is dense in the reference as well).  The kept pixels' branch is `br`; the dropped ones' comes from the same three
+            # launches over the COMPLEMENT's lists -- together one dense execution of the block, of which the forward already paid the kept part.
+            cix = ops.mask_to_index((1.0 - m3d).reshape(B, Ho, Wo).contiguous(), Ho, Wo, stride)
+            d1 = torch.zeros(cix.cap1, W, device=dev)
+            ops.conv_rows(x2d, w1r, s1, t1, d1, a_rows=cix.idx1, taps=1, m_count=cix.cnt[1:2], m_cap=cix.cap1)
+            d2 = torch.zeros(cix.cap3, W, device=dev)
+            ops.conv_rows(d1, w2r, s2, t2, d2, a_rows=cix.nbr, taps=9, m_count=cix.cnt[0:1], m_cap=cix.cap3)
+            full = br.clone()
+            ops.conv_rows(d2, w3s.reshape(cout, 1, W).contiguous(), None, t3, full, taps=1, m_count=cix.cnt[0:1], m_cap=cix.cap3, relu=0, out_rows=cix.idx3)
             gm = (go * full).sum(dim=1).view(B, 1, Ho, Wo)
         return grad_x, gw1, gw2, gw3, gm, gs1, gt1, gs2, gt2, gs3, gt3, None
 
@@ -221,7 +228,7 @@ class _ChannelBranchFn(torch.autograd.Function):
         w3r = w3f.reshape(cout, W)
         w3s = (w3r * s3.view(-1, 1)).reshape(cout, 1, W).contiguous()
         chm2d = chm.detach().float().reshape(B, W).contiguous()
-        ix = ops.mask_to_index(torch.ones(B, 1, 1, device=dev), Ho, Wo, stride)
+        ix = _dense_lists(B, Ho, Wo, stride, dev)
         fused = ops.dense_kernel_ok() and Cin % 32 == 0 and W % 32 == 0
         h1 = torch.empty(ix.cap1, W, device=dev)
         if fused:

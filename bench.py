@@ -52,6 +52,10 @@ WORKLOADS = {
                     kw=dict(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[4, 4, 2, 1]), p_channel=None, p_spatial=0.5),
     "layer": dict(name="LAUD-ResNet101 layer-skip target-0.5 @224",
                   kw=dict(dyn_mode=["layer"] * 4), p_channel=None, p_spatial=0.5),
+    # BASELINE config 1's model on the GPU: per-pixel masks -- every block runs the stand-alone spatial masker (one
+    # pass over x), no pooled means to carry
+    "spatial_g1": dict(name="LAUD-ResNet50 spatial g=1-1-1-1 (per-pixel masks) target-0.5 @224", arch="uni_resnet50", ref="resnet50_ref",
+                       kw=dict(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[1, 1, 1, 1]), p_channel=None, p_spatial=0.5),
     # BASELINE config 4: the reference rejects dyn_mode='layer' for RegNet; layer skip = spatial with one patch per image
     "regnet": dict(name="LAUD-RegNetY-800MF layer-skip target-0.5 @224", arch="lad_regnet_y_800mf",
                    kw=dict(dyn_mode=["spatial"] * 4, mask_spatial_granularity=[56, 28, 14, 7]), p_channel=None, p_spatial=0.5),
@@ -1089,7 +1093,9 @@ def main():
         torch.cuda.synchronize()
     if rank == 0 and world == 1:
         from oracle import torch_ref as TR
-        if "arch" in wl:
+        if "ref" in wl:
+            ref = getattr(TR, wl["ref"])(**kw).eval()
+        elif "arch" in wl:
             from oracle import regnet_ref as RR
             ref = RR.regnet_y_ref(wl["arch"], **kw).eval()
         else:

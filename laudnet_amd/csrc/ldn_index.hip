@@ -158,6 +158,85 @@ __global__ __launch_bounds__(256) void k_spatial_masker(const float* __restrict_
     }
 }
 
+// Per-PIXEL masks (mask_size == the map: models/utils.py:48 takes x itself, BASELINE config 1's granularity 1-1-1-1): k_spatial_masker gives
+// every pixel its own wave with ONE 16-byte load per lane in flight -- latency-bound at 1.9 TB/s, 30 % of a LAUD-ResNet50 g = 1 forward
+// (round 6, profiles/r06_spatial_g1_kernel_stats.txt).  Here a wave walks PX consecutive pixels with all of their rows requested before the
+// first dot product; per pixel the arithmetic (lane l: channels 4 l + 256 k, dot4, the xor-butterfly wave sum, + bias, l_keep >= l_drop) is
+// k_spatial_masker's: identical logits and decisions.  C % 4 == 0.
+// Sixteen values per lane summed over the wave with 18 exchanges instead of 16 x 6: at the level that pairs lanes l and l ^ M a lane hands over
+// the half of its values its partner keeps.  Per value the additions are the xor-butterfly's (levels 32, 16, 8, 4, 2, 1, own + partner at each):
+// bit-identical to wave_sum.  Returns the total of value index ((lane >> 2) & 15) (bit 5 of the lane = bit 3 of the index, ...).
+__device__ __forceinline__ float wave_sum16(float (&v)[16]) {
+    const int lane = threadIdx.x & 63;
+    float u8[8], u4[4], u2[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float recv = __shfl_xor(b5 ? v[i] : v[i + 8], 32, 64);
+        u8[i] = (b5 ? v[i + 8] : v[i]) + recv;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float recv = __shfl_xor(b4 ? u8[i] : u8[i + 4], 16, 64);
+        u4[i] = (b4 ? u8[i + 4] : u8[i]) + recv;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float recv = __shfl_xor(b3 ? u4[i] : u4[i + 2], 8, 64);
+        u2[i] = (b3 ? u4[i + 2] : u4[i]) + recv;
+    }
+    float r = (b2 ? u2[1] : u2[0]) + __shfl_xor(b2 ? u2[0] : u2[1], 4, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
+template <int PX, int G2>      // PX * G2 == 16: (8 pixels, one mask group) or (4 pixels, two mask groups)
+__global__ __launch_bounds__(256) void k_pixel_masker(const float* __restrict__ x, int B, int HW, int C, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ mask, float* __restrict__ logits) {
+    static_assert(PX * G2 == 16, "sixteen sums per wave");
+    constexpr int g = G2 / 2;
+    const int lane = threadIdx.x & 63;
+    const long job = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int per_img = (HW + PX - 1) / PX;
+    if (job >= (long)B * per_img) return;
+    const int b = (int)(job / per_img), p0 = (int)(job - (long)b * per_img) * PX;
+    const int nk = (C + 255) >> 8;
+    float acc[16];      // value index = pixel * G2 + output
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k = 0; k < nk; ++k) {
+        const int c = lane * 4 + 256 * k;
+        if (c >= C) break;                                   // (C % 4 == 0; lanes beyond a narrow map's channels add nothing, as in the general kernel)
+        f32x4 v[PX];
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            const int pp = min(p0 + i, HW - 1);
+            v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + ((size_t)b * HW + pp) * C + c));
+        }
+        f32x4 wv[G2];
+#pragma unroll
+        for (int o = 0; o < G2; ++o) wv[o] = *reinterpret_cast<const f32x4*>(w + o * C + c);
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+#pragma unroll
+            for (int o = 0; o < G2; ++o) acc[i * G2 + o] += dot4(wv[o], v[i]);
+    }
+    const float tot = wave_sum16(acc);                       // this lane: value (lane >> 2) & 15 = (pixel, output)
+    const int vi = (lane >> 2) & 15, pix = vi / G2, o = vi % G2;
+    const float mine = tot + bias[o];
+    const float other = __shfl_xor(mine, 4 * g, 64);         // output o ^ g of the same pixel: the other logit of the (keep, drop) pair
+    const int pp = p0 + pix;
+    if ((lane & 3) == 0 && o < g && pp < HW) {
+        const float lk = mine, ld = other;
+        mask[((size_t)b * g + o) * HW + pp] = lk >= ld ? 1.f : 0.f;  // ties keep (utils.py:60)
+        if (logits) {
+            logits[((size_t)b * G2 + o) * HW + pp] = lk;
+            logits[((size_t)b * G2 + g + o) * HW + pp] = ld;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- a4 / a11
 struct IdxGeom {
     int B, S, Sx, Ho, Wo, stride, Hi, Wi;      // patch mask [B][S][Sx]
@@ -1230,6 +1309,20 @@ extern "C" int ldn_spatial_masker(const float* x, int B, int Hi, int Wi, int C, 
         hipLaunchKernelGGL(k_spatial_head, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), work, B, HW,
                            C, splits, w, bias, g, mask, logits);
         LDN_CHECK_LAUNCH("k_spatial_head");
+        return LDN_OK;
+    }
+    if (!pooled && g <= 2 && C % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && !getenv("LDN_PIXEL_MASKER_OLD")) {
+        // per-pixel masks: several pixels' rows in flight per wave, one shared reduction (k_pixel_masker; same logits and decisions as the
+        // general kernel; the patch carry does not exist at this granularity: there are no pooled means to keep)
+        hipStream_t st_ = static_cast<hipStream_t>(stream);
+        if (g == 1) {
+            const long jobs8 = (long)B * ceil_div(Hi * Wi, 8);
+            hipLaunchKernelGGL((k_pixel_masker<8, 2>), dim3((unsigned)((jobs8 + 3) / 4)), dim3(256), 0, st_, x, B, Hi * Wi, C, w, bias, mask, logits);
+        } else {
+            const long jobs4 = (long)B * ceil_div(Hi * Wi, 4);
+            hipLaunchKernelGGL((k_pixel_masker<4, 4>), dim3((unsigned)((jobs4 + 3) / 4)), dim3(256), 0, st_, x, B, Hi * Wi, C, w, bias, mask, logits);
+        }
+        LDN_CHECK_LAUNCH("k_pixel_masker");
         return LDN_OK;
     }
     const long jobs = (long)B * (pooled ? S * S : Hi * Wi);

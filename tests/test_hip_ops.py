@@ -157,6 +157,27 @@ def test_spatial_masker(ops, cin, g, S, hin):
     assert not bool((differs & (margin > 1e-4)).any()), "mask decisions may differ only at near-ties"
 
 
+@pytest.mark.parametrize("cin,g,hin,win", [(256, 1, 14, 14), (256, 2, 9, 20), (512, 1, 7, 7), (1024, 1, 5, 3), (2048, 2, 7, 7), (64, 1, 12, 12), (16, 2, 6, 5), (320, 1, 7, 7)])
+def test_pixel_masker_equals_general_kernel(ops, cin, g, hin, win):
+    """Round 6: per-pixel masks (mask_size == the map, BASELINE config 1) run on k_pixel_masker (eight pixels' rows in flight per wave).  Same
+    arithmetic per pixel as k_spatial_masker: logits and decisions bit-equal (the general kernel is pinned to the oracle above), ragged pixel
+    counts and non-square maps included."""
+    import os
+    torch.manual_seed(cin + hin)
+    w = torch.randn(2 * g, cin, device=DEV)
+    b = torch.randn(2 * g, device=DEV)
+    xn = F.relu(seeded_randn((3, hin, win, cin), 11)).to(DEV).contiguous()
+    mask, logits = ops.spatial_masker(xn, w, b, g, hin, want_logits=True)
+    os.environ["LDN_PIXEL_MASKER_OLD"] = "1"
+    try:
+        mask0, logits0 = ops.spatial_masker(xn, w, b, g, hin, want_logits=True)
+    finally:
+        del os.environ["LDN_PIXEL_MASKER_OLD"]
+    assert torch.equal(logits, logits0) and torch.equal(mask, mask0)
+    want = torch.einsum("bhwc,oc->bohw", xn.double(), w.double()) + b.double().view(1, -1, 1, 1)
+    assert torch.allclose(logits.double(), want, atol=1e-3, rtol=1e-5)
+
+
 @pytest.mark.parametrize("hin,S", [(14, 3), (52, 7), (14, 7), (28, 7)])
 def test_spatial_masker_patch_carry_uneven_grid(ops, hin, S):
     """on an uneven grid (H % S != 0) the adaptive-pool bin of a patch overlaps pixels the nearest mapping gives to a

@@ -1189,9 +1189,9 @@ def main():
     # generated in the build container by importing the reference's DyNetSimulator; committed under profiles/)
     pj = os.path.join(ROOT, "profiles", "predicted_speedup_mi355x.json")
     if os.path.exists(pj):
-        key = {"channel": "channel-2222", "spatial": "spatial S=4-4-2-1", "layer": "ResNet101 layer skip", "regnet": "RegNetY-800MF"}[args.workload]
+        key = {"channel": "channel-2222", "spatial": "spatial S=4-4-2-1", "layer": "ResNet101 layer skip", "regnet": "RegNetY-800MF"}.get(args.workload)
         pd = json.load(open(pj))
-        rows = [r for r in pd["rows"] if key in r["workload"]]
+        rows = [r for r in pd["rows"] if key is not None and key in r["workload"]]
         unc = [r for r in rows if r["mem_bandwidth"].startswith("8.0 TB/s (spec)")]
         cal = [r for r in rows if "calibrated" in r["mem_bandwidth"]]
         if unc:

@@ -26,6 +26,9 @@ namespace ldn {
 #ifndef LDN_LD_R2MAX
 #define LDN_LD_R2MAX 4       // tuning: deepest W2 ring
 #endif
+#ifndef LDN_LD3_ABLATE
+#define LDN_LD3_ABLATE 0      // tuning only (wrong results): conv3 of the chained kernel without 1 = its whole epilogue, 2 = the residual loads and output stores only, 4 = its MFMAs
+#endif
 #ifndef LDN_LD2_STAGED
 #define LDN_LD2_STAGED 0     // conv2's weight tiles through the loader's registers as well: measured SLOWER -- 45 tiles of 20 KB per block are more than one wave can shuffle (4.3 k cycles per tile against the consumers' 2.8 k: conv2 149 k -> 195 k cycles per block); conv2 keeps LDS-DMA into the dense pair layout + per-wave shuffles
 #endif
@@ -998,7 +1001,11 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
         for (int it = 0; it < 4; ++it) {
             const int prow = wave * 32 + trw + 8 * it;
             const float* src = (p.residual && prow < npix) ? p.residual + (size_t)(pix0 + prow) * p.ldr + c0 + tcq * 4 : g_tail_zero;
+#if LDN_LD3_ABLATE & 3
+            res[it] = f32x4{(float)prow, 0.f, 1.f, 2.f};
+#else
             res[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+#endif
         }
         f32x4 sh = *reinterpret_cast<const f32x4*>(p.sh3 + c0 + tcq * 4);
         f32x16 acc3;
@@ -1020,7 +1027,11 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const bf16x8 hb = frag_hi(j, t), lb = frag_lo(j, t);
+#if LDN_LD3_ABLATE & 4
+                    asm volatile("" :: "v"(ah[t]), "v"(al[t]), "v"(hb), "v"(lb));
+#else
                     LDN_K16(false, acc3, ah[t], al[t], hb, lb)
+#endif
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
@@ -1052,6 +1063,10 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
         ld_post_done(sy, wave, base3 + (unsigned)cc + 1u);
         // the residual (and this wave's earlier stores) before this chunk's stores, which then fly through the next chunk (tail_body: gfx9 counts
         // loads and stores in one vmcnt and completes them out of order with each other)
+#if LDN_LD3_ABLATE & 1
+        asm volatile("" :: "v"(acc3), "v"(res[0]), "v"(res[3]), "v"(sh));
+        continue;
+#endif
         wait_vm<0>();
         asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sh));
 #pragma unroll
@@ -1070,7 +1085,9 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
             if (prow < npix) {
+#if !(LDN_LD3_ABLATE & 2)
                 __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p.out + (size_t)(pix0 + prow) * p.ldo + c0 + tcq * 4));
+#endif
                 csum += x;
             }
         }

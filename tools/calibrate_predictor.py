@@ -19,12 +19,13 @@ sys.path.insert(0, ROOT)
 from laudnet_amd.predictor import BlockShape, Calibration, Predictor  # noqa: E402
 
 FIT = (0.25, 0.5, 0.75, 1.0)
-OUT = os.path.join(ROOT, "profiles", "r03_predictor_calibration.json")
+TAG = os.environ.get("ROUND_TAG", "r06")      # which round's sweep (profiles/<TAG>_density_sweep_*.jsonl) -> profiles/<TAG>_predictor_calibration.json
+OUT = os.path.join(ROOT, "profiles", f"{TAG}_predictor_calibration.json")
 
 
 def load(workload):
     pts = []
-    for line in open(os.path.join(ROOT, "profiles", f"r03_density_sweep_{workload}.jsonl")):
+    for line in open(os.path.join(ROOT, "profiles", f"{TAG}_density_sweep_{workload}.jsonl")):
         d = json.loads(line)
         r = d.get("roofline") or {}
         pts.append(dict(keep=d["config"]["keep_probability_calibrated_to"], ms=d["ms_per_step"], bd=d["block_densities"],

@@ -35,9 +35,10 @@ import os
 from dataclasses import dataclass, field
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CALIBRATION = os.path.join(ROOT, "profiles", "r03_predictor_calibration.json")
-if not os.path.exists(CALIBRATION):
-    CALIBRATION = os.path.join(ROOT, "profiles", "r02_predictor_calibration.json")
+import glob as _glob
+
+_cals = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_predictor_calibration.json")))      # the latest round's fit (round 6: re-fitted on the
+CALIBRATION = _cals[-1] if _cals else os.path.join(ROOT, "profiles", "r03_predictor_calibration.json")     # kernels of rounds 5-6: k_dense2 / k_rows3 / k_chain_ld)
 
 
 @dataclass

@@ -29,6 +29,12 @@ namespace ldn {
 #ifndef LDN_LD3_ABLATE
 #define LDN_LD3_ABLATE 0      // tuning only (wrong results): conv3 of the chained kernel without 1 = its whole epilogue, 2 = the residual loads and output stores only, 4 = its MFMAs
 #endif
+#ifndef LDN_LD3_DEFER
+#define LDN_LD3_DEFER 0        // conv3's per-chunk epilogue deferred into the next chunk's K loop (0 = epilogue behind its own K loop)
+#endif
+#ifndef LDN_LD3_STORE_STEP
+#define LDN_LD3_STORE_STEP 1     // K step (n-subtile) of the next chunk behind which a deferred epilogue waits for its residual tile and stores
+#endif
 #ifndef LDN_LD2_STAGED
 #define LDN_LD2_STAGED 0     // conv2's weight tiles through the loader's registers as well: measured SLOWER -- 45 tiles of 20 KB per block are more than one wave can shuffle (4.3 k cycles per tile against the consumers' 2.8 k: conv2 149 k -> 195 k cycles per block); conv2 keeps LDS-DMA into the dense pair layout + per-wave shuffles
 #endif
@@ -150,6 +156,11 @@ __device__ __forceinline__ void wait_vm_rt63(int n) {
 __device__ __forceinline__ u32x4 ld_global16(const unsigned char* sbase, unsigned off) {
     typedef const __attribute__((address_space(1))) u32x4* gptr;
     return *(gptr)(sbase + off);
+}
+
+__device__ __forceinline__ f32x4 ld_global_f4(const float* ptr) {
+    typedef const __attribute__((address_space(1))) f32x4* gptr;
+    return *(gptr)(ptr);
 }
 
 // One LDS-DMA piece (1 KB: 16 bytes per lane) from sbase (wave-uniform) + vo (per-lane byte offset) to LDS lds_base + lane * 16.
@@ -992,6 +1003,106 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
     const unsigned a3_lane = (unsigned)(2 * h * W3_ROW + l31 * 8);
     const unsigned a3q = (unsigned)(h * 1024 + l31 * 16);      // staged form: the lane's channel in the hi plane of lane half h's group
     float* const scr = reinterpret_cast<float*>(s_scr + wave * 4096);   // this wave's 32 x 32 transpose scratch
+#if LDN_LD3_DEFER && LDN_LD3_STAGED
+    // DEFERRED epilogue (round 6, an experiment kept as a switch: measured NEUTRAL, 221-225 us per block either way -- timers around its pieces
+    // show ~1.0 k cycles per chunk of instruction issue (VALU + stores) against ~0.2 k of waiting for the residual tile: the epilogue is issue-bound,
+    // there is no latency to hide).  A chunk's K loop ends with the four
+    // ds_write_b128 of its accumulators into the wave's scratch and the request of its residual tile; everything that has to WAIT -- the transposed
+    // read-back, the residual's arrival, the stores -- is placed between the n-subtile steps of the NEXT chunk's K loop (program order = issue order:
+    // the steps are separate basic blocks), where the MFMAs of this wave and its SIMD partner cover it.  Same values, same order per element.
+    int slot = 0;
+    f32x4 res[4], xr[4], sh;
+    int c0p = 0;                                            // first channel of the chunk whose epilogue is pending
+    auto epi_read = [&]() {                                 // piece 1: the tile back from the scratch in the row layout (written one K loop ago)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = trw + 8 * it;
+            xr[it] = *reinterpret_cast<const f32x4*>(scr + row * 32 + ((tcq ^ (row & 7)) << 2));
+        }
+    };
+    auto epi_store = [&]() {                                // piece 2: + shift + residual, ReLU, store; piece 3: the GAP partials
+        wait_vm<0>();                                       // the residual tile (requested behind the previous K loop) and this wave's earlier stores
+        asm volatile("" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(sh));
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int prow = wave * 32 + trw + 8 * it;
+            f32x4 x = xr[it] + sh + res[it];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+            if (prow < npix) {
+                __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p.out + (size_t)(pix0 + prow) * p.ldo + c0p + tcq * 4));
+                csum += x;
+            }
+        }
+        xr[0] = csum;                                       // (handed to the third piece)
+    };
+    auto epi_gap = [&]() {
+        if (p.colsum) {
+            f32x4 csum = xr[0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[e] = sum_lane_bits_345(csum[e]);
+            if (trw == 0) *reinterpret_cast<f32x4*>(p.colsum + ((size_t)b * 8 + wave) * p.cout + c0p + tcq * 4) = csum;
+        }
+    };
+    for (int cc = 0; cc < nchunk3; ++cc) {
+        const int c0 = cc * LD_CW;
+        const bool pend = cc > 0;                           // (wave-uniform) chunk cc - 1's epilogue is pending
+        f32x16 acc3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+        LD_TIMED(7, ld_wait_landed(sy, base3 + (unsigned)cc + 1u, q.seen))
+        const unsigned char* ws = s_w3 + slot * slot3;
+        slot = slot + 1 == R3 ? 0 : slot + 1;
+        // pieces of the pending epilogue: the read-back behind step 0, the stores behind step js (late: the residual tile then had most of
+        // a K loop to arrive), the GAP partials one step later
+        const int js = min(LDN_LD3_STORE_STEP, nsub - 1), jg = min(js + 1, nsub - 1);
+        bool todo = pend;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if (j < nsub) {
+                bf16x8 ah[2], al[2];      // group 4 j + 2 t + h of the slot: [hi plane 32 channels x 16 B | lo plane]
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ah[t] = *reinterpret_cast<const bf16x8*>(ws + a3q + (4 * j + 2 * t) * 1024);
+                    al[t] = *reinterpret_cast<const bf16x8*>(ws + a3q + (4 * j + 2 * t) * 1024 + 512);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 hb = frag_hi(j, t), lb = frag_lo(j, t);
+                    LDN_K16(false, acc3, ah[t], al[t], hb, lb)
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                if (pend) {
+                    if (j == 0) epi_read();
+                    if (j == js) epi_store();
+                    if (j == jg) { epi_gap(); todo = false; }
+                }
+            }
+        }
+        if (todo) { epi_read(); epi_store(); epi_gap(); }   // (an image without live conv2 channels: no K steps to hide behind)
+        ld_post_done(sy, wave, base3 + (unsigned)cc + 1u);
+        // this chunk's accumulators into the scratch (C layout -> rows of 32 channels per pixel, 16-byte slots XOR-swizzled with the pixel), its
+        // residual tile and shift requested: both are consumed inside the next K loop
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = {acc3[4 * q4], acc3[4 * q4 + 1], acc3[4 * q4 + 2], acc3[4 * q4 + 3]};
+            *reinterpret_cast<f32x4*>(scr + l31 * 32 + (((2 * q4 + h) ^ (l31 & 7)) << 2)) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int prow = wave * 32 + trw + 8 * it;
+            const float* src = (p.residual && prow < npix) ? p.residual + (size_t)(pix0 + prow) * p.ldr + c0 + tcq * 4 : g_tail_zero;
+            res[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+        }
+        sh = ld_global_f4(p.sh3 + c0 + tcq * 4);            // (address space 1: a flat load here makes the compiler drain vmcnt in front of it)
+        c0p = c0;
+    }
+    if (nchunk3 > 0) { epi_read(); epi_store(); epi_gap(); }      // the last chunk's epilogue
+#else
     int slot = 0;
     for (int cc = 0; cc < nchunk3; ++cc) {
         const int c0 = cc * LD_CW;
@@ -1007,7 +1118,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
             res[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
 #endif
         }
-        f32x4 sh = *reinterpret_cast<const f32x4*>(p.sh3 + c0 + tcq * 4);
+        f32x4 sh = ld_global_f4(p.sh3 + c0 + tcq * 4);
         f32x16 acc3;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
@@ -1099,6 +1210,7 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
+#endif
     LT(td)
     LD_SPAN(4, tc, td)
 }

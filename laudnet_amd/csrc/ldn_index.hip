@@ -481,16 +481,30 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(const PlanArgs a) {
         // a wave takes four patches at a time: their rows are in flight together (one patch after the other is one memory latency per
         // patch and wave: 25 patches x ~2 us at stage 1); per patch the arithmetic order is k_spatial_masker's
         const float b0 = a.bias[0], b1 = a.bias[1];
+        // (round 6: the channel loop in blocks of four steps whose 16 row loads are issued together -- one step at a time the loop was a chain
+        // of C / 256 memory latencies per patch group, ~30 us per launch at 1024 channels on the serial path between two blocks; same sums in the
+        // same order)
         for (int p0 = wave * 4; p0 < SS; p0 += NW * 4) {
             float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int c = lane * 4; c < a.C; c += 256) {
-                f32x4 sv[4];
+            const float* rowp[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    sv[u] = p0 + u < SS ? *reinterpret_cast<const f32x4*>(a.pool + ((size_t)b * SS + p0 + u) * a.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.w + c), w1 = *reinterpret_cast<const f32x4*>(a.w + a.C + c);
+            for (int u = 0; u < 4; ++u) rowp[u] = a.pool + ((size_t)b * SS + min(p0 + u, SS - 1)) * a.C;
+            for (int c0 = lane * 4; c0 < a.C; c0 += 1024) {
+                f32x4 sv[4][4], w0[4], w1[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { a0[u] += dot4(w0, sv[u]); a1[u] += dot4(w1, sv[u]); }
+                for (int k = 0; k < 4; ++k) {
+                    const int c = min(c0 + 256 * k, a.C - 4);            // (steps beyond C re-read the last one; their sums are not taken)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sv[k][u] = *reinterpret_cast<const f32x4*>(rowp[u] + c);
+                    w0[k] = *reinterpret_cast<const f32x4*>(a.w + c);
+                    w1[k] = *reinterpret_cast<const f32x4*>(a.w + a.C + c);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c0 + 256 * k < a.C) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { a0[u] += dot4(w0[k], sv[k][u]); a1[u] += dot4(w1[k], sv[k][u]); }
+                    }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

@@ -1,3 +1,5 @@
+# tuning / evidence only: backs the gradient criterion of tests/test_hip_training.py (_close) -- counts the ReLU decisions of the bf16x3 forward that
+# differ from an fp64 evaluation of the same block (pre-activations within rounding of zero) and shows the gradient difference is confined to them.
 import sys, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "tests/golden")
 from helpers import block_input, load_golden, make_block

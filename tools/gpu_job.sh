@@ -5,8 +5,8 @@
 #   tests[:<pytest -k expr>]          pytest -m gpu (optionally filtered)           -> tests.log
 #   testfile:<path>[::k]              one test file                                  -> tests_<name>.log
 #   bench[:<workload>[:extra args]]   bench.py --brief of a workload (default: all legs of the headline when workload = full)
-#   trace:<workload>                  rocprofv3 --kernel-trace --stats over bench.py --no-legs  -> <w>_kernel_stats.txt, period_<w>.txt
-#   pmc:<workload>:<kernel-substr>    MFMA-busy / traffic counters of the matching kernels (separate passes)  -> pmc_<w>.txt
+#   trace:<workload>[:<keep>]         rocprofv3 --kernel-trace --stats over bench.py --no-legs  -> <w>_kernel_stats.txt, period_<w>.txt
+#   pmc:<workload>:<kernel-substr>[:<keep>]  MFMA-busy / traffic counters of the matching kernels (separate passes)  -> pmc_<w>.txt
 #   py:<script and args>              python <script> (tools/*.py micro-benchmarks)  -> py_<n>.log
 #   env:NAME=VALUE                    export for the following steps
 TAG=$1; shift
@@ -66,10 +66,11 @@ except Exception as e:
 PY
       ;;
     trace)
-      w=$rest; steps=3; [ $w = channel ] && steps=5
+      w=${rest%%:*}; kk=${rest#*:}; [ "$kk" = "$rest" ] && kk=""
+      steps=3; [ $w = channel ] && steps=5
       cd /tmp; rm -rf /tmp/prof_$w
       bj=$OUT/bench_$w.json; [ $w = channel ] && bj=$OUT/bench_headline.json
-      KEEP=$(keep_of $bj)
+      KEEP=$(keep_of $bj); [ -n "$kk" ] && KEEP="--keep $kk"
       echo "profiled command: bench.py --workload $w --steps $steps --warmup 2 --no-legs $KEEP" > $OUT/prof_$w.cmd
       # LDN_BENCH_NO_EVENTS: no event-bracketed roofline leg in the profiled run -- its HIP event records show up as ~5.6 us "gaps" behind every
       # bracketed launch (round 5: that is what the "unexplained gap" of earlier rounds was); the trace then holds uninstrumented forwards only
@@ -78,15 +79,15 @@ PY
       [ $w != adavit ] && python $R/tools/rocpd_period.py $(ls /tmp/prof_$w/*.db | head -1) 15 > $OUT/period_$w.txt 2>&1
       head -14 $OUT/${w}_kernel_stats.txt ;;
     pmc)
-      w=${rest%%:*}; pat=${rest#*:}
+      w=${rest%%:*}; pat=${rest#*:}; kk=${pat#*:}; [ "$kk" = "$pat" ] && kk=""; pat=${pat%%:*}
       cd /tmp; rm -f $OUT/pmc_$w.txt
       bj=$OUT/bench_$w.json; [ $w = channel ] && bj=$OUT/bench_headline.json
-      KEEP=$(keep_of $bj)
+      KEEP=$(keep_of $bj); [ -n "$kk" ] && KEEP="--keep $kk"
       for c in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE; do
         rm -rf /tmp/pmc_x
         LDN_BENCH_NO_EVENTS=1 timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_x -o r -- python $R/bench.py --workload $w --steps 2 --warmup 1 --no-legs $KEEP > /tmp/pmc_x.log 2>&1
         echo "== $c (per dispatch; columns in alphabetical order of the counter names; FETCH_SIZE / WRITE_SIZE in KiB)" >> $OUT/pmc_$w.txt
-        python $R/tools/rocpd_pmc.py $(ls /tmp/pmc_x/*.db | head -1) "$pat" 2>&1 | tail -10 >> $OUT/pmc_$w.txt
+        python $R/tools/rocpd_pmc.py $(ls /tmp/pmc_x/*.db | head -1) "$pat" 2>&1 | { read h; echo "$h"; tail -8; } >> $OUT/pmc_$w.txt
       done
       cat $OUT/pmc_$w.txt ;;
     py)

@@ -929,8 +929,8 @@ def main():
             mfma_floor_us = 3.0 * flops / n / (BF16_MFMA_PEAK_TFLOPS * 1e12) * 1e6
             mfma_binds = mfma_floor_us > hbm_floor_us
             tr = traffic.get("chain_fused_bf16x3", {})
-            return {"kernel": "k_chain (one launch = a run of stride-1 channel-mode bottlenecks: masker -> conv1 -> conv2 3x3 -> conv3 "
-                              "+ residual per block, one workgroup per image, bf16x3)",
+            return {"kernel": "k_chain_ld (`ldn::k_chain_ld<8>` in the rocprof stats: the loader / consumer form of k_chain; one launch = a run of "
+                              "stride-1 channel-mode bottlenecks: masker -> conv1 -> conv2 3x3 -> conv3 + residual per block, one workgroup per image, bf16x3)",
                     "bound": "mfma" if mfma_binds else "hbm",
                     "achieved": 3 * tf if mfma_binds else achieved, "peak": BF16_MFMA_PEAK_TFLOPS if mfma_binds else HBM_PEAK_GBS,
                     "unit": "TFLOP/s" if mfma_binds else "GB/s",
@@ -1228,8 +1228,9 @@ def main():
                 sta = P.predict_regnet_layerskip(args.batch, [1.0] * len(bd["s3"]))["ms"]
             else:
                 lm = args.workload == "layer"
-                dyn = P.predict_rows_resnet(args.batch, bd["s3"], bd["s1"], layer_mode=lm)["ms"]
-                sta = P.predict_rows_resnet(args.batch, [1.0] * len(bd["s3"]), [1.0] * len(bd["s1"]), layer_mode=lm)["ms"]
+                lay = (3, 4, 6, 3) if WORKLOADS[args.workload].get("arch", "").endswith("resnet50") else (3, 4, 23, 3)
+                dyn = P.predict_rows_resnet(args.batch, bd["s3"], bd["s1"], layers=lay, layer_mode=lm)["ms"]
+                sta = P.predict_rows_resnet(args.batch, [1.0] * len(bd["s3"]), [1.0] * len(bd["s1"]), layers=lay, layer_mode=lm)["ms"]
             k1 = result.get("same_kernels_keep_1.0", {})
             result["mi355x_model"] = {
                 "predicted_ms_per_step": dyn, "predicted_ms_with_everything_kept": sta, "predicted_speedup_of_the_masks": sta / dyn,
@@ -1238,6 +1239,8 @@ def main():
                 "note": "static baseline = the same HIP kernels with every unit kept (`same_kernels_keep_1.0`, measured in this run); the "
                         "constants were fitted on another box of the pool (boxes differ by up to ~9 %)",
                 "calibration": P.cal.source}
+            if args.workload == "spatial_g1":
+                result["mi355x_model"]["note"] += "; NOT fitted on per-pixel masks (its masker term is the pooled-mean masker's): indicative only"
         except Exception as e:   # informative only
             result["mi355x_model"] = {"error": repr(e)[:200]}
     if (rank == 0 and world == 1 and args.workload == "channel" and not args.no_legs and not args.brief and not args.graph

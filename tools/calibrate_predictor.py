@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Fit the free constants of laudnet_amd/predictor.py to measurements of this repository on MI355X, and validate them OUT OF SAMPLE.
 
-Input : profiles/r03_density_sweep_{channel,spatial,layer,regnet}.jsonl -- bench.py lines (--no-legs, bs256) at seven keep
+Input : profiles/<TAG>_density_sweep_{channel,spatial,layer,regnet}.jsonl -- bench.py lines (--no-legs, bs256) at seven keep
         probabilities (tools/density_sweep.sh on the GPU box): step time, per-block densities (`block_densities`) and, for the channel
         workload, the chained stage-3 launch's time per block (HIP events).
-Output: profiles/r03_predictor_calibration.json -- constants, fit / validation tables.
+Output: profiles/<TAG>_predictor_calibration.json -- constants, fit / validation tables.
 The constants are fitted on the keep probabilities FIT = {0.25, 0.5, 0.75, 1.0} only; {0.4, 0.62, 0.9} are held out and reported as
 `out_of_sample` (tests/test_predictor.py asserts on them)."""
 import json
@@ -96,7 +96,7 @@ def main():
                fitted=["cu_mfma_eff", "act_hbm_eff", "cu_l2_bytes_per_s", "dense_mfma_eff", "fixed_s", "rows_cu_eff", "narrow_alpha", "tile_fixed_s", "rows_hbm_eff",
                        "grouped_eff", "rows_fixed_s", "small_step_s", "small_single_slot"],
                fit_keeps=list(FIT), held_out_keeps=[0.4, 0.62, 0.9],
-               source="profiles/r03_density_sweep_{channel,spatial,layer,regnet}.jsonl (tools/density_sweep.sh on one MI355X; the channel sweep redone after the one-launch stage-4 blocks)",
+               source=f"profiles/{TAG}_density_sweep_{{channel,spatial,layer,regnet}}.jsonl (tools/density_sweep.sh on one MI355X)",
                summary=summary, tables=tables)
     json.dump(out, open(OUT, "w"), indent=1)
     print(json.dumps(dict(constants=consts, summary=summary), indent=1))

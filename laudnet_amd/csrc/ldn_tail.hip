@@ -1497,7 +1497,8 @@ __device__ __forceinline__ void head_body2(const HeadArgs& p, const int b, const
 template <int NS, bool F32 = false>
 __global__ __launch_bounds__(512, 2) void k_head(const HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef LDN_HEAD_V2      // (round 5: measured neutral on the headline -- 12.11-12.26 vs 12.20 ms: conv1 of a channel block is bound by the CU's fetch of x)
+#ifdef LDN_HEAD_V2      // (round 5: measured neutral on the headline -- 12.11-12.26 vs 12.20 ms.  NOT because conv1 is bound by the CU's fetch of x, as this line used to say: DESIGN.md 4v
+                        // retracts that -- the phase keeps its time without DMA and without MFMA; what binds it is the per-chunk serial chain)
     if constexpr (!F32) {
         if (p.xs == nullptr && p.cin % 64 == 0) {     // (wave-uniform) the round-5 staging structure; the x_split by-product keeps the old body
             head_body2<NS>(p, blockIdx.x % p.B, blockIdx.x / p.B, smem, threadIdx.x);

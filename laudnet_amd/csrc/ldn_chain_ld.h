@@ -130,7 +130,13 @@ __device__ __forceinline__ void ld_wait_done(LdSync* sy, int ncomp, unsigned nee
         __builtin_amdgcn_s_sleep(2);
     }
 }
+#ifdef LDN_DEBUG
+__device__ int g_chain_stall = -1;             // test hook (ldn_debug_chain_stall): the loader of this image's workgroup never publishes "landed"
+#endif
 __device__ __forceinline__ void ld_publish(LdSync* sy, unsigned landed) {
+#ifdef LDN_DEBUG
+    if ((int)blockIdx.x == g_chain_stall) return;      // (the DMA itself still runs: consumers time out ONCE, stop waiting, read whatever has landed)
+#endif
     asm volatile("" ::: "memory");
     if ((threadIdx.x & 63) == 0) ld_lds_write(&sy->landed, landed);
     asm volatile("" ::: "memory");

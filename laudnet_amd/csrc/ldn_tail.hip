@@ -1783,6 +1783,14 @@ int tu_chain_stalls(unsigned* count, int reset) {
 }
 }  // namespace ldn
 
+#ifdef LDN_DEBUG
+// test hook of the debug build: the loader wave of workgroup `image` of every following k_chain_ld launch never publishes its "landed" word, so
+// that image's consumer waves run into the bound of their hand-off wait (-1 = off)
+extern "C" int ldn_debug_chain_stall(int image) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(ldn::g_chain_stall), &image, sizeof(image)) == hipSuccess ? LDN_OK : LDN_EHIP;
+}
+#endif
+
 extern "C" int ldn_bottleneck_chain_fits(int H, int Wd, int C, int width, int hidden, int G) {
     if (H < 1 || Wd < 1 || H * Wd > 256 || C < 1 || G < 1 || hidden < 0 || (width != 64 && width != 128 && width != 256)) return 0;
     return ldn::chain_fits(H, Wd, width, C, hidden, G) ? 1 : 0;

@@ -152,3 +152,72 @@ def test_plan_timeout_leaves_empty_lists_and_is_counted():
     assert r["consumer_untouched"]
     assert r["loud"], "the call behind a failed list build must raise (ldn_fault_flag read by _lib.check)"
     assert r["again_equal"] and r["t4"] == 0, "the next launch must be healthy again"
+
+
+CHAIN_STALL_SCRIPT = r"""
+import ctypes, json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests", "golden"))
+import torch
+import laudnet_amd
+import bench
+from fill import fill_state_dict, seeded_randn
+from laudnet_amd import _lib, ops
+lib = _lib.load()
+lib.ldn_debug_chain_stall.argtypes, lib.ldn_debug_chain_stall.restype = [ctypes.c_int], ctypes.c_int
+ops.set_math_mode("bf16x3")
+kw = dict(dyn_mode=["channel"] * 4, channel_dyn_granularity=[2, 2, 2, 2], channel_masker=["MLP"] * 4, channel_masker_layers=[2, 2, 2, 2],
+          reduction_ratio=[16] * 4, num_classes=1000, input_size=224, width_mult=0.5)
+m = laudnet_amd.uni_resnet50(**kw).eval()
+sd = fill_state_dict(m.state_dict(), 3)
+for k in sd:
+    if k.endswith("bn3.weight"):
+        sd[k] = sd[k] * 0.3
+m.load_state_dict(sd)
+m = m.cuda()
+x = seeded_randn((9, 3, 224, 224), 77).cuda().contiguous(memory_format=torch.channels_last)
+bench.calibrate_maskers(m, x, 0.62, None)
+calls = []
+orig = ops.bottleneck_chain
+ops.bottleneck_chain = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+def fwd():
+    with torch.no_grad():
+        o = m(x, 1.0)
+    torch.cuda.synchronize()
+    return o[0].clone()
+res = {"t0": ops.plan_timeouts(reset=True)}
+good = fwd()
+res["chained"] = len(calls)
+res["t1"] = ops.plan_timeouts()
+assert lib.ldn_debug_chain_stall(3) == 0          # image 3's loader never publishes: its seven consumer waves run into the bound once each
+bad = fwd()                                       # (the launch terminates; the image's values are whatever had landed)
+res["t2"] = ops.plan_timeouts()
+res["others_equal"] = bool(torch.equal(bad[[0, 1, 2, 4, 5, 6, 7, 8]], good[[0, 1, 2, 4, 5, 6, 7, 8]]))
+try:
+    fwd()
+    res["loud"] = False
+except _lib.LdnError as e:
+    res["loud"] = "bounded wait" in str(e)
+torch.cuda.synchronize()
+assert lib.ldn_debug_chain_stall(-1) == 0
+res["t3"] = ops.plan_timeouts(reset=True)
+again = fwd()
+res["again_equal"] = bool(torch.equal(again, good))
+res["t4"] = ops.plan_timeouts()
+print("RESULT " + json.dumps(res))
+"""
+
+
+def test_chain_handoff_timeout_terminates_is_counted_and_loud():
+    """The loader / consumer hand-off of k_chain_ld (csrc/ldn_chain_ld.h) spins on LDS words; every spin is bounded.  The debug build's hook makes one
+    image's loader never publish: the launch must TERMINATE, the event must be counted (ldn_plan_timeouts) and LOUD (ldn_fault_flag: the next
+    library call raises), the other images must be untouched, and the next launch must be healthy again."""
+    env = dict(os.environ, LDN_LIB_PATH=os.path.join(ROOT, "laudnet_amd", "libldn_hip_debug.so"))
+    p = subprocess.run([sys.executable, "-c", CHAIN_STALL_SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert r["chained"] >= 1, "stage 3 must have run as a chain"
+    assert r["t0"] == 0 and r["t1"] == 0
+    assert r["t2"] >= 1, "the failed hand-off waits must be counted"
+    assert r["others_equal"], "the images whose hand-offs worked must be bit-identical to the healthy run"
+    assert r["loud"], "the call behind a failed hand-off must raise (ldn_fault_flag read by _lib.check)"
+    assert r["t3"] == r["t2"] and r["again_equal"] and r["t4"] == 0, "the next launch must be healthy again"

@@ -493,6 +493,8 @@ class Bottleneck(_PrepCache):
             h2.view(B, -1, W).mul_(chm)
         cout = p["w3_nk"].shape[0]
         if self.downsample is not None:
+            # (round 6: the projection on the side stream next to conv1 / conv2, as the gathered execution below does, was measured here and does
+            # not pay -- stage 4's first block 644 -> 658 us: these launches are matrix-bound and fill the chip on their own)
             identity = torch.empty(B, Ho, Wo, cout, device=dev, dtype=torch.float32)
             self._shortcut(xn, p, identity)
             out = identity
@@ -840,6 +842,31 @@ class Bottleneck(_PrepCache):
         # round 5: h1 and h2 stay PRE-SPLIT (bf16 hi | lo per octet, the weights' layout) between the three launches -- conv1's epilogue
         # writes h1 that way, the packed 3x3 (k_rows3) and conv3 split nothing in their K loops; same values, bit-identical results
         ps = ops.rows_ps_ok(Cin, W, cout)
+
+        def projection(out2d, groups):
+            # the projection shortcut (laud_resnet.py:138-141) on the output pixels, ReLU applied where no branch output will be added
+            if pool is not None and gS_ds is not None:
+                # the projection's rows cell by cell: its epilogue leaves the mean of every cell (final for the inactive ones; conv3 below
+                # rewrites the active cells and their means)
+                src_pm, out_pm, out_pm_long = self._patch_major_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], gS_ds, dev)
+                ops.conv_rows(x2d, p["wd"], p["sd"], p["td"], out2d, a_rows=src_pm, taps=1, m_cap=ix.cap3, relu=2,
+                              relu_if_neg=ix.pos3.view(-1)[out_pm_long].contiguous(), out_rows=out_pm, pool=pool, pool_grid=(gS_ds, gS_ds, Ho, Wo))
+            else:
+                ds_rows = self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev)
+                for ig, _, cs in groups:   # ReLU directly where the (pixel, group) is inactive: no branch output is added there
+                    ops.conv_rows(x2d, p["wd"][cs], p["sd"][cs], p["td"][cs], out2d[:, cs], a_rows=ds_rows, taps=1, m_cap=ix.cap3,
+                                  relu=2, relu_if_neg=ig.pos3)
+
+        side, out2d_ds = None, None
+        if self.downsample is not None and G == 1 and _USE_SIDE_STREAM:
+            # round 6: it only depends on x and the lists -- on the side stream next to conv1 / the 3x3, joined in front of conv3 (as the channel path
+            # does; the first block of every stage ran it between the 3x3 and conv3)
+            out2d_ds = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
+            cur = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                projection(out2d_ds, [(ix, None, slice(0, cout))])
         h1 = torch.empty(ix.cap1, W, device=dev, dtype=torch.float32)
         h2 = torch.empty(ix.cap3, W, device=dev, dtype=torch.float32)
         if ps:
@@ -861,18 +888,12 @@ class Bottleneck(_PrepCache):
                 rows = torch.where(ar < ig.cnt[0], ix.pos3[ig.idx3.clamp(0, ix.cap3 - 1).long()], torch.full_like(ar, -1))
                 groups.append((ig, rows.contiguous(), slice(g * (cout // G), (g + 1) * (cout // G))))
         if self.downsample is not None:
-            out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
-            if pool is not None and gS_ds is not None:
-                # the projection's rows cell by cell: its epilogue leaves the mean of every cell (final for the inactive ones; conv3 below
-                # rewrites the active cells and their means)
-                src_pm, out_pm, out_pm_long = self._patch_major_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], gS_ds, dev)
-                ops.conv_rows(x2d, p["wd"], p["sd"], p["td"], out2d, a_rows=src_pm, taps=1, m_cap=ix.cap3, relu=2,
-                              relu_if_neg=ix.pos3.view(-1)[out_pm_long].contiguous(), out_rows=out_pm, pool=pool, pool_grid=(gS_ds, gS_ds, Ho, Wo))
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+                out2d = out2d_ds
             else:
-                ds_rows = self._ds_rows(B, Hi, Wi, Ho, Wo, p["ds_stride"], dev)
-                for ig, _, cs in groups:   # ReLU directly where the (pixel, group) is inactive: no branch output is added there
-                    ops.conv_rows(x2d, p["wd"][cs], p["sd"][cs], p["td"][cs], out2d[:, cs], a_rows=ds_rows, taps=1, m_cap=ix.cap3,
-                                  relu=2, relu_if_neg=ig.pos3)
+                out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
+                projection(out2d, groups)
             resid = out2d
         elif self._inplace:
             resid = out2d = x2d          # x >= 0 (post-ReLU) inside the network: inactive pixels pass through

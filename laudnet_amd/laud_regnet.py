@@ -270,6 +270,8 @@ class ResBottleneckBlock(_PrepCache):
             ops.se_packed(h_b, ix.pre3, p["se_w1"], p["se_b1"], p["se_w2"], p["se_b2"], Ho * Wo)
         cout = p["wc"].shape[0]
         if self.proj is not None:
+            # (round 6: on a side stream next to conv a / b, as LAUD-ResNet's spatial path runs its projections, this launch costs more than it
+            # hides here -- 3.22 -> 3.31 ms per forward: RegNet's launches are 30-70 us, the fork / join and the contention outweigh the overlap)
             wp, sp, tp = self._proj(dev)
             out2d = torch.empty(ix.cap3, cout, device=dev, dtype=torch.float32)
             ops.conv_rows(x2d, wp, sp, tp, out2d, a_rows=self._ds_rows(B, Hi, Wi, Ho, Wo, self.stride, dev), taps=1,

@@ -35,6 +35,9 @@ CONFIGS = {
     "r101_spatial4444": dict(factory="uni_resnet101", batch=32, kw=dict(
         dyn_mode=["spatial"] * 4, mask_spatial_granularity=[4, 4, 4, 4])),
     "r101_layer": dict(factory="uni_resnet101", batch=64, kw=dict(dyn_mode=["layer"] * 4)),
+    # BASELINE configs[0]'s model (per-pixel masks: one decision per pixel of every stage) at full width on the GPU -- the maskers run on k_pixel_masker
+    "r50_spatial1111": dict(factory="uni_resnet50", batch=32, kw=dict(
+        dyn_mode=["spatial"] * 4, mask_spatial_granularity=[1, 1, 1, 1])),
     "r50_both": dict(factory="uni_resnet50", batch=32, kw=dict(
         dyn_mode=["both"] * 4, channel_dyn_granularity=[2, 2, 2, 2], channel_masker=["MLP"] * 4,
         channel_masker_layers=[2, 2, 2, 2], mask_spatial_granularity=[4, 4, 2, 1])),
@@ -178,6 +181,40 @@ def test_spatial_and_layer_bs64_masker_produced_masks(name, math_mode):
     if math_mode == "bf16x3":
         assert fused >= 20, f"only {fused} blocks decided from pooled means: the fused masker is not on the tested path"
     _check(got, want, f"{name} bs64 own masks/{math_mode}")
+
+
+def test_per_pixel_masks_bs32_masker_produced_masks(math_mode):
+    """BASELINE configs[0]'s model on the GPU (LAUD-ResNet50, spatial granularity 1-1-1-1: one decision per pixel): the
+    maskers run on k_pixel_masker, every block reads x for its decision (there are no pooled means to carry).  The masks the HIP path produced
+    itself, replayed into the oracle: plain 1e-3; and the decisions against the oracle's own maskers on the same block inputs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from laudnet_amd import ops
+    _set_mode(math_mode)
+    name = "r50_spatial1111"
+    hip, ref, x = _pair(name)
+    bench.calibrate_maskers(hip, x, None, 0.5)
+    ref.load_state_dict({k: v.detach().clone() for k, v in hip.state_dict().items()})
+    with torch.no_grad():
+        got = hip(x, 1.0)
+        kept = []
+        for hb, rb in zip(_hip_blocks(hip), _ref_blocks(ref)):
+            assert hb.last_spatial_mask.shape[-1] == hb.masker_spatial.mask_size and not hb.last_fused_decision
+            rb.forced_spatial_mask = hb.last_spatial_mask.clone()
+            kept.append(float(hb.last_spatial_mask.mean()))
+        want = ref(x, 1.0)
+    torch.cuda.synchronize()
+    assert 0.2 < sum(kept) / len(kept) < 0.7, "calibration failed: the test must run near the target-0.5 operating point"
+    _check(got, want, f"{name} bs32 own masks/{math_mode}")
+    if math_mode == "bf16x3":
+        for rb in _ref_blocks(ref):
+            rb.forced_spatial_mask = None
+        res = bench.audit_masker_decisions(hip, ref, x, ops, "fp32")
+        print("masker decision audit", name, res)
+        for mode, r in res.items():
+            assert r["decisions_total"] > 0
+            assert r["decisions_differing_from_oracle_maskers"] <= 5e-4 * r["decisions_total"], (mode, r)
+            assert r["largest_oracle_logit_margin_at_a_differing_decision"] <= 2e-3, (mode, r)
 
 
 @pytest.mark.parametrize("name", ["r101_channel2222", "r101_spatial4421", "r101_layer"])

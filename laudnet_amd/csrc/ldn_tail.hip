@@ -605,6 +605,19 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     const int trw = lane >> 3, tc = lane & 7;                  // epilogue layout: lane = (row trw + 8 it, 4 channels at 4 tc)
     const unsigned a3_lane = (unsigned)(2 * h * W3_ROW + l31 * 8);
     float* const scr = reinterpret_cast<float*>(s_scr + wave * 4096);   // this wave's 32 x 32 transpose scratch
+    // PROJ: the lane's pixel of the block input, pre-split (K16 step s = octet 2 s + h: 8 hi | 8 lo), loaded ONCE for all chunks (round 6: re-loaded per
+    // 32-channel chunk -- eight times -- these 8 KB per wave were assumed L2 hits and are not: profiles/r06_pmc_stage12.txt, FETCH x 2 = 1.67 GB per launch
+    // against 0.52 GB of h1 + input; the launch's own output stream evicts them)
+    bf16x8 pjh[PROJ ? T_PROJ_CIN / 16 : 1], pjl[PROJ ? T_PROJ_CIN / 16 : 1];
+    if constexpr (PROJ) {
+        const long q = out_row0 + min(wave * 32 + l31, npix - 1);
+        const unsigned char* xr = p.pxs + (q >> 5) * ((long)T_PROJ_CIN * 128) + (q & 31) * 16 + h * 1024;
+#pragma unroll
+        for (int s2 = 0; s2 < T_PROJ_CIN / 16; ++s2) {
+            pjh[s2] = *reinterpret_cast<const bf16x8*>(xr + s2 * 2048);
+            pjl[s2] = *reinterpret_cast<const bf16x8*>(xr + s2 * 2048 + 512);
+        }
+    }
     for (int cc = 0; cc < nchunk3; ++cc) {
         if (cc == 0) { wait_vm<0>(); lds_barrier(); }           // W3(0) is in LDS for every wave
         if (cc + 1 < nchunk3) dma_w3(cc + 1);                   // slot (cc + 1) & 1: every wave left it before the last barrier
@@ -614,17 +627,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
             const int c0 = cc * CW + cs * 32;
             // residual tile in the layout the epilogue stores in, requested before the K loop that hides its latency
             f32x4 res[PROJ ? 1 : 4];
-            bf16x8 pjh[PROJ ? T_PROJ_CIN / 16 : 1], pjl[PROJ ? T_PROJ_CIN / 16 : 1];
-            if constexpr (PROJ) {
-                // the lane's pixel of the block input, pre-split: K16 step s = octet 2 s + h (8 hi | 8 lo); L2 hits after the first sub-pass
-                const long q = out_row0 + min(wave * 32 + l31, npix - 1);
-                const unsigned char* xr = p.pxs + (q >> 5) * ((long)T_PROJ_CIN * 128) + (q & 31) * 16 + h * 1024;
-#pragma unroll
-                for (int s2 = 0; s2 < T_PROJ_CIN / 16; ++s2) {
-                    pjh[s2] = *reinterpret_cast<const bf16x8*>(xr + s2 * 2048);
-                    pjl[s2] = *reinterpret_cast<const bf16x8*>(xr + s2 * 2048 + 512);
-                }
-            } else {
+            if constexpr (!PROJ) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int prow = wave * 32 + trw + 8 * it;

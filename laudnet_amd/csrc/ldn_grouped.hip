@@ -119,6 +119,7 @@ struct GiArgs {
     int Hi, Wi, Ho, Wo, stride;
     int gchunk, in_ld;                      // groups per workgroup; floats per staged pixel (16 gchunk + 4)
     int R, nbands;                          // output rows per workgroup (Ho: the whole image), bands per image
+    int images_cap;                         // images the launch covers (workgroups = (image, band) pairs x group chunks, see the kernel)
     float* gap;                             // optional [kept image][band][C]: channel sums of this launch's FINAL output over the band's pixels
                                             // (the squeeze of the SE block that follows conv b, laud_regnet.py:194: no second pass over h_b)
 };
@@ -144,12 +145,19 @@ __global__ __launch_bounds__(512, 2) void k_grouped16_img(const GiArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = p.C / 16;
-    const int band = blockIdx.x % p.nbands;
-    const int g0 = (blockIdx.x / p.nbands) * p.gchunk;
+    // Workgroup order (round 6): the group chunks of ONE (image, band) pair take linear ids L, L + 8, L + 16, ... -- consecutive workgroups of ONE XCD
+    // (block b runs on XCD b % 8).  With one group per workgroup (the banded form: 64 bytes of every 128-byte line of a staged pixel) the chunks of a
+    // pair were nbands ids apart, on unrelated XCDs, and every line came over the fabric once per chunk: 926 MB fetched for 394 MB of input rows on
+    // the first block of stage 1 (profiles/r06_pmc_all_regnet_before.txt), 463 MB in this order (r06_pmc_all_regnet.txt).  The launch's time did not
+    // move (191 -> 198 us): it is not bound by the fabric; the bytes are simply no longer wasted.
+    const int nch = (G + p.gchunk - 1) / p.gchunk;
+    const int per = 8 * nch, jid = (int)(blockIdx.x % (unsigned)per);
+    const long pair = (long)(blockIdx.x / (unsigned)per) * 8 + (jid & 7);
+    const int k = (int)(pair / p.nbands), band = (int)(pair - (long)k * p.nbands);
+    const int g0 = (jid >> 3) * p.gchunk;
     const int ng = min(p.gchunk, G - g0);
     const int HWo = p.Ho * p.Wo;
-    const int k = blockIdx.y;
-    if ((long)k * HWo >= (long)p.m_count[0]) return;                       // beyond the kept images
+    if (k >= p.images_cap || (long)k * HWo >= (long)p.m_count[0]) return;   // beyond the launch's pairs / beyond the kept images
     // this workgroup's band of output rows and the input rows it reads (pad 1: one halo row on each side, inside the image)
     const int y0 = band * p.R, rows_out = min(p.R, p.Ho - y0);
     const int iy0 = max(y0 * p.stride - 1, 0), iy1 = min((y0 + rows_out - 1) * p.stride + 1, p.Hi - 1);
@@ -315,8 +323,11 @@ static int grouped16_images(const float* a, int lda, const int32_t* m_count, int
     const size_t lds = (size_t)g.gchunk * GM_FRAG + ((size_t)in_rows * Wi + 1) * g.in_ld * 4 +
                        (gap ? (size_t)g.gchunk * ceil_div(g.R * Wo, 16) * 64 : 0);        // (gap: per-tile channel sums)
     LDN_REQUIRE(allow_dynamic_lds(reinterpret_cast<const void*>(&k_grouped16_img), lds), "k_grouped16_img: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(k_grouped16_img, dim3((unsigned)(ceil_div(G, g.gchunk) * g.nbands), (unsigned)images_cap), dim3(512), lds,
-                       static_cast<hipStream_t>(stream), g);
+    g.images_cap = images_cap;
+    const long pairs = (long)images_cap * g.nbands;
+    const long nwg = (pairs + 7) / 8 * 8 * ceil_div(G, g.gchunk);
+    LDN_REQUIRE(nwg < (1l << 31), "ldn_grouped16_conv3x3_images: too many workgroups (%ld)", nwg);
+    hipLaunchKernelGGL(k_grouped16_img, dim3((unsigned)nwg), dim3(512), lds, static_cast<hipStream_t>(stream), g);
     LDN_CHECK_LAUNCH("k_grouped16_img");
     return LDN_OK;
 }

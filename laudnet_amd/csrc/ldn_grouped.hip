@@ -167,10 +167,26 @@ __global__ __launch_bounds__(512, 2) void k_grouped16_img(const GiArgs p) {
     for (int i = tid; i < ng * (GM_FRAG / 16); i += 512)
         reinterpret_cast<f32x4*>(smem)[i] = reinterpret_cast<const f32x4*>(p.wf + (size_t)g0 * GM_FRAG)[i];
     const int qpp = ng * 4;                                                // 16-byte pieces per pixel
-    for (int i = tid; i < HWi * qpp; i += 512) {
-        const int px = i / qpp, q = i - px * qpp;
-        *reinterpret_cast<f32x4*>(s_in + (size_t)px * p.in_ld + q * 4) =
-            *reinterpret_cast<const f32x4*>(p.a + (in_row0 + px) * p.lda + g0 * 16 + q * 4);
+    // (round 6) eight pieces per thread in flight: one piece at a time the staging was a chain of up to ten memory latencies per workgroup -- what the
+    // banded launches of the first blocks spent part of their time in (k_grouped16_img on RegNetY-800MF's first block, 63 KB staged per workgroup:
+    // 198 -> 172 us; the rest is 18 rounds of 9 us workgroups with ~1 us of matrix work each -- launch, zero-fill, barrier)
+    const int npiece = HWi * qpp;
+    const float inv_qpp = 1.f / (float)qpp;
+    for (int i0 = tid; i0 < npiece; i0 += 8 * 512) {
+        f32x4 v[8];
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * 512, npiece - 1);
+            int px = (int)(((float)i + 0.5f) * inv_qpp);                   // i / qpp through the reciprocal, corrected (i < 2^22)
+            int q = i - px * qpp;
+            if (q < 0) { --px; q += qpp; } else if (q >= qpp) { ++px; q -= qpp; }
+            dst[u] = px * p.in_ld + q * 4;
+            v[u] = *reinterpret_cast<const f32x4*>(p.a + (in_row0 + px) * p.lda + g0 * 16 + q * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 512 < npiece) *reinterpret_cast<f32x4*>(s_in + dst[u]) = v[u];
     }
     for (int i = tid; i < p.in_ld; i += 512) s_in[(size_t)HWi * p.in_ld + i] = 0.f;   // the zero pixel
     __syncthreads();

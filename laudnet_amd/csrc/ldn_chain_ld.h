@@ -951,15 +951,28 @@ __device__ __forceinline__ void tail_ld(const TailArgs& p, const int b, unsigned
     // ======================================================================================================== conv3 (1x1)
     {   // conversion tables (gathered through the channel list) by the seven waves that are not the loader
         const int t7 = tid;                                               // threads 0 .. 447
+        // (round 6) the gathers of five entries per thread in flight together: as plain loops hipcc emits LDS read -> global load -> s_waitcnt
+        // vmcnt(0) -> ds_write per entry -- ten memory latencies in a row per block at width 256, ~12 k of the 16 k cycles this phase took
+        constexpr int TB = 5;
         for (int i = t7; i < NP; i += 448) {
             const int ch = i < Kb ? s_kidx[i] : -1;
-            s_tab[i] = ch >= 0 ? p.sc2[ch] : 0.f;
-            s_tab[NP + i] = ch >= 0 ? p.ps2[ch] : 0.f;
+            const float a = p.sc2[max(ch, 0)], c = p.ps2[max(ch, 0)];
+            s_tab[i] = ch >= 0 ? a : 0.f;
+            s_tab[NP + i] = ch >= 0 ? c : 0.f;
         }
-        for (int i = t7; i < 16 * NP; i += 448) {
-            const int k = i / NP, n = i - k * NP;
-            const int ch = n < Kb ? s_kidx[n] : -1;
-            s_tab[2 * NP + i] = ch >= 0 ? p.sh2[k * W + ch] : 0.f;
+        for (int i0 = t7; i0 < 16 * NP; i0 += 448 * TB) {
+            float v[TB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                const int i = min(i0 + 448 * u, 16 * NP - 1);
+                const int k = i / NP, n = i - k * NP;
+                const int ch = n < Kb ? s_kidx[n] : -1;
+                const float x = p.sh2[k * W + max(ch, 0)];
+                v[u] = ch >= 0 ? x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+                if (i0 + 448 * u < 16 * NP) s_tab[2 * NP + i0 + 448 * u] = v[u];
         }
     }
     __syncthreads();       // (2) the tables are in LDS

@@ -297,11 +297,18 @@ __global__ __launch_bounds__(2 * R, 2) void k_dense(const DenseArgs p) {
         s_orow[tid] = orw;
         if (T9) s_cls[tid] = cls;
     }
-    if (T9)
-        for (int i = tid; i < D_ROWS * 9; i += NTHR) {
-            const int r = i / 9;
-            s_atap[i] = r < rows ? p.a_rows[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
+    if (T9) {      // (round 6: all of a thread's table entries requested before the first is stored -- a plain loop is one memory latency per entry)
+        constexpr int NE = (D_ROWS * 9 + NTHR - 1) / NTHR;
+        int tv[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int i = tid + NTHR * u, r = i / 9;
+            tv[u] = (i < D_ROWS * 9 && r < rows) ? p.a_rows[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
         }
+#pragma unroll
+        for (int u = 0; u < NE; ++u)
+            if (tid + NTHR * u < D_ROWS * 9) s_atap[tid + NTHR * u] = tv[u];
+    }
     __syncthreads();
 
     const bool active = wave * 32 < rows;
@@ -606,11 +613,18 @@ __global__ __launch_bounds__(512, 2) void k_dense2(const DenseArgs p) {
         s_orow[tid] = orw;
         if (T9) s_cls[tid] = cls;
     }
-    if (T9)
-        for (int i = tid; i < D_ROWS * 9; i += 512) {
-            const int r = i / 9;
-            s_atap[i] = r < rows ? p.a_rows[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
+    if (T9) {      // (round 6: all of a thread's table entries requested before the first is stored -- a plain loop is one memory latency per entry)
+        constexpr int NE = (D_ROWS * 9 + 511) / 512;
+        int tv[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int i = tid + 512 * u, r = i / 9;
+            tv[u] = (i < D_ROWS * 9 && r < rows) ? p.a_rows[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
         }
+#pragma unroll
+        for (int u = 0; u < NE; ++u)
+            if (tid + 512 * u < D_ROWS * 9) s_atap[tid + 512 * u] = tv[u];
+    }
     int goff = 0;                                         // (AG) this lane's row: offset of its image's gate vector in s_gate
     if constexpr (AG) {
         const int gld = round_up(p.cin, 32), q4 = gld >> 2;

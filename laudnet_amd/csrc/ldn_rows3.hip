@@ -86,11 +86,21 @@ __global__ __launch_bounds__(512, 2) void k_rows3(const Rows3Args p) {
     const int rows = min(R3_ROWS, M - m0);
     const int n0 = nt * NT;
 
-    for (int i = tid; i < R3_ROWS * 9; i += 512) {
-        const int r = i / 9;
-        const int v = r < rows ? p.nbr[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
-        LDN_DCHECK(v >= -1, 601);
-        s_atap[i] = v;
+    {   // the tile's neighbour table: all five entries of a thread requested before the first is stored (round 6: as a plain loop hipcc emits
+        // load -> s_waitcnt vmcnt(0) -> ds_write per entry, five memory latencies in a row in front of the first DMA of every workgroup)
+        constexpr int NE = (R3_ROWS * 9 + 511) / 512;
+        int v[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int i = tid + 512 * u, r = i / 9;
+            v[u] = (i < R3_ROWS * 9 && r < rows) ? p.nbr[(size_t)(m0 + r) * 9 + (i - r * 9)] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int i = tid + 512 * u;
+            LDN_DCHECK(v[u] >= -1, 601);
+            if (i < R3_ROWS * 9) s_atap[i] = v[u];
+        }
     }
     __syncthreads();
 

@@ -543,15 +543,29 @@ __device__ __forceinline__ void tail_body(const TailArgs& p, const int b, const 
     if (nchunk3 > 0) dma_w3(0);
 
     // ---- conversion tables (gathered through the channel list), then acc -> h2 operand fragments in registers
+    // (round 6: up to four gathers per thread in flight together -- as plain loops hipcc emits LDS read -> global load -> s_waitcnt vmcnt(0) ->
+    // ds_write per entry, 16 NP / 512 memory latencies in a row)
     for (int i = tid; i < NP; i += 512) {
         const int ch = i < Kb ? s_kidx[i] : -1;
-        s_tab[i] = ch >= 0 ? p.sc2[ch] : 0.f;
-        s_tab[NP + i] = ch >= 0 ? p.ps2[ch] : 0.f;
+        const float a = p.sc2[max(ch, 0)], c = p.ps2[max(ch, 0)];
+        s_tab[i] = ch >= 0 ? a : 0.f;
+        s_tab[NP + i] = ch >= 0 ? c : 0.f;
     }
-    for (int i = tid; i < 16 * NP; i += 512) {
-        const int k = i / NP, n = i - k * NP;
-        const int ch = n < Kb ? s_kidx[n] : -1;
-        s_tab[2 * NP + i] = ch >= 0 ? p.sh2[k * W + ch] : 0.f;
+    {
+        constexpr int TB = (16 * NP / 512) < 4 ? (16 * NP / 512) : 4;
+        for (int i0 = tid; i0 < 16 * NP; i0 += 512 * TB) {
+            float v[TB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                const int i = i0 + 512 * u;                       // (16 NP is a multiple of 512 TB: no ragged pass)
+                const int k = i / NP, n = i - k * NP;
+                const int ch = n < Kb ? s_kidx[n] : -1;
+                const float x = p.sh2[k * W + max(ch, 0)];
+                v[u] = ch >= 0 ? x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < TB; ++u) s_tab[2 * NP + i0 + 512 * u] = v[u];
+        }
     }
     lds_barrier();
     // In place: the 16 fp32 accumulators of n-subtile j become 16 dwords of bf16 pairs -- for each K16 step t of conv3
